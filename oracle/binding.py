@@ -1,0 +1,150 @@
+"""ctypes bindings for the CPU oracle (TEST INFRASTRUCTURE).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product package ``lidar_transfer_amd`` never does.
+
+* :func:`oracle_trace`  -- our C restatement (oracle/lt_oracle.c)
+* :func:`ref_trace`     -- the REAL reference ``ctrace`` (RayTracer.cpp:116-124) compiled
+  from /root/reference into ``oracle/_ref/*.so`` by ``oracle/Makefile``
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+MODE_REF_BVH, MODE_BRUTE, MODE_LBVH = 0, 1, 2
+NORM_SSE, NORM_EXACT = 0, 1
+
+
+class Stats(C.Structure):
+    _fields_ = [("t_setup_ms", C.c_double), ("t_build_ms", C.c_double), ("t_trace_ms", C.c_double),
+                ("nodes_popped", C.c_longlong), ("tris_tested", C.c_longlong), ("box_tests", C.c_longlong),
+                ("n_nodes", C.c_int), ("n_leaves", C.c_int), ("max_stack", C.c_int), ("n_hits", C.c_int)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(quiet: bool = True) -> None:
+    """(Re)build liblt_oracle.so and, when /root/reference is present, oracle/_ref."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+_oracle = None
+_refs = {}
+
+
+def _lib():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(HERE, "liblt_oracle.so")
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        lib.lto_trace.argtypes = [fp, fp, fp, ip, ip, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip, fp, fp, ip,
+                                  C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(Stats)]
+        lib.lto_trace.restype = C.c_int
+        lib.lto_normalize_rays.argtypes = [fp, C.c_int, C.c_int, fp]
+        lib.lto_normalize_rays.restype = None
+        lib.lto_num_threads.restype = C.c_int
+        _oracle = lib
+    return _oracle
+
+
+def ref_available(kind: str = "strict") -> bool:
+    return os.path.exists(os.path.join(HERE, "_ref", f"libref_{kind}.so"))
+
+
+def _ref(kind: str):
+    if kind not in _refs:
+        lib = C.CDLL(os.path.join(HERE, "_ref", f"libref_{kind}.so"))
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        lib.ctrace.argtypes = [fp, fp, fp, ip, ip, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip, fp, fp]
+        lib.ctrace.restype = None
+        _refs[kind] = lib
+    return _refs[kind]
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _outputs(n_rays):
+    return dict(endpoints=np.zeros(3 * n_rays, np.float32), endcolors=np.zeros(3 * n_rays, np.int32),
+                range=np.zeros(n_rays, np.float32), endrem=np.zeros(n_rays, np.float32))
+
+
+def oracle_trace(rays, origin, verts, faces, colors, rem, H, mode=MODE_REF_BVH, norm=NORM_EXACT, nthreads=0,
+                 pad=0.0):
+    """Run the restatement; returns dict(endpoints [R,3], endcolors [R,3], range [R], endrem [R], tri [R], stats)."""
+    lib = _lib()
+    rays_a, rays_p = _f(rays)
+    org_a, org_p = _f(origin)
+    v_a, v_p = _f(verts)
+    f_a, f_p = _i(faces)
+    c_a, c_p = _i(colors)
+    r_a, r_p = _f(rem)
+    n_rays = rays_a.size // 3
+    out = _outputs(n_rays)
+    tri = np.full(n_rays, -1, np.int32)
+    st = Stats()
+    rc = lib.lto_trace(rays_p, org_p, v_p, f_p, c_p, r_p, n_rays, v_a.size // 3, f_a.size // 3, int(H),
+                       out["endpoints"].ctypes.data_as(C.POINTER(C.c_float)),
+                       out["endcolors"].ctypes.data_as(C.POINTER(C.c_int)),
+                       out["range"].ctypes.data_as(C.POINTER(C.c_float)),
+                       out["endrem"].ctypes.data_as(C.POINTER(C.c_float)),
+                       tri.ctypes.data_as(C.POINTER(C.c_int)), int(mode), int(norm), int(nthreads), float(pad),
+                       C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"lto_trace failed rc={rc}")
+    out["endpoints"] = out["endpoints"].reshape(-1, 3)
+    out["endcolors"] = out["endcolors"].reshape(-1, 3)
+    out["tri"] = tri
+    out["stats"] = st.asdict()
+    return out
+
+
+def ref_trace(rays, origin, verts, faces, colors, rem, H, kind="strict"):
+    """Run the real reference ``ctrace``; same dict minus ``tri``/``stats`` (stdout chatter is the reference's)."""
+    lib = _ref(kind)
+    rays_a, rays_p = _f(rays)
+    org_a, org_p = _f(origin)
+    v_a, v_p = _f(verts)
+    f_a, f_p = _i(faces)
+    c_a, c_p = _i(colors)
+    r_a, r_p = _f(rem)
+    n_rays = rays_a.size // 3
+    out = _outputs(n_rays)
+    lib.ctrace(rays_p, org_p, v_p, f_p, c_p, r_p, n_rays, v_a.size // 3, f_a.size // 3, int(H),
+               out["endpoints"].ctypes.data_as(C.POINTER(C.c_float)),
+               out["endcolors"].ctypes.data_as(C.POINTER(C.c_int)),
+               out["range"].ctypes.data_as(C.POINTER(C.c_float)),
+               out["endrem"].ctypes.data_as(C.POINTER(C.c_float)))
+    out["endpoints"] = out["endpoints"].reshape(-1, 3)
+    out["endcolors"] = out["endcolors"].reshape(-1, 3)
+    return out
+
+
+def normalize_rays(rays, norm=NORM_EXACT):
+    lib = _lib()
+    rays_a, rays_p = _f(rays)
+    out = np.zeros_like(rays_a)
+    lib.lto_normalize_rays(rays_p, rays_a.size // 3, int(norm), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out.reshape(-1, 3)
+
+
+def num_threads() -> int:
+    return int(_lib().lto_num_threads())
