@@ -1,0 +1,133 @@
+/*
+ * lidarhip.h -- C ABI of liblidarhip.so, the MI355X (gfx950) virtual-LiDAR ray-cast path.
+ *
+ * Drop-in boundary for PRBonn/lidar_transfer's native raytracer: every entry point below names
+ * the reference interface it replaces (paths relative to the reference repository).  Plain C
+ * types only -- pointers, sizes, an opaque handle -- so the library can be bound from ctypes,
+ * Cython, cgo, JNI ... exactly where the reference binds `ctrace`
+ * (auxiliary/raytracer/RayTracerCython.pyx:5-7).
+ *
+ * Conventions
+ *   - every function returns an int status: LT_OK (0) or a negative LT_ERR_* code; the message
+ *     of the last failure on the calling thread is available from lt_last_error();
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device pointers on the
+ *     scene's device (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - array layouts are the reference's: all arrays flat and C-contiguous, rays / endpoints /
+ *     endcolors at 3*(W*j + i), range / endrem / tri at W*j + i, W = n_rays / height
+ *     (auxiliary/raytracer/RayTracer.cpp:56, :65, :86-89); `colors` holds 3 ints per VERTEX and
+ *     only vertex 0 of the hit face is reported (RayTracer.cpp:75, Triangle.h:56-61).
+ */
+#ifndef LIDARHIP_H
+#define LIDARHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_OK 0
+#define LT_ERR_INVALID_ARG (-1)  /* NULL pointer, negative size, height <= 0 ...                      */
+#define LT_ERR_NO_MEMORY (-2)    /* hipMalloc failed                                                  */
+#define LT_ERR_HIP (-3)          /* any other HIP runtime error (message has the HIP error string)    */
+#define LT_ERR_BAD_INDEX (-4)    /* a face references a vertex outside [0, n_verts)                   */
+#define LT_ERR_NOT_BUILT (-5)    /* trace requested before lt_scene_build                             */
+#define LT_ERR_TOO_LARGE (-6)    /* more than LT_MAX_FACES triangles                                  */
+
+#define LT_MAX_FACES (1 << 28)
+
+/* trace flags */
+#define LT_TRACE_WRITE_MISSES 1u /* write 0 / tri = -1 for rays that hit nothing (otherwise outputs   */
+                                 /* are left untouched for misses, as in RayTracer.cpp:73)            */
+#define LT_TRACE_COUNT 2u        /* accumulate nodes visited / triangles tested into the scene stats  */
+
+/* Per-phase timings (hipEvent, milliseconds) and work counters of the last build / trace of a scene. */
+typedef struct lt_stats {
+  float ms_bounds;     /* scene bounds reduction                                        */
+  float ms_morton;     /* centroid Morton codes                                         */
+  float ms_sort;       /* LSD radix sort (4 passes)                                     */
+  float ms_gather;     /* sorted triangle records + padded leaf boxes                   */
+  float ms_segtree;    /* min/max segment tree over the leaf boxes                      */
+  float ms_hierarchy;  /* Karras topology + child boxes                                 */
+  float ms_build;      /* whole build, first to last kernel                             */
+  float ms_trace;      /* ray-cast kernel                                               */
+  int n_faces;
+  int n_nodes;         /* node slots (n_faces - 1)                                      */
+  int n_rays;
+  int n_hits;          /* valid after a LT_TRACE_COUNT trace                            */
+  unsigned long long nodes_visited; /* internal nodes fetched, summed over rays         */
+  unsigned long long tris_tested;   /* Moller-Trumbore evaluations, summed over rays    */
+  unsigned long long stack_overflows; /* rays that spilled past the LDS stack           */
+} lt_stats;
+
+typedef struct lt_scene lt_scene; /* opaque: device workspace + BVH of one mesh */
+
+/* ---- one-call drop-in ----------------------------------------------------------------------- */
+
+/*
+ * lt_ctrace -- same 14 parameters, order and meaning as the reference's
+ *   extern "C" void ctrace(float* rays, float* origin, float* verts, int* faces, int* colors,
+ *                          float* rem, int n_rays, int n_verts, int n_faces, int height,
+ *                          float* endpoints, int* endcolors, float* range, float* endrem)
+ * (auxiliary/raytracer/RayTracer.cpp:116-124), but returns a status instead of void.
+ * All pointers are HOST pointers; the call uploads the mesh and rays to the current HIP device,
+ * builds the BVH, casts the rays and copies the four outputs back.  As in the reference, outputs
+ * are written only for rays that hit (the caller pre-zeroes them, fusion_lidar.py:440-447).
+ */
+int lt_ctrace(const float* rays, const float* origin, const float* verts, const int* faces,
+              const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
+              float* endpoints, int* endcolors, float* range, float* endrem);
+
+/* As lt_ctrace, plus the hit-triangle image `tri` (face index, -1 = miss; may be NULL) and
+ * optional statistics (may be NULL).  The reference has no triangle output (IntersectionInfo.h:9-13
+ * keeps the object pointer internal). */
+int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
+                 const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
+                 float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                 lt_stats* stats);
+
+/* ---- split API: build once, trace many, device-resident buffers ----------------------------- */
+
+/* Create an empty scene on HIP device `device` (-1 = current device).  Replaces the per-call
+ * `vector<Object*> objects` + `BVH bvh(&objects)` of RayTracer.cpp:22, :54. */
+int lt_scene_create(lt_scene** scene, int device);
+
+/* Attach a mesh given as DEVICE pointers (borrowed: they must stay valid until the last trace of
+ * this mesh has completed).  Replaces the triangle de-indexing loop RayTracer.cpp:32-51. */
+int lt_scene_set_mesh_dev(lt_scene* scene, const float* verts, const int* faces, const int* colors,
+                          const float* rem, int n_verts, int n_faces);
+
+/* Same from HOST pointers: the scene copies the mesh into device buffers it owns. */
+int lt_scene_set_mesh_host(lt_scene* scene, const float* verts, const int* faces, const int* colors,
+                           const float* rem, int n_verts, int n_faces, void* stream);
+
+/* Build the linear BVH (Morton codes -> radix sort -> Karras topology -> child boxes) on `stream`.
+ * Asynchronous unless `stats` is non-NULL (then it synchronises and fills the ms_* fields).
+ * Replaces BVH::BVH / BVH::build (auxiliary/raytracer/BVH.cpp:116-126, :143-243). */
+int lt_scene_build(lt_scene* scene, void* stream, lt_stats* stats);
+
+/* Cast n_rays rays (DEVICE pointer, [n_rays,3] f32, normalised inside like Vector3.h:73-89) from
+ * `origin` (HOST pointer to 3 floats) against the built scene on `stream`; outputs are DEVICE
+ * pointers, any of them may be NULL.  Asynchronous unless `stats` is non-NULL.
+ * Replaces the OpenMP ray loop RayTracer.cpp:62-92 incl. BVH::getIntersection (BVH.cpp:19-110). */
+int lt_scene_trace_dev(lt_scene* scene, const float* rays, const float* origin, int n_rays, int height,
+                       float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                       unsigned flags, void* stream, lt_stats* stats);
+
+/* Synchronise the scene's last stream and report deferred device-side errors (LT_ERR_BAD_INDEX). */
+int lt_scene_status(lt_scene* scene);
+
+/* Free the workspace.  Replaces the delete loop RayTracer.cpp:110-113 and BVH::~BVH (BVH.cpp:112-114). */
+int lt_scene_destroy(lt_scene* scene);
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char* lt_last_error(void);
+
+/* Library version string, e.g. "lidarhip 0.1 (gfx950)". */
+const char* lt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARHIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of liblidarhip.so -- the C ABI declared in include/lidarhip.h.
+
+There is deliberately NO fallback: if the HIP library is missing or a call
+fails, a ``RuntimeError`` is raised.  Nothing in this package computes the hot
+path on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+LT_OK = 0
+LT_TRACE_WRITE_MISSES = 1
+LT_TRACE_COUNT = 2
+
+#: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
+           "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy", "lt_last_error",
+           "lt_version"]
+
+
+class Stats(C.Structure):
+    """Mirror of ``lt_stats`` (include/lidarhip.h)."""
+    _fields_ = [("ms_bounds", C.c_float), ("ms_morton", C.c_float), ("ms_sort", C.c_float),
+                ("ms_gather", C.c_float), ("ms_segtree", C.c_float), ("ms_hierarchy", C.c_float),
+                ("ms_build", C.c_float), ("ms_trace", C.c_float), ("n_faces", C.c_int), ("n_nodes", C.c_int),
+                ("n_rays", C.c_int), ("n_hits", C.c_int), ("nodes_visited", C.c_ulonglong),
+                ("tris_tested", C.c_ulonglong), ("stack_overflows", C.c_ulonglong)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the sources are newer) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.needs_build():
+        try:
+            _build.build_lib()
+        except RuntimeError as e:  # no hipcc: a prebuilt library is acceptable, nothing else is
+            if not os.path.exists(path):
+                raise RuntimeError(f"liblidarhip.so is missing and cannot be built: {e}") from e
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64.  If the system copy were loaded first (as a dependency of liblidarhip.so)
+    # and torch's second, torch would find "No HIP GPUs".  Importing torch first makes the dynamic
+    # linker resolve our DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise RuntimeError(f"cannot load {path}: {e}") from e
+    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+    sp = C.POINTER(Stats)
+    lib.lt_ctrace.argtypes = [fp, fp, fp, ip, ip, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip, fp, fp]
+    lib.lt_ctrace_ex.argtypes = lib.lt_ctrace.argtypes + [ip, sp]
+    lib.lt_scene_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.lt_scene_set_mesh_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    lib.lt_scene_set_mesh_host.argtypes = [vp, fp, ip, ip, fp, C.c_int, C.c_int, vp]
+    lib.lt_scene_build.argtypes = [vp, vp, sp]
+    lib.lt_scene_trace_dev.argtypes = [vp, vp, fp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint, vp, sp]
+    lib.lt_scene_status.argtypes = [vp]
+    lib.lt_scene_destroy.argtypes = [vp]
+    for name in ("lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
+                 "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy"):
+        getattr(lib, name).restype = C.c_int
+    lib.lt_last_error.restype = C.c_char_p
+    lib.lt_version.restype = C.c_char_p
+    if hasattr(lib, "lt_create_rays_dev"):
+        lib.lt_create_rays_dev.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
+        lib.lt_create_rays_dev.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "liblidarhip") -> None:
+    if rc != LT_OK:
+        msg = load().lt_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,324 @@
+// lt_api.hip -- C-ABI entry points of liblidarhip.so (declared in include/lidarhip.h).
+#include "lt_internal.h"
+#include <mutex>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void lt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* lt_last_error(void) { return g_err; }
+extern "C" const char* lt_version(void) { return "lidarhip 0.1 (gfx950)"; }
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  LT_HIP(hipMalloc((void**)p, count * sizeof(T)));
+  return LT_OK;
+}
+
+static void ws_free(lt_scene* s) {
+  for (int k = 0; k < 2; ++k) {
+    if (s->keys[k]) (void)hipFree(s->keys[k]);
+    if (s->vals[k]) (void)hipFree(s->vals[k]);
+    s->keys[k] = s->vals[k] = nullptr;
+  }
+  if (s->hist) (void)hipFree(s->hist);
+  if (s->tris) (void)hipFree(s->tris);
+  if (s->seg) (void)hipFree(s->seg);
+  if (s->nodes) (void)hipFree(s->nodes);
+  s->hist = nullptr; s->tris = nullptr; s->seg = nullptr; s->nodes = nullptr;
+  s->cap_faces = 0;
+}
+
+int lt_scene_reserve(lt_scene* s, int n_faces) {
+  if (n_faces <= s->cap_faces) return LT_OK;
+  LT_HIP(hipSetDevice(s->device));
+  if (s->last_stream || s->cap_faces) LT_HIP(hipDeviceSynchronize());
+  ws_free(s);
+  size_t cap = (size_t)n_faces + (size_t)n_faces / 4 + 1024;  // headroom: meshes of a sequence vary in size
+  if (cap > (size_t)LT_MAX_FACES) cap = LT_MAX_FACES;
+  size_t np = 1;
+  while (np < cap) np <<= 1;
+  const size_t nb = (cap + LT_SORT_TILE - 1) / LT_SORT_TILE;
+  for (int k = 0; k < 2; ++k) {
+    LT_CHECK(dev_alloc(&s->keys[k], cap));
+    LT_CHECK(dev_alloc(&s->vals[k], cap));
+  }
+  LT_CHECK(dev_alloc(&s->hist, 256 * nb));
+  LT_CHECK(dev_alloc(&s->tris, 3 * cap));
+  LT_CHECK(dev_alloc(&s->seg, 4 * np));
+  LT_CHECK(dev_alloc(&s->nodes, 4 * cap));
+  s->cap_faces = (int)cap;
+  return LT_OK;
+}
+
+int lt_scene_reserve_rays(lt_scene* s, int n_rays) {
+  if (n_rays <= s->cap_rays) return LT_OK;
+  LT_HIP(hipSetDevice(s->device));
+  if (s->overflow) {
+    LT_HIP(hipDeviceSynchronize());
+    (void)hipFree(s->overflow);
+    s->overflow = nullptr;
+  }
+  LT_CHECK(dev_alloc(&s->overflow, (size_t)n_rays * (LT_STACK_MAX - LT_STACK_LDS)));
+  s->cap_rays = n_rays;
+  return LT_OK;
+}
+
+extern "C" int lt_scene_create(lt_scene** out, int device) {
+  if (!out) {
+    lt_set_error("lt_scene_create: NULL out pointer");
+    return LT_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  if (device < 0) LT_HIP(hipGetDevice(&device));
+  LT_HIP(hipSetDevice(device));
+  lt_scene* s = (lt_scene*)calloc(1, sizeof(lt_scene));
+  if (!s) {
+    lt_set_error("lt_scene_create: out of host memory");
+    return LT_ERR_NO_MEMORY;
+  }
+  s->device = device;
+  int rc = dev_alloc(&s->partial, 6 * LT_BOUNDS_BLOCKS);
+  if (rc == LT_OK) rc = dev_alloc(&s->params, 8);
+  if (rc == LT_OK) rc = dev_alloc(&s->flags, 4);
+  if (rc == LT_OK) rc = dev_alloc(&s->counters, 4);
+  if (rc == LT_OK && hipMemset(s->flags, 0, 4 * sizeof(unsigned)) != hipSuccess) rc = LT_ERR_HIP;
+  for (int k = 0; rc == LT_OK && k < 10; ++k) {
+    if (hipEventCreate(&s->ev[k]) != hipSuccess) {
+      lt_set_error("hipEventCreate failed");
+      rc = LT_ERR_HIP;
+    } else {
+      s->have_events = k + 1;
+    }
+  }
+  if (rc != LT_OK) {
+    lt_scene_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return LT_OK;
+}
+
+extern "C" int lt_scene_destroy(lt_scene* s) {
+  if (!s) return LT_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipDeviceSynchronize();
+  ws_free(s);
+  if (s->owned_mesh) (void)hipFree(s->owned_mesh);
+  if (s->partial) (void)hipFree(s->partial);
+  if (s->params) (void)hipFree(s->params);
+  if (s->flags) (void)hipFree(s->flags);
+  if (s->counters) (void)hipFree(s->counters);
+  if (s->overflow) (void)hipFree(s->overflow);
+  for (int k = 0; k < s->have_events; ++k) (void)hipEventDestroy(s->ev[k]);
+  free(s);
+  return LT_OK;
+}
+
+static int check_mesh_args(const char* who, const void* verts, const void* faces, const void* colors,
+                           const void* rem, int n_verts, int n_faces) {
+  if (n_verts < 0 || n_faces < 0 || (n_faces > 0 && (!verts || !faces || !colors || !rem))) {
+    lt_set_error("%s: invalid mesh (n_verts=%d n_faces=%d, NULL array?)", who, n_verts, n_faces);
+    return LT_ERR_INVALID_ARG;
+  }
+  if (n_faces >= LT_MAX_FACES) {
+    lt_set_error("%s: %d faces exceed LT_MAX_FACES", who, n_faces);
+    return LT_ERR_TOO_LARGE;
+  }
+  return LT_OK;
+}
+
+extern "C" int lt_scene_set_mesh_dev(lt_scene* s, const float* verts, const int* faces, const int* colors,
+                                     const float* rem, int n_verts, int n_faces) {
+  if (!s) {
+    lt_set_error("lt_scene_set_mesh_dev: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_CHECK(check_mesh_args("lt_scene_set_mesh_dev", verts, faces, colors, rem, n_verts, n_faces));
+  s->verts = verts; s->faces = faces; s->colors = colors; s->rem = rem;
+  s->n_verts = n_verts; s->n_faces = n_faces;
+  s->built = 0;
+  return LT_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int lt_scene_set_mesh_host(lt_scene* s, const float* verts, const int* faces, const int* colors,
+                                      const float* rem, int n_verts, int n_faces, void* stream_) {
+  if (!s) {
+    lt_set_error("lt_scene_set_mesh_host: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_CHECK(check_mesh_args("lt_scene_set_mesh_host", verts, faces, colors, rem, n_verts, n_faces));
+  hipStream_t stream = (hipStream_t)stream_;
+  LT_HIP(hipSetDevice(s->device));
+  const size_t bv = align256((size_t)n_verts * 12), bf = align256((size_t)n_faces * 12), bc = bv,
+               br = align256((size_t)n_verts * 4);
+  const size_t total = bv + bf + bc + br + 256;
+  if (total > s->owned_mesh_bytes) {
+    if (s->owned_mesh) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(s->owned_mesh);
+      s->owned_mesh = nullptr;
+      s->owned_mesh_bytes = 0;
+    }
+    LT_HIP(hipMalloc(&s->owned_mesh, total + total / 4));
+    s->owned_mesh_bytes = total + total / 4;
+  }
+  char* base = (char*)s->owned_mesh;
+  float* dv = (float*)base;
+  int* df = (int*)(base + bv);
+  int* dc = (int*)(base + bv + bf);
+  float* dr = (float*)(base + bv + bf + bc);
+  if (n_verts > 0) {
+    LT_HIP(hipMemcpyAsync(dv, verts, (size_t)n_verts * 12, hipMemcpyHostToDevice, stream));
+    if (colors) LT_HIP(hipMemcpyAsync(dc, colors, (size_t)n_verts * 12, hipMemcpyHostToDevice, stream));
+    if (rem) LT_HIP(hipMemcpyAsync(dr, rem, (size_t)n_verts * 4, hipMemcpyHostToDevice, stream));
+  }
+  if (n_faces > 0) LT_HIP(hipMemcpyAsync(df, faces, (size_t)n_faces * 12, hipMemcpyHostToDevice, stream));
+  s->verts = dv; s->faces = df; s->colors = dc; s->rem = dr;
+  s->n_verts = n_verts; s->n_faces = n_faces;
+  s->built = 0;
+  s->last_stream = stream;
+  return LT_OK;
+}
+
+extern "C" int lt_scene_build(lt_scene* s, void* stream, lt_stats* stats) {
+  if (!s) {
+    lt_set_error("lt_scene_build: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_HIP(hipSetDevice(s->device));
+  return lt_build_launch(s, (hipStream_t)stream, stats);
+}
+
+extern "C" int lt_scene_trace_dev(lt_scene* s, const float* rays, const float* origin, int n_rays, int height,
+                                  float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                                  unsigned flags, void* stream, lt_stats* stats) {
+  if (!s) {
+    lt_set_error("lt_scene_trace_dev: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_HIP(hipSetDevice(s->device));
+  return lt_trace_launch(s, rays, origin, n_rays, height, endpoints, endcolors, range, endrem, tri, flags,
+                         (hipStream_t)stream, stats);
+}
+
+extern "C" int lt_scene_status(lt_scene* s) {
+  if (!s) {
+    lt_set_error("lt_scene_status: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_HIP(hipSetDevice(s->device));
+  LT_HIP(hipStreamSynchronize(s->last_stream));
+  unsigned f = 0;
+  LT_HIP(hipMemcpy(&f, s->flags, sizeof(f), hipMemcpyDeviceToHost));
+  if (f) LT_HIP(hipMemset(s->flags, 0, sizeof(unsigned)));
+  if (f & LT_FLAG_BAD_INDEX) {
+    lt_set_error("mesh has faces referencing vertices outside [0, n_verts); those faces were ignored");
+    return LT_ERR_BAD_INDEX;
+  }
+  return LT_OK;
+}
+
+// ---- one-call drop-in for the reference's ctrace -------------------------------------------------------
+// A process-wide scratch scene (workspace + staging buffers) is kept between calls so that a
+// sequence of scans does not pay hipMalloc every time; calls are serialised like the reference's
+// (Cython holds the GIL around ctrace, RayTracerCython.pyx:30-33).
+static std::mutex g_mu;
+static lt_scene* g_scene = nullptr;
+static int g_scene_dev = -1;
+static void* g_io = nullptr;
+static size_t g_io_bytes = 0;
+
+extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
+                            const int* colors, const float* rem, int n_rays, int n_verts, int n_faces,
+                            int height, float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                            lt_stats* stats) {
+  if (height <= 0 || n_rays < 0 || !origin || (n_rays > 0 && !rays)) {
+    lt_set_error("lt_ctrace: invalid argument (n_rays=%d height=%d)", n_rays, height);
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_CHECK(check_mesh_args("lt_ctrace", verts, faces, colors, rem, n_verts, n_faces));
+  std::lock_guard<std::mutex> lock(g_mu);
+  int dev = 0;
+  LT_HIP(hipGetDevice(&dev));
+  if (g_scene && g_scene_dev != dev) {
+    lt_scene_destroy(g_scene);
+    g_scene = nullptr;
+    if (g_io) (void)hipFree(g_io);
+    g_io = nullptr;
+    g_io_bytes = 0;
+  }
+  if (!g_scene) {
+    LT_CHECK(lt_scene_create(&g_scene, dev));
+    g_scene_dev = dev;
+  }
+  lt_scene* s = g_scene;
+  hipStream_t stream = nullptr;
+  const int W = n_rays / height;
+  const size_t R = (size_t)W * height;
+  // staging: rays | endpoints | endcolors | range | endrem | tri
+  const size_t b3 = align256(R * 12), b1 = align256(R * 4);
+  const size_t total = 3 * b3 + 3 * b1 + 256;
+  if (total > g_io_bytes) {
+    if (g_io) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(g_io);
+      g_io = nullptr;
+      g_io_bytes = 0;
+    }
+    LT_HIP(hipMalloc(&g_io, total));
+    g_io_bytes = total;
+  }
+  char* io = (char*)g_io;
+  float* d_rays = (float*)io;
+  float* d_end = (float*)(io + b3);
+  int* d_col = (int*)(io + 2 * b3);
+  float* d_range = (float*)(io + 3 * b3);
+  float* d_rem = (float*)(io + 3 * b3 + b1);
+  int* d_tri = (int*)(io + 3 * b3 + 2 * b1);
+  LT_CHECK(lt_scene_set_mesh_host(s, verts, faces, colors, rem, n_verts, n_faces, stream));
+  if (R > 0) {
+    LT_HIP(hipMemcpyAsync(d_rays, rays, R * 12, hipMemcpyHostToDevice, stream));
+    // outputs are written only for hits (RayTracer.cpp:73): start from the caller's contents
+    if (endpoints) LT_HIP(hipMemcpyAsync(d_end, endpoints, R * 12, hipMemcpyHostToDevice, stream));
+    if (endcolors) LT_HIP(hipMemcpyAsync(d_col, endcolors, R * 12, hipMemcpyHostToDevice, stream));
+    if (range) LT_HIP(hipMemcpyAsync(d_range, range, R * 4, hipMemcpyHostToDevice, stream));
+    if (endrem) LT_HIP(hipMemcpyAsync(d_rem, endrem, R * 4, hipMemcpyHostToDevice, stream));
+    if (tri) LT_HIP(hipMemcpyAsync(d_tri, tri, R * 4, hipMemcpyHostToDevice, stream));
+  }
+  lt_stats st;
+  memset(&st, 0, sizeof(st));
+  LT_CHECK(lt_build_launch(s, stream, stats ? &st : nullptr));
+  LT_CHECK(lt_trace_launch(s, d_rays, origin, (int)R, height, endpoints ? d_end : nullptr,
+                           endcolors ? d_col : nullptr, range ? d_range : nullptr, endrem ? d_rem : nullptr,
+                           tri ? d_tri : nullptr, stats ? LT_TRACE_COUNT : 0u, stream, stats ? &st : nullptr));
+  if (R > 0) {
+    if (endpoints) LT_HIP(hipMemcpyAsync(endpoints, d_end, R * 12, hipMemcpyDeviceToHost, stream));
+    if (endcolors) LT_HIP(hipMemcpyAsync(endcolors, d_col, R * 12, hipMemcpyDeviceToHost, stream));
+    if (range) LT_HIP(hipMemcpyAsync(range, d_range, R * 4, hipMemcpyDeviceToHost, stream));
+    if (endrem) LT_HIP(hipMemcpyAsync(endrem, d_rem, R * 4, hipMemcpyDeviceToHost, stream));
+    if (tri) LT_HIP(hipMemcpyAsync(tri, d_tri, R * 4, hipMemcpyDeviceToHost, stream));
+  }
+  LT_HIP(hipStreamSynchronize(stream));
+  if (stats) *stats = st;
+  return lt_scene_status(s);
+}
+
+extern "C" int lt_ctrace(const float* rays, const float* origin, const float* verts, const int* faces,
+                         const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
+                         float* endpoints, int* endcolors, float* range, float* endrem) {
+  return lt_ctrace_ex(rays, origin, verts, faces, colors, rem, n_rays, n_verts, n_faces, height, endpoints,
+                      endcolors, range, endrem, nullptr, nullptr);
+}

@@ -1,0 +1,469 @@
+// lt_build.hip -- linear BVH construction on gfx950 (replaces BVH::build, reference
+// auxiliary/raytracer/BVH.cpp:143-243, and the triangle de-indexing loop RayTracer.cpp:32-51).
+//
+// Pipeline (every kernel is free of inter-workgroup communication, so the build is deterministic
+// and needs no agent-scope fences):
+//   k_bounds     vertex AABB partials per workgroup                      (HBM stream of verts)
+//   k_morton     reduce partials, centroid -> 30-bit Morton key, val = face id
+//   4 x { k_hist, k_scan, k_scatter }   stable LSD radix sort, 8-bit digits, LDS ranking
+//   k_gather     sorted triangle records (v0,e1,e2,face) + padded leaf boxes
+//   k_seg_sub / k_seg_top   min/max segment tree over the leaf boxes (coalesced AABB reduction)
+//   k_hierarchy  Karras radix-tree topology by binary search on the sorted keys; both child
+//                boxes of every node come from O(log) segment-tree range queries
+#include "lt_internal.h"
+#include <math.h>
+
+#define WAVE 64
+
+// ---- small device helpers -----------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// block-wide reduction of 3 mins + 3 maxes; result valid in every thread
+__device__ __forceinline__ void block_bounds(float lo[3], float hi[3], float (*red)[6]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = wave_min(lo[k]);
+    hi[k] = wave_max(hi[k]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      red[wave][k] = lo[k];
+      red[wave][3 + k] = hi[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float l = red[0][k], h = red[0][3 + k];
+    for (int w = 1; w < nw; ++w) {
+      l = fminf(l, red[w][k]);
+      h = fmaxf(h, red[w][3 + k]);
+    }
+    lo[k] = l;
+    hi[k] = h;
+  }
+}
+
+// ---- scene bounds ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ verts, int n_verts,
+                                                float* __restrict__ partial) {
+  __shared__ float red[4][6];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < n_verts; v += gridDim.x * 256) {
+    const float x = verts[3 * (size_t)v], y = verts[3 * (size_t)v + 1], z = verts[3 * (size_t)v + 2];
+    lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+    hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+  }
+  block_bounds(lo, hi, red);
+  if (threadIdx.x < 3) partial[blockIdx.x * 6 + threadIdx.x] = lo[threadIdx.x];
+  else if (threadIdx.x < 6) partial[blockIdx.x * 6 + threadIdx.x] = hi[threadIdx.x - 3];
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// ---- Morton keys ----------------------------------------------------------------------------------
+// Every workgroup re-reduces the LT_BOUNDS_BLOCKS partials (6 KB from L2) instead of waiting for a
+// grid-wide result: no atomics, no second launch.  params = {lo.x, lo.y, lo.z, scale, pad}.
+__global__ __launch_bounds__(256) void k_morton(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                int n_verts, int n_faces, const float* __restrict__ partial,
+                                                float* __restrict__ params, uint32_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals, unsigned* __restrict__ flags) {
+  __shared__ float red[4][6];
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = partial[threadIdx.x * 6 + k];
+    hi[k] = partial[threadIdx.x * 6 + 3 + k];
+  }
+  block_bounds(lo, hi, red);
+  const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  const float scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float maxabs = fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(hi[0])), fmaxf(fabsf(lo[1]), fabsf(hi[1]))),
+                               fmaxf(fabsf(lo[2]), fabsf(hi[2])));
+    params[0] = lo[0]; params[1] = lo[1]; params[2] = lo[2];
+    params[3] = scale;
+    params[4] = 1e-4f + 2e-6f * maxabs;  // box padding, see DESIGN.md "conservative boxes"
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_faces) return;
+  const int a = faces[3 * (size_t)i], b = faces[3 * (size_t)i + 1], c = faces[3 * (size_t)i + 2];
+  uint32_t key = 0x3FFFFFFFu;
+  if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
+    const float* pa = verts + 3 * (size_t)a;
+    const float* pb = verts + 3 * (size_t)b;
+    const float* pc = verts + 3 * (size_t)c;
+    // centroid as the reference: (v0 + v1 + v2) / 3 (Triangle.h:78-80)
+    const float cx = ((pa[0] + pb[0]) + pc[0]) / 3.0f;
+    const float cy = ((pa[1] + pb[1]) + pc[1]) / 3.0f;
+    const float cz = ((pa[2] + pb[2]) + pc[2]) / 3.0f;
+    const uint32_t qx = (uint32_t)fminf(fmaxf((cx - lo[0]) * scale, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((cy - lo[1]) * scale, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((cz - lo[2]) * scale, 0.0f), 1023.0f);
+    key = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
+  } else {
+    atomicOr(flags, LT_FLAG_BAD_INDEX);
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+// ---- LSD radix sort, 8-bit digits -----------------------------------------------------------------
+// One workgroup owns LT_SORT_TILE consecutive keys per pass.  hist is digit-major: hist[d * nb + b].
+__global__ __launch_bounds__(LT_SORT_THREADS) void k_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                         uint32_t* __restrict__ hist, int nb) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * LT_SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < LT_SORT_TILE / LT_SORT_THREADS; ++k) {
+    const int e = base + k * LT_SORT_THREADS + threadIdx.x;
+    if (e < n) atomicAdd(&h[(keys[e] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of hist[0 .. total) in place, single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ hist, int total) {
+  __shared__ uint32_t wsum[16];
+  const int per = (total + 1023) / 1024;
+  const int s = threadIdx.x * per, e = min(s + per, total);
+  uint32_t sum = 0;
+  for (int i = s; i < e; ++i) sum += hist[i];
+  // inclusive scan across the wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, WAVE);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  uint32_t run = woff + inc - sum;
+  for (int i = s; i < e; ++i) {
+    const uint32_t v = hist[i];
+    hist[i] = run;
+    run += v;
+  }
+}
+
+// Stable scatter.  Wave w of the workgroup ranks the contiguous quarter [w*1024, (w+1)*1024) of the
+// tile in 16 rounds of 64 keys: lanes holding the same digit find each other with 8 ballots, the
+// running per-(wave, digit) count lives in LDS.  Order inside a tile is (wave, round, lane) = memory
+// order, so the sort is stable.
+__global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out, int n, int shift,
+                                                            const uint32_t* __restrict__ hist, int nb) {
+  constexpr int ROUNDS = LT_SORT_TILE / LT_SORT_THREADS;  // 16
+  constexpr int NW = LT_SORT_THREADS / 64;                 // 4
+  __shared__ uint32_t cnt[NW][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  volatile uint32_t* mycnt = cnt[wave];
+  const int base = blockIdx.x * LT_SORT_TILE + wave * (ROUNDS * 64);
+  uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = base + r * 64 + lane;
+    const bool valid = e < n;
+    key[r] = valid ? keys_in[e] : 0xFFFFFFFFu;
+    val[r] = valid ? vals_in[e] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = base + r * 64 + lane;
+    const bool valid = e < n;
+    const uint32_t digit = (key[r] >> shift) & 255u;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool b = (digit >> bit) & 1u;
+      const unsigned long long bal = __ballot(b);
+      m &= b ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t prev = mycnt[digit];
+      rank[r] = prev + (uint32_t)__popcll(m & lt_mask);
+      if ((m & lt_mask) == 0ull) mycnt[digit] = prev + (uint32_t)__popcll(m);  // group leader
+    } else {
+      rank[r] = 0;
+    }
+  }
+  __syncthreads();
+  {  // thread d owns digit d: global base + exclusive prefix over the waves
+    const int d = threadIdx.x;
+    uint32_t run = hist[d * nb + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = cnt[w][d];
+      cnt[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = base + r * 64 + lane;
+    if (e < n) {
+      const uint32_t pos = cnt[wave][(key[r] >> shift) & 255u] + rank[r];
+      keys_out[pos] = key[r];
+      vals_out[pos] = val[r];
+    }
+  }
+}
+
+// ---- sorted triangle records + padded leaf boxes -----------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                int n_verts, int n_faces, int np,
+                                                const uint32_t* __restrict__ vals, const float* __restrict__ params,
+                                                float4* __restrict__ tris, float4* __restrict__ seg) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= np) return;
+  float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+  if (p < n_faces) {
+    const int f = (int)vals[p];
+    const int a = faces[3 * (size_t)f], b = faces[3 * (size_t)f + 1], c = faces[3 * (size_t)f + 2];
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    q2.y = __int_as_float(f);
+    if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
+      const float pad = params[4];
+      const float* pa = verts + 3 * (size_t)a;
+      const float* pb = verts + 3 * (size_t)b;
+      const float* pc = verts + 3 * (size_t)c;
+      const float v0x = pa[0], v0y = pa[1], v0z = pa[2];
+      const float v1x = pb[0], v1y = pb[1], v1z = pb[2];
+      const float v2x = pc[0], v2y = pc[1], v2z = pc[2];
+      q0 = make_float4(v0x, v0y, v0z, v1x - v0x);
+      q1 = make_float4(v1y - v0y, v1z - v0z, v2x - v0x, v2y - v0y);
+      q2.x = v2z - v0z;
+      lo.x = fminf(v0x, fminf(v1x, v2x)) - pad; lo.y = fminf(v0y, fminf(v1y, v2y)) - pad;
+      lo.z = fminf(v0z, fminf(v1z, v2z)) - pad;
+      hi.x = fmaxf(v0x, fmaxf(v1x, v2x)) + pad; hi.y = fmaxf(v0y, fmaxf(v1y, v2y)) + pad;
+      hi.z = fmaxf(v0z, fmaxf(v1z, v2z)) + pad;
+    }
+    tris[3 * (size_t)p] = q0;
+    tris[3 * (size_t)p + 1] = q1;
+    tris[3 * (size_t)p + 2] = q2;
+  }
+  seg[2 * ((size_t)np + p)] = lo;
+  seg[2 * ((size_t)np + p) + 1] = hi;
+}
+
+__device__ __forceinline__ void box_union(float4& lo, float4& hi, const float4 l2, const float4 h2) {
+  lo.x = fminf(lo.x, l2.x); lo.y = fminf(lo.y, l2.y); lo.z = fminf(lo.z, l2.z);
+  hi.x = fmaxf(hi.x, h2.x); hi.y = fmaxf(hi.y, h2.y); hi.z = fmaxf(hi.z, h2.z);
+}
+
+// ---- segment tree: each workgroup reduces `sub` consecutive leaves up to their common ancestor ----------
+__global__ __launch_bounds__(256) void k_seg_sub(float4* __restrict__ seg, int np, int sub) {
+  __shared__ float4 slo[LT_SEG_SUB / 2], shi[LT_SEG_SUB / 2];
+  const int t = threadIdx.x;
+  int cnt = sub >> 1;                                  // nodes at the level above the leaves
+  size_t first = ((size_t)np + (size_t)blockIdx.x * sub) >> 1;  // heap index of the first of them
+  float4 lo, hi;
+  if (t < cnt) {
+    const size_t k = first + t;
+    lo = seg[2 * (2 * k)]; hi = seg[2 * (2 * k) + 1];
+    box_union(lo, hi, seg[2 * (2 * k + 1)], seg[2 * (2 * k + 1) + 1]);
+    seg[2 * k] = lo; seg[2 * k + 1] = hi;
+    slo[t] = lo; shi[t] = hi;
+  }
+  __syncthreads();
+  while (cnt > 1) {
+    cnt >>= 1;
+    first >>= 1;
+    if (t < cnt) {
+      lo = slo[2 * t]; hi = shi[2 * t];
+      box_union(lo, hi, slo[2 * t + 1], shi[2 * t + 1]);
+    }
+    __syncthreads();
+    if (t < cnt) {
+      slo[t] = lo; shi[t] = hi;
+      seg[2 * (first + t)] = lo; seg[2 * (first + t) + 1] = hi;
+    }
+    __syncthreads();
+  }
+}
+
+// top of the segment tree: one workgroup, level by level through global memory
+__global__ __launch_bounds__(1024) void k_seg_top(float4* __restrict__ seg, int m) {
+  for (int cnt = m >> 1; cnt >= 1; cnt >>= 1) {
+    for (int j = threadIdx.x; j < cnt; j += 1024) {
+      const size_t k = (size_t)cnt + j;
+      float4 lo = seg[2 * (2 * k)], hi = seg[2 * (2 * k) + 1];
+      box_union(lo, hi, seg[2 * (2 * k + 1)], seg[2 * (2 * k + 1) + 1]);
+      seg[2 * k] = lo; seg[2 * k + 1] = hi;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ---- Karras topology + child boxes --------------------------------------------------------------------
+__device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, int i, uint32_t ki, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t kj = keys[j];
+  return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
+}
+
+__device__ __forceinline__ void range_box(const float4* __restrict__ seg, int np, int a, int b, float4& lo,
+                                          float4& hi) {
+  lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+  int l = a + np, r = b + np + 1;
+  while (l < r) {
+    if (l & 1) { box_union(lo, hi, seg[2 * (size_t)l], seg[2 * (size_t)l + 1]); ++l; }
+    if (r & 1) { --r; box_union(lo, hi, seg[2 * (size_t)r], seg[2 * (size_t)r + 1]); }
+    l >>= 1;
+    r >>= 1;
+  }
+}
+
+__device__ __forceinline__ int leaf_ref(int start, int cnt) { return ~(start | ((cnt - 1) << 28)); }
+
+__global__ __launch_bounds__(256) void k_hierarchy(const uint32_t* __restrict__ keys, int n, int np,
+                                                   const float4* __restrict__ seg, float4* __restrict__ nodes) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (n == 1) {
+    if (i == 0) {
+      const float4 lo = seg[2 * (size_t)np], hi = seg[2 * (size_t)np + 1];
+      const int c = leaf_ref(0, 1);
+      nodes[0] = make_float4(lo.x, lo.y, lo.z, hi.x);
+      nodes[1] = make_float4(hi.y, hi.z, INFINITY, INFINITY);   // second child: mn = mx = +inf, never hit
+      nodes[2] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      nodes[3] = make_float4(__int_as_float(c), __int_as_float(c), 0.f, 0.f);
+    }
+    return;
+  }
+  if (i >= n - 1) return;
+  const uint32_t ki = keys[i];
+  const int d = (delta(keys, n, i, ki, i + 1) - delta(keys, n, i, ki, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, ki, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, ki, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dn = delta(keys, n, i, ki, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (delta(keys, n, i, ki, i + (s + t) * d) > dn) s += t;
+    if (t == 1) break;
+  }
+  const int g = i + s * d + (d < 0 ? -1 : 0);
+  const int first = min(i, j), last = max(i, j);
+  if (last - first + 1 <= LT_LEAF_MAX && i != 0) return;  // swallowed by a leaf of an ancestor
+  const int lc = g - first + 1, rc = last - g;
+  const int c0 = lc <= LT_LEAF_MAX ? leaf_ref(first, lc) : g;
+  const int c1 = rc <= LT_LEAF_MAX ? leaf_ref(g + 1, rc) : g + 1;
+  float4 l0, h0, l1, h1;
+  range_box(seg, np, first, g, l0, h0);
+  range_box(seg, np, g + 1, last, l1, h1);
+  float4* N = nodes + 4 * (size_t)i;
+  N[0] = make_float4(l0.x, l0.y, l0.z, h0.x);
+  N[1] = make_float4(h0.y, h0.z, l1.x, l1.y);
+  N[2] = make_float4(l1.z, h1.x, h1.y, h1.z);
+  N[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
+  const int n = s->n_faces;
+  s->built = 0;
+  s->last_stream = stream;
+  if (n > LT_MAX_FACES - 1) {
+    lt_set_error("lt_scene_build: %d faces exceed LT_MAX_FACES", n);
+    return LT_ERR_TOO_LARGE;
+  }
+  LT_CHECK(lt_scene_reserve(s, n));
+  const bool timed = stats != nullptr;
+  int ev = 0;
+#define LT_MARK()                                              \
+  do {                                                         \
+    if (timed) LT_HIP(hipEventRecord(s->ev[ev++], stream));    \
+  } while (0)
+  LT_MARK();  // 0
+  if (n > 0) {
+    int np = 1;
+    while (np < n) np <<= 1;
+    s->np = np;
+    hipLaunchKernelGGL(k_bounds, dim3(LT_BOUNDS_BLOCKS), dim3(256), 0, stream, s->verts, s->n_verts, s->partial);
+    LT_MARK();  // 1
+    hipLaunchKernelGGL(k_morton, dim3(cdiv(n, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n,
+                       s->partial, s->params, s->keys[0], s->vals[0], s->flags);
+    LT_MARK();  // 2
+    const int nb = cdiv(n, LT_SORT_TILE);
+    int cur = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 8 * pass;
+      hipLaunchKernelGGL(k_hist, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], n, shift, s->hist, nb);
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, s->hist, 256 * nb);
+      hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], s->vals[cur],
+                         s->keys[cur ^ 1], s->vals[cur ^ 1], n, shift, s->hist, nb);
+      cur ^= 1;
+    }
+    // 4 passes: sorted data is back in buffer 0
+    LT_MARK();  // 3
+    hipLaunchKernelGGL(k_gather, dim3(cdiv(np, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n, np,
+                       s->vals[cur], s->params, s->tris, s->seg);
+    LT_MARK();  // 4
+    if (np >= 2) {
+      const int sub = np < LT_SEG_SUB ? np : LT_SEG_SUB;
+      hipLaunchKernelGGL(k_seg_sub, dim3(np / sub), dim3(256), 0, stream, s->seg, np, sub);
+      if (np / sub > 1) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, stream, s->seg, np / sub);
+    }
+    LT_MARK();  // 5
+    hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n, np,
+                       s->seg, s->nodes);
+    LT_MARK();  // 6
+    LT_HIP(hipGetLastError());
+  }
+  s->built = 1;
+  s->stats.n_faces = n;
+  s->stats.n_nodes = n > 1 ? n - 1 : (n == 1 ? 1 : 0);
+  if (timed) {
+    LT_HIP(hipStreamSynchronize(stream));
+    float ms[6] = {0, 0, 0, 0, 0, 0};
+    if (n > 0)
+      for (int k = 0; k < 6; ++k) LT_HIP(hipEventElapsedTime(&ms[k], s->ev[k], s->ev[k + 1]));
+    s->stats.ms_bounds = ms[0]; s->stats.ms_morton = ms[1]; s->stats.ms_sort = ms[2];
+    s->stats.ms_gather = ms[3]; s->stats.ms_segtree = ms[4]; s->stats.ms_hierarchy = ms[5];
+    float tot = 0.f;
+    if (n > 0) LT_HIP(hipEventElapsedTime(&tot, s->ev[0], s->ev[6]));
+    s->stats.ms_build = tot;
+    *stats = s->stats;
+  }
+#undef LT_MARK
+  return LT_OK;
+}

@@ -1,0 +1,88 @@
+// lt_internal.h -- shared declarations of liblidarhip.so (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "lidarhip.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void lt_set_error(const char* fmt, ...);
+
+#define LT_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      lt_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return e__ == hipErrorOutOfMemory ? LT_ERR_NO_MEMORY : LT_ERR_HIP;                      \
+    }                                                                                         \
+  } while (0)
+
+#define LT_CHECK(expr)              \
+  do {                              \
+    int rc__ = (expr);              \
+    if (rc__ != LT_OK) return rc__; \
+  } while (0)
+
+// ---- device data layout -----------------------------------------------------------------------
+// Sorted triangle record, 48 B = 3 x float4 (one 16-B-aligned dwordx4 load each):
+//   q0 = (v0.x, v0.y, v0.z, e1.x)   q1 = (e1.y, e1.z, e2.x, e2.y)   q2 = (e2.z, face, -, -)
+// e1 = v1 - v0, e2 = v2 - v0 are the first two operations of Triangle::getIntersection
+// (Triangle.h:28-29) hoisted into the build; float subtraction is deterministic, so the result
+// bits are those of the reference.
+//
+// Segment-tree box, 32 B = 2 x float4: lo = (mn.xyz, 0), hi = (mx.xyz, 0); heap layout, leaves at
+// [np, 2np), node k = union(2k, 2k+1).
+//
+// BVH node, 64 B = 4 x float4, Karras numbering (node i splits the sorted key range it owns):
+//   q0 = (b0.mn.x, b0.mn.y, b0.mn.z, b0.mx.x)   q1 = (b0.mx.y, b0.mx.z, b1.mn.x, b1.mn.y)
+//   q2 = (b1.mn.z, b1.mx.x, b1.mx.y, b1.mx.z)   q3 = (c0, c1, -, -) as int bits
+// child reference c >= 0: node index; c < 0: leaf, ~c = start | (count-1) << 28.
+
+#define LT_LEAF_MAX 4
+#define LT_SORT_TILE 4096      // keys per workgroup per radix pass (256 threads x 16)
+#define LT_SORT_THREADS 256
+#define LT_SEG_SUB 512         // segment-tree leaves reduced per workgroup
+#define LT_STACK_LDS 32        // per-ray stack entries kept in LDS; deeper entries spill to HBM
+#define LT_STACK_MAX 64        // Karras depth bound for 62-bit unique keys
+
+struct lt_scene {
+  int device;
+  // mesh (borrowed or owned)
+  const float* verts;
+  const int* faces;
+  const int* colors;
+  const float* rem;
+  int n_verts, n_faces;
+  void* owned_mesh;  // single allocation backing the four arrays when set from host
+  size_t owned_mesh_bytes;
+  // workspace, sized for cap_faces
+  int cap_faces;
+  int np;               // segment-tree leaf count (power of two >= n_faces)
+  uint32_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;       // [256 * n_sort_blocks]
+  float4* tris;         // [3 * n_faces]
+  float4* seg;          // [2 * 2 * np]
+  float4* nodes;        // [4 * max(n_faces - 1, 1)]
+  float* partial;       // per-workgroup bounds partials [6 * LT_BOUNDS_BLOCKS]
+  float* params;        // device: lo.xyz, scale, pad
+  unsigned* flags;      // device: [0] error bits
+  unsigned long long* counters;  // device: nodes, tris, hits, overflows
+  int* overflow;        // [n_rays_cap * (LT_STACK_MAX - LT_STACK_LDS)] spill area
+  int cap_rays;
+  int built;
+  hipStream_t last_stream;
+  hipEvent_t ev[10];
+  int have_events;
+  lt_stats stats;
+};
+
+#define LT_BOUNDS_BLOCKS 256
+#define LT_FLAG_BAD_INDEX 1u
+
+int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats);
+int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_rays, int height,
+                    float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                    unsigned flags, hipStream_t stream, lt_stats* stats);
+int lt_scene_reserve(lt_scene* s, int n_faces);
+int lt_scene_reserve_rays(lt_scene* s, int n_rays);

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's native raytracer interface.
+
+* :func:`C_Trace` -- same positional signature, dtype/contiguity checks and in-place output
+  semantics as ``auxiliary/raytracer/RayTracerCython.pyx:15-33`` of the reference; numpy in,
+  numpy out, one call = upload + BVH build + ray cast + download on the current HIP device.
+* :class:`Scene` -- the split, device-resident API (``lt_scene_*`` in include/lidarhip.h) for
+  callers that keep meshes, rays and images in HBM as ``torch`` tensors (the multi-GPU driver,
+  ``bench.py``).  torch is only used for device memory and streams.
+
+Everything routes through the C ABI of ``liblidarhip.so``; there is no CPU implementation here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _chk1d(name, a, dtype):
+    """Reproduce the failure modes of Cython's ``float[::1]`` / ``int[::1]`` typed memoryviews."""
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{name}: expected a numpy array, got {type(a).__name__}")
+    if a.ndim != 1:
+        raise ValueError(f"{name}: Buffer has wrong number of dimensions (expected 1, got {a.ndim})")
+    if a.dtype != dtype:
+        raise ValueError(f"{name}: Buffer dtype mismatch, expected '{np.dtype(dtype).name}' but got '{a.dtype.name}'")
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"{name}: ndarray is not C-contiguous")
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def C_Trace(rays, origin, verts, faces, colors, rem, ray_endpoints, ray_colors, range_image, rem_image, H, W,
+            tri_image=None, stats=None):
+    """Drop-in for ``RayTracerCython.C_Trace`` (RayTracerCython.pyx:15-33).
+
+    All arrays are flat, C-contiguous ``float32`` / ``int32``.  Outputs are modified in place and
+    only for rays that hit (the caller pre-zeroes them, fusion_lidar.py:440-447).  ``W`` is unused,
+    exactly as in the reference (width = n_rays // H, RayTracer.cpp:56).
+
+    Extensions (keyword-only use): ``tri_image`` (flat int32) receives the hit face index;
+    ``stats`` (a dict) is filled with per-phase timings and traversal counters.
+    """
+    rays = _chk1d("rays", rays, np.float32)
+    origin = _chk1d("origin", origin, np.float32)
+    verts = _chk1d("verts", verts, np.float32)
+    faces = _chk1d("faces", faces, np.int32)
+    colors = _chk1d("colors", colors, np.int32)
+    rem = _chk1d("rem", rem, np.float32)
+    ray_endpoints = _chk1d("ray_endpoints", ray_endpoints, np.float32)
+    ray_colors = _chk1d("ray_colors", ray_colors, np.int32)
+    range_image = _chk1d("range_image", range_image, np.float32)
+    rem_image = _chk1d("rem_image", rem_image, np.float32)
+    n_rays = len(rays) // 3
+    n_verts = len(verts) // 3
+    n_faces = len(faces) // 3
+    lib = _lib.load()
+    st = _lib.Stats()
+    tri_p = None
+    if tri_image is not None:
+        tri_image = _chk1d("tri_image", tri_image, np.int32)
+        tri_p = _ip(tri_image)
+    rc = lib.lt_ctrace_ex(_fp(rays), _fp(origin), _fp(verts), _ip(faces), _ip(colors), _fp(rem), n_rays, n_verts,
+                          n_faces, int(H), _fp(ray_endpoints), _ip(ray_colors), _fp(range_image), _fp(rem_image),
+                          tri_p, C.byref(st) if stats is not None else None)
+    _lib.check(rc, "lt_ctrace")
+    if stats is not None:
+        stats.update(st.asdict())
+
+
+class Scene:
+    """Device-resident mesh + BVH (``lt_scene`` in include/lidarhip.h).
+
+    ``verts [V,3] f32``, ``faces [F,3] i32``, ``colors [V,3] i32``, ``rem [V] f32`` are contiguous
+    ``torch`` tensors on the scene's GPU; they are borrowed, so keep them alive until the traces of
+    this mesh have finished.
+    """
+
+    def __init__(self, device=None):
+        import torch
+        self._torch = torch
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.lt_scene_create(C.byref(h), self.device.index), "lt_scene_create")
+        self._h = h
+        self._mesh = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _t(self, x, dtype, name):
+        torch = self._torch
+        if not isinstance(x, torch.Tensor):
+            raise TypeError(f"{name}: expected a torch tensor")
+        if x.device != self.device:
+            raise ValueError(f"{name}: tensor on {x.device}, scene on {self.device}")
+        if x.dtype != dtype or not x.is_contiguous():
+            raise ValueError(f"{name}: must be contiguous {dtype}")
+        return x
+
+    def set_mesh(self, verts, faces, colors, rem):
+        torch = self._torch
+        verts = self._t(verts, torch.float32, "verts")
+        faces = self._t(faces, torch.int32, "faces")
+        colors = self._t(colors, torch.int32, "colors")
+        rem = self._t(rem, torch.float32, "rem")
+        self._mesh = (verts, faces, colors, rem)
+        _lib.check(self._lib.lt_scene_set_mesh_dev(self._h, verts.data_ptr(), faces.data_ptr(), colors.data_ptr(),
+                                                   rem.data_ptr(), verts.numel() // 3, faces.numel() // 3),
+                   "lt_scene_set_mesh_dev")
+
+    def _stream(self, stream):
+        torch = self._torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        return C.c_void_p(stream.cuda_stream)
+
+    def build(self, stream=None, stats=False):
+        st = _lib.Stats()
+        _lib.check(self._lib.lt_scene_build(self._h, self._stream(stream), C.byref(st) if stats else None),
+                   "lt_scene_build")
+        return st.asdict() if stats else None
+
+    def trace(self, rays, origin, H, out=None, stream=None, write_misses=True, count=False, stats=False):
+        """Cast ``rays [R,3] f32`` (device) from ``origin`` (3 floats, host); returns dict of device tensors.
+
+        ``out`` may carry preallocated ``endpoints [R,3] f32, endcolors [R,3] i32, range [R] f32,
+        endrem [R] f32, tri [R] i32`` tensors to reuse.
+        """
+        torch = self._torch
+        rays = self._t(rays, torch.float32, "rays")
+        n_rays = rays.numel() // 3
+        if out is None:
+            out = self.alloc_outputs(n_rays)
+        org = (C.c_float * 3)(*[float(v) for v in origin])
+        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
+        st = _lib.Stats()
+
+        def p(k):
+            t = out.get(k)
+            return t.data_ptr() if t is not None else None
+
+        _lib.check(self._lib.lt_scene_trace_dev(self._h, rays.data_ptr(), org, n_rays, int(H), p("endpoints"),
+                                                p("endcolors"), p("range"), p("endrem"), p("tri"), flags,
+                                                self._stream(stream), C.byref(st) if (stats or count) else None),
+                   "lt_scene_trace_dev")
+        if stats or count:
+            out = dict(out)
+            out["stats"] = st.asdict()
+        return out
+
+    def alloc_outputs(self, n_rays):
+        torch = self._torch
+        d = self.device
+        return dict(endpoints=torch.empty((n_rays, 3), dtype=torch.float32, device=d),
+                    endcolors=torch.empty((n_rays, 3), dtype=torch.int32, device=d),
+                    range=torch.empty((n_rays,), dtype=torch.float32, device=d),
+                    endrem=torch.empty((n_rays,), dtype=torch.float32, device=d),
+                    tri=torch.empty((n_rays,), dtype=torch.int32, device=d))
+
+    def status(self):
+        _lib.check(self._lib.lt_scene_status(self._h), "lt_scene_status")

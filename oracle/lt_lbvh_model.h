@@ -141,7 +141,8 @@ static int lbvh_build(lbvh_t* L, const tri_t* prims, int n, float pad_unused) {
   if (n == 1) {
     lnode_t* N = &L->nodes[0];
     N->c0 = lbvh_leaf_ref(0, 1); N->b0 = L->seg[np];
-    N->c1 = lbvh_leaf_ref(0, 1); N->b1 = lbox_empty();
+    N->c1 = lbvh_leaf_ref(0, 1);
+    N->b1.mn.x = N->b1.mn.y = N->b1.mn.z = N->b1.mx.x = N->b1.mx.y = N->b1.mx.z = INFINITY; /* never hit */
     L->n_nodes = 1; L->n_leaves = 1;
     return 0;
   }
