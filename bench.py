@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- virtual-LiDAR synthesis throughput on MI355X (one process per GPU).
+
+A *step* is one pass of the hot path over one scan: LBVH build over that scan's triangle mesh
+(the mesh changes every scan, exactly as in the reference where `BVH bvh(&objects)` is rebuilt
+per call, RayTracer.cpp:54) + one ray per (beam, azimuth) cell + hit write-back, with mesh, rays
+and images resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle
+scene, 64x2048 HDL-64E target, fov +3/-25), synthetic.
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Scans shard over ranks (weak scaling: every rank renders K scans) with no data-path collective;
+the rendered range/label images are gathered ONCE over RCCL at the end of the timed region.
+Rank 0 prints one JSON line (contract in the task statement), with `roofline` for the dominant
+kernel and `cpu_baseline` = the real reference raytracer (oracle/_ref, prebuilt from
+/root/reference) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+# algorithmic bytes per unit (DESIGN.md "Roofline"): one BVH node = 64 B, one triangle record = 48 B,
+# per ray 12 B direction in + 44 B out (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
+B_NODE, B_TRI, B_RAY = 64, 48, 12 + 44 + 40
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "1")),
+                    help="scans in flight per GPU (HIP streams)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=0, help="reference runs for the CPU baseline (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload: dict, seed: int, reps: int):
+    """Time the real reference (oracle/_ref) in a subprocess on this host; bounded sample."""
+    code = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import binding as ob
+from lidar_transfer_amd.synth import synth_scene
+from lidar_transfer_amd.laserscan import create_rays
+wl = json.loads(sys.argv[1]); seed = int(sys.argv[2]); reps = int(sys.argv[3]); kind = sys.argv[4]
+v, f, c, r = synth_scene(seed, wl["tris"])
+rays = create_rays(wl["fov_up"], wl["fov_down"], wl["H"], wl["W"]); org = np.zeros(3, np.float32)
+ts = []
+t_all = time.time()
+for i in range(reps):
+    t = time.time()
+    if kind == "port":
+        ob.oracle_trace(rays, org, v, f, c, r, wl["H"], mode=ob.MODE_REF_BVH, norm=ob.NORM_SSE)
+    else:
+        ob.ref_trace(rays, org, v, f, c, r, wl["H"], kind=kind)
+    ts.append(time.time() - t)
+    if time.time() - t_all > 25: break
+sys.stderr.write("LTBASE " + json.dumps({"times": ts, "threads": ob.num_threads(), "faces": int(f.shape[0])}) + "\n")
+""" % ROOT
+    for kind in ("fast", "strict", "port"):
+        if kind != "port" and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", f"libref_{kind}.so")):
+            continue
+        try:
+            res = subprocess.run([sys.executable, "-c", code, json.dumps(workload), str(seed), str(reps), kind],
+                                 capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            continue
+        line = [l for l in res.stderr.splitlines() if l.startswith("LTBASE ")]
+        if res.returncode != 0 or not line:
+            continue
+        info = json.loads(line[0][7:])
+        t = float(np.min(info["times"]))
+        n_rays = workload["H"] * workload["W"]
+        return {"value": round(n_rays / t / 1e6, 4), "unit": "Mrays/s", "cores": info["threads"],
+                "kind": "port" if kind == "port" else "reference",
+                "sample": f"{len(info['times'])} end-to-end ctrace calls (triangle set-up + BVH build + trace) on one "
+                          f"{workload['H']}x{workload['W']} scan vs {info['faces']} triangles, min of runs, "
+                          f"{'oracle/_ref/libref_' + kind + '.so' if kind != 'port' else 'oracle restatement'}, "
+                          f"OpenMP threads={info['threads']}",
+                "s_per_scan": round(t, 4), "scans_per_s": round(1.0 / t, 3)}
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from lidar_transfer_amd.laserscan import create_rays
+    from lidar_transfer_amd.raytracer import Scene
+    from lidar_transfer_amd.synth import WORKLOADS, synth_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    wl = dict(WORKLOADS[args.workload])
+    H, W = wl["H"], wl["W"]
+    R = H * W
+    K, Wm, S = args.steps, args.warmup, max(1, args.streams)
+
+    # ---- synthetic inputs, resident in HBM before the clock starts -----------------------------------
+    scenes = []
+    for i in range(args.scenes):
+        v, f, c, r = synth_scene(1000 * rank + i, wl["tris"])
+        scenes.append(tuple(torch.from_numpy(x).to(dev) for x in (v, f, c, r)))
+    n_faces = int(scenes[0][1].shape[0])
+    rays = torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev)
+    origin = (0.0, 0.0, 0.0)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    workers = [Scene(local_rank) for _ in range(S)]
+    # every timed scan keeps its images (what a real job would gather / write)
+    range_all = torch.zeros((K, R), dtype=torch.float32, device=dev)
+    label_all = torch.zeros((K, R, 3), dtype=torch.int32, device=dev)
+    scratch = [workers[0].alloc_outputs(R) for _ in range(S)]
+
+    def step(i, slot=None, timed_events=None):
+        s = i % S
+        sc = workers[s]
+        out = dict(scratch[s])
+        if slot is not None:
+            out["range"] = range_all[slot]
+            out["endcolors"] = label_all[slot]
+        with torch.cuda.stream(streams[s]):
+            sc.set_mesh(*scenes[i % len(scenes)])
+            sc.build(stream=streams[s])
+            if timed_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(streams[s])
+            sc.trace(rays, origin, H, out=out, stream=streams[s], write_misses=True)
+            if timed_events is not None:
+                e1.record(streams[s])
+                timed_events.append((e0, e1))
+
+    # one counting pass per scene (outside the clock): nodes / triangles per ray for the roofline
+    counts = []
+    for i in range(len(scenes)):
+        workers[0].set_mesh(*scenes[i])
+        workers[0].build()
+        o = workers[0].trace(rays, origin, H, out=scratch[0], count=True)
+        counts.append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
+    phase = workers[0].build(stats=True)
+    torch.cuda.synchronize()
+
+    for i in range(Wm):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = []
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i, slot=i, timed_events=events)
+    for st in streams:
+        st.synchronize()
+    gathered = None
+    if world > 1:  # the single RCCL gather of the rendered images (range + vertex-0 colour/label)
+        gathered_r = torch.empty((world, K, R), dtype=torch.float32, device=dev) if True else None
+        gathered_l = torch.empty((world, K, R, 3), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(gathered_r, range_all)
+        dist.all_gather_into_tensor(gathered_l, label_all)
+        gathered = (gathered_r, gathered_l)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    hits = int((range_all[K - 1] > 0).sum().item())
+
+    if rank == 0:
+        n_nodes = float(np.mean([c[0] for c in counts]))
+        n_tris = float(np.mean([c[1] for c in counts]))
+        alg_bytes = n_nodes * B_NODE + n_tris * B_TRI + R * B_RAY
+        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9
+        value = world * K * R / dt / 1e6
+        out = {
+            "metric": "Mrays/sec, LBVH build + ray cast per scan (mesh changes every scan)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {H}x{W} rays vs {n_faces}-triangle synthetic scene "
+                                   f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan per step, "
+                                   f"{len(scenes)} distinct scenes cycled",
+                       "parallelism": f"scan-parallel x{world}" + (", one all_gather of images" if world > 1 else ""),
+                       "streams_per_gpu": S},
+            "scans_per_s": round(world * K / dt, 2),
+            "trace_only_Mrays_s": round(R / (trace_ms * 1e-3) / 1e6, 2),
+            "phase_ms": {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"},
+            "hit_fraction": round(hits / R, 4),
+            "roofline": {"kernel": "k_trace", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_kernel_ms": round(trace_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "nodes_per_ray": round(n_nodes / R, 2), "tris_per_ray": round(n_tris / R, 2)},
+        }
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(wl, 0, args.cpu_reps or 12)
+            out["cpu_baseline"] = cb
+            if cb:
+                out["speedup_vs_cpu_baseline"] = round(value / world / cb["value"], 1)
+        print(json.dumps(out), flush=True)
+    for wk in workers:
+        wk.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

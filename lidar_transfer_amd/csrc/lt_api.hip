@@ -53,7 +53,7 @@ int lt_scene_reserve(lt_scene* s, int n_faces) {
     LT_CHECK(dev_alloc(&s->keys[k], cap));
     LT_CHECK(dev_alloc(&s->vals[k], cap));
   }
-  LT_CHECK(dev_alloc(&s->hist, 256 * nb));
+  LT_CHECK(dev_alloc(&s->hist, 256 * nb + 256));
   LT_CHECK(dev_alloc(&s->tris, 3 * cap));
   LT_CHECK(dev_alloc(&s->seg, 4 * np));
   LT_CHECK(dev_alloc(&s->nodes, 4 * cap));

@@ -143,31 +143,34 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_hist(const uint32_t* __rest
   hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. total) in place, single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ hist, int total) {
-  __shared__ uint32_t wsum[16];
-  const int per = (total + 1023) / 1024;
-  const int s = threadIdx.x * per, e = min(s + per, total);
-  uint32_t sum = 0;
-  for (int i = s; i < e; ++i) sum += hist[i];
-  // inclusive scan across the wave
+// Row scan: workgroup d turns hist[d*nb .. d*nb+nb) (the counts of digit d per tile) into its
+// exclusive prefix sum and stores the digit total in hist[256*nb + d].  The cross-digit prefix
+// (256 values) is redone by every k_scatter workgroup in LDS -- cheaper than another launch.
+__global__ __launch_bounds__(256) void k_scan(uint32_t* __restrict__ hist, int nb) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = sum;
+  uint32_t* row = hist + (size_t)blockIdx.x * nb;
+  uint32_t carry = 0;
+  for (int base = 0; base < nb; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < nb ? row[i] : 0u;
+    uint32_t inc = v;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, WAVE);
-    if (lane >= o) inc += t;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, WAVE);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (i < nb) row[i] = carry + woff + inc - v;
+    if (threadIdx.x == 255) carry_s = carry + woff + inc;
+    __syncthreads();
+    carry = carry_s;
   }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wsum[w];
-  uint32_t run = woff + inc - sum;
-  for (int i = s; i < e; ++i) {
-    const uint32_t v = hist[i];
-    hist[i] = run;
-    run += v;
-  }
+  if (threadIdx.x == 0) hist[256 * (size_t)nb + blockIdx.x] = carry;
 }
 
 // Stable scatter.  Wave w of the workgroup ranks the contiguous quarter [w*1024, (w+1)*1024) of the
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
   constexpr int ROUNDS = LT_SORT_TILE / LT_SORT_THREADS;  // 16
   constexpr int NW = LT_SORT_THREADS / 64;                 // 4
   __shared__ uint32_t cnt[NW][256];
+  __shared__ uint32_t wtot[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < NW; ++w) cnt[w][threadIdx.x] = 0;
@@ -218,9 +222,20 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
     }
   }
   __syncthreads();
-  {  // thread d owns digit d: global base + exclusive prefix over the waves
+  {  // thread d owns digit d: digit base (exclusive scan of the 256 totals) + tile base + prefix over the waves
     const int d = threadIdx.x;
-    uint32_t run = hist[d * nb + blockIdx.x];
+    const uint32_t tot = hist[256 * (size_t)nb + d];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, WAVE);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t dbase = inc - tot;
+    for (int w = 0; w < wave; ++w) dbase += wtot[w];
+    uint32_t run = dbase + hist[d * nb + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const uint32_t c = cnt[w][d];
@@ -428,7 +443,7 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 8 * pass;
       hipLaunchKernelGGL(k_hist, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], n, shift, s->hist, nb);
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, s->hist, 256 * nb);
+      hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, stream, s->hist, nb);
       hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], s->vals[cur],
                          s->keys[cur ^ 1], s->vals[cur ^ 1], n, shift, s->hist, nb);
       cur ^= 1;

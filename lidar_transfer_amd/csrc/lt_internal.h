@@ -60,7 +60,7 @@ struct lt_scene {
   int np;               // segment-tree leaf count (power of two >= n_faces)
   uint32_t* keys[2];
   uint32_t* vals[2];
-  uint32_t* hist;       // [256 * n_sort_blocks]
+  uint32_t* hist;       // [256 * n_sort_blocks + 256 digit totals]
   float4* tris;         // [3 * n_faces]
   float4* seg;          // [2 * 2 * np]
   float4* nodes;        // [4 * max(n_faces - 1, 1)]
