@@ -39,6 +39,9 @@ extern "C" {
 #define LT_TRACE_WRITE_MISSES 1u /* write 0 / tri = -1 for rays that hit nothing (otherwise outputs   */
                                  /* are left untouched for misses, as in RayTracer.cpp:73)            */
 #define LT_TRACE_COUNT 2u        /* accumulate nodes visited / triangles tested into the scene stats  */
+#define LT_TRACE_NORM_EXACT 4u   /* seed the direction normalisation (Vector3.h:73-89) with a correctly */
+                                 /* rounded 1/sqrt instead of the replayed x86 RSQRTSS seed (default);  */
+                                 /* vendor independent, differs from the reference in the last ulp      */
 
 /* Per-phase timings (hipEvent, milliseconds) and work counters of the last build / trace of a scene. */
 typedef struct lt_stats {

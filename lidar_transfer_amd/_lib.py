@@ -14,6 +14,7 @@ from . import build as _build
 LT_OK = 0
 LT_TRACE_WRITE_MISSES = 1
 LT_TRACE_COUNT = 2
+LT_TRACE_NORM_EXACT = 4
 
 #: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",

@@ -300,10 +300,15 @@ extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float*
   }
   lt_stats st;
   memset(&st, 0, sizeof(st));
+  // LIDARHIP_NORMALIZE=exact selects the vendor-independent 1/sqrt seed (LT_TRACE_NORM_EXACT);
+  // default is the replayed RSQRTSS seed of the reference's normalize() (Vector3.h:83).
+  const char* nm = getenv("LIDARHIP_NORMALIZE");
+  const unsigned norm_flag = (nm && strcmp(nm, "exact") == 0) ? LT_TRACE_NORM_EXACT : 0u;
   LT_CHECK(lt_build_launch(s, stream, stats ? &st : nullptr));
   LT_CHECK(lt_trace_launch(s, d_rays, origin, (int)R, height, endpoints ? d_end : nullptr,
                            endcolors ? d_col : nullptr, range ? d_range : nullptr, endrem ? d_rem : nullptr,
-                           tri ? d_tri : nullptr, stats ? LT_TRACE_COUNT : 0u, stream, stats ? &st : nullptr));
+                           tri ? d_tri : nullptr, (stats ? LT_TRACE_COUNT : 0u) | norm_flag, stream,
+                           stats ? &st : nullptr));
   if (R > 0) {
     if (endpoints) LT_HIP(hipMemcpyAsync(endpoints, d_end, R * 12, hipMemcpyDeviceToHost, stream));
     if (endcolors) LT_HIP(hipMemcpyAsync(endcolors, d_col, R * 12, hipMemcpyDeviceToHost, stream));

@@ -141,7 +141,8 @@ class Scene:
                    "lt_scene_build")
         return st.asdict() if stats else None
 
-    def trace(self, rays, origin, H, out=None, stream=None, write_misses=True, count=False, stats=False):
+    def trace(self, rays, origin, H, out=None, stream=None, write_misses=True, count=False, stats=False,
+              exact_normalize=False):
         """Cast ``rays [R,3] f32`` (device) from ``origin`` (3 floats, host); returns dict of device tensors.
 
         ``out`` may carry preallocated ``endpoints [R,3] f32, endcolors [R,3] i32, range [R] f32,
@@ -153,7 +154,8 @@ class Scene:
         if out is None:
             out = self.alloc_outputs(n_rays)
         org = (C.c_float * 3)(*[float(v) for v in origin])
-        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
+        flags = ((_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
+                 | (_lib.LT_TRACE_NORM_EXACT if exact_normalize else 0))
         st = _lib.Stats()
 
         def p(k):

@@ -34,8 +34,13 @@
  * whose bits are CPU-vendor specific):
  *   LTO_NORM_SSE       _mm_rsqrt_ss seed  (bit-identical to the reference on
  *                      the CPU it runs on)
- *   LTO_NORM_EXACT     correctly rounded 1/sqrtf seed, same NR step (what the
- *                      HIP kernels compute; vendor independent)
+ *   LTO_NORM_EXACT     correctly rounded 1/sqrtf seed, same NR step (vendor
+ *                      independent; LT_TRACE_NORM_EXACT in the HIP library)
+ *   LTO_NORM_SSE_TABLE the RSQRTSS seed replayed from a 2x1024 table measured on an
+ *                      Intel CPU and verified exhaustively (oracle/gen_rsqrt_table.c);
+ *                      equals LTO_NORM_SSE on Intel hosts, and is what the HIP
+ *                      library computes by default, so that its images equal the
+ *                      reference's as run on the machine the goldens came from.
  */
 #include <math.h>
 #include <stdint.h>
@@ -52,6 +57,9 @@
 
 #define LTO_NORM_SSE 0
 #define LTO_NORM_EXACT 1
+#define LTO_NORM_SSE_TABLE 2 /* RSQRTSS emulated from oracle/rsqrt_sse_table.h (measured on an Intel CPU) */
+
+#include "rsqrt_sse_table.h"
 
 typedef struct {
   double t_setup_ms, t_build_ms, t_trace_ms;
@@ -85,12 +93,29 @@ static inline v3 v3cross(v3 a, v3 b) {
   return r;
 }
 
+/* RSQRTSS replayed from the measured table; D is a sum of squares (never negative) */
+static inline float lto_rsqrt_sse_table(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  const int e = (int)((b >> 23) & 255u);
+  if (e == 0) return INFINITY;               /* zero / denormal source: treated as zero */
+  if (e == 255) return (b & 0x7fffffu) ? x : 0.0f; /* NaN -> NaN, inf -> 0 */
+  const int p = (e - 127) & 1;
+  const int k = (e - 127 - p) / 2;
+  const uint32_t t = LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((uint32_t)k << 23);
+  float r;
+  memcpy(&r, &t, 4);
+  return r;
+}
+
 /* normalize (Vector3.h:73-89): D = (x^2+y^2)+(z^2+0); r = 1.5 r0 + ((D*-0.5)*r0)*(r0*r0) */
 static inline v3 lto_normalize(v3 a, int norm_mode) {
   float D = (a.x * a.x + a.y * a.y) + (a.z * a.z + 0.0f);
   float r0;
   if (norm_mode == LTO_NORM_SSE) {
     r0 = _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(D)));
+  } else if (norm_mode == LTO_NORM_SSE_TABLE) {
+    r0 = lto_rsqrt_sse_table(D);
   } else {
     r0 = 1.0f / sqrtf(D);
   }

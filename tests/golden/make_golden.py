@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What runs is the reference itself, not our restatement:
+  * the C++ raytracer compiled from /root/reference/auxiliary/raytracer by oracle/Makefile into
+    oracle/_ref/libref_strict.so (strict IEEE flags, no FMA contraction), driven through the
+    reference's own Python `TSDFVolume.throw_rays_at_mesh` (auxiliary/fusion_lidar.py:426-455) with
+    `get_mesh` monkey-patched to return our synthetic mesh;
+  * the reference's Python `create_rays`, `do_range_projection`, `do_range_projection_new`
+    (auxiliary/laserscan.py) imported from /root/reference with three import shims
+    (np.float alias, imageio stub, skimage stub -- none of them on the computed path).
+
+Only data is written: inputs that cannot be regenerated from a seed, and expected outputs.
+No reference source or bytecode is copied.
+"""
+import ctypes as C
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import binding as ob  # noqa: E402
+from lidar_transfer_amd.synth import soup, synth_cloud, synth_scene  # noqa: E402
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden.py needs /root/reference")
+    ob.build(quiet=True)
+    np.float = float  # removed alias used at laserscan.py:568, :714
+    sys.modules["imageio"] = types.ModuleType("imageio")
+    sk = types.ModuleType("skimage")
+    sk.measure = types.ModuleType("skimage.measure")
+    sys.modules["skimage"] = sk
+    sys.modules["skimage.measure"] = sk.measure
+    # auxiliary.raytracer.RayTracerCython -> the compiled reference ctrace (same C_Trace signature)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_strict.so"))
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.ctrace.argtypes = [fp, fp, fp, ip, ip, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip, fp, fp]
+    lib.ctrace.restype = None
+    rtc = types.ModuleType("auxiliary.raytracer.RayTracerCython")
+
+    def C_Trace(rays, origin, verts, faces, colors, rem, ray_endpoints, ray_colors, range_image, rem_image, H, W):
+        for a, dt in ((rays, np.float32), (origin, np.float32), (verts, np.float32), (faces, np.int32),
+                      (colors, np.int32), (rem, np.float32), (ray_endpoints, np.float32), (ray_colors, np.int32),
+                      (range_image, np.float32), (rem_image, np.float32)):
+            assert a.dtype == dt and a.ndim == 1 and a.flags["C_CONTIGUOUS"]
+        f = lambda a: a.ctypes.data_as(fp)  # noqa: E731
+        i = lambda a: a.ctypes.data_as(ip)  # noqa: E731
+        lib.ctrace(f(rays), f(origin), f(verts), i(faces), i(colors), f(rem), len(rays) // 3, len(verts) // 3,
+                   len(faces) // 3, H, f(ray_endpoints), i(ray_colors), f(range_image), f(rem_image))
+
+    rtc.C_Trace = C_Trace
+    sys.path.insert(0, REF)
+    import auxiliary
+    pkg = types.ModuleType("auxiliary.raytracer")
+    pkg.RayTracerCython = rtc
+    auxiliary.raytracer = pkg
+    sys.modules["auxiliary.raytracer"] = pkg
+    sys.modules["auxiliary.raytracer.RayTracerCython"] = rtc
+    import auxiliary.fusion_lidar as fl
+    import auxiliary.laserscan as ls
+    return ls, fl
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def throw(fl, verts, faces, colors, rem, rays, origin, H, W):
+    """The genuine throw_rays_at_mesh on a TSDFVolume whose get_mesh returns our mesh."""
+    vol = object.__new__(fl.TSDFVolume)
+    vol.get_mesh = lambda color_lut: (verts, faces, None, colors, rem)
+    endpoints, ray_colors, _, _, _, range_image, rem_image = vol.throw_rays_at_mesh(rays, origin, H, W, None)
+    return endpoints, ray_colors, range_image, rem_image
+
+
+def main():
+    ls, fl = import_reference()
+    create_rays = lambda *a: ls.MultiSemLaserScan.create_rays(None, *a)  # noqa: E731  (self is unused there)
+
+    # ---- F1: create_rays --------------------------------------------------------------------------
+    f1 = {}
+    for name, args in (("a", (3, -25, 4, 8)), ("b", (10, -30, 16, 64)), ("c", (3, -25, 64, 1024)),
+                       ("d", (10, -30, 32, 1024)), ("e", (3, -25, 64, 2048)), ("f", (15, -25, 128, 2048))):
+        r = create_rays(*args)
+        f1[f"{name}_args"] = np.array(args, np.float64)
+        if r.shape[0] <= 1024:
+            f1[f"{name}_rays"] = r
+        else:
+            f1[f"{name}_sha256"] = np.frombuffer(bytes.fromhex(sha(r)), np.uint8)
+            f1[f"{name}_head"] = r[:64]
+            f1[f"{name}_tail"] = r[-64:]
+            f1[f"{name}_stride997"] = r[::997]
+    np.savez_compressed(os.path.join(HERE, "f1_create_rays.npz"), **f1)
+
+    # ---- F2: three-triangle smoke scene ---------------------------------------
+    verts = np.array([[5, -5, -5], [5, 5, -5], [5, 5, 5], [5, -5, 5], [2, -0.5, -0.5], [2, 0.5, -0.5], [2, 0, 0.5]],
+                     np.float32)
+    faces = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6]], np.int32)
+    colors = np.array([[1, 2, 40], [3, 4, 41], [5, 6, 42], [7, 8, 43], [9, 10, 70], [11, 12, 71], [13, 14, 72]],
+                      np.uint8)
+    rem = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7], np.float32)
+    rays = np.array([[1, 0, 0], [1, 0.5, 0.25], [-1, 0, 0], [0, 0, 1], [1, 0.01, 0.05], [1, -0.7, 0.6], [0, 1, 0],
+                     [1, .9, .9]], np.float32)
+    origin = np.zeros(3, np.float32)
+    ep, rc, rg, rm = throw(fl, verts, faces, colors, rem, rays, origin, 2, 4)
+    np.savez_compressed(os.path.join(HERE, "f2_three_triangles.npz"), verts=verts, faces=faces,
+                        colors=colors.astype(np.int32), rem=rem, rays=rays, origin=origin, H=2, W=4, endpoints=ep,
+                        endcolors=rc, range=rg, endrem=rm)
+
+    # ---- F3: geometry of the raytracing.py demo (auxiliary/raytracing.py:229-263) ----------------------
+    verts3 = np.array([[-40.5, -25.5, -1.7], [-39.5, -26.5, -1.7], [-39.5, -25.5, -1.75],
+                       [-40.5, -25.5, -1.9], [-39.5, -26.5, -1.9], [-39.5, -25.5, -1.9]], np.float32)
+    faces3 = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    colors3 = np.array([[1, 1, 10]] * 3 + [[2, 2, 20]] * 3, np.uint8)
+    rem3 = np.linspace(0.1, 0.6, 6).astype(np.float32)
+    rays3 = np.array([[-39.5, -25.5, -1.7], [-39.9, -25.9, -1.72], [-39.6, -25.7, -1.72], [1, 0, 0]], np.float32)
+    ep, rc, rg, rm = throw(fl, verts3, faces3, colors3, rem3, rays3, origin, 1, 4)
+    np.savez_compressed(os.path.join(HERE, "f3_demo_geometry.npz"), verts=verts3, faces=faces3,
+                        colors=colors3.astype(np.int32), rem=rem3, rays=rays3, origin=origin, H=1, W=4,
+                        endpoints=ep, endcolors=rc, range=rg, endrem=rm)
+
+    # ---- F4 / F5: seeded synthetic scenes; hit-triangle ids through the soup trick ---------------------
+    def scene_case(tag, seed, ntri, fov, H, W, org, full, overlap=False):
+        v, f, c, r = synth_scene(seed, ntri, allow_overlap=overlap)
+        sv, sf, sc, sr = soup(v, f, c, r)
+        rays = create_rays(fov[0], fov[1], H, W)
+        org = np.asarray(org, np.float32)
+        ep, rcol, rg, rm = throw(fl, sv, sf, sc, sr, rays, org, H, W)
+        hit = rg.reshape(-1) != 0
+        tri = np.where(hit, rcol[:, 0], -1).astype(np.int32)
+        label = rcol[:, 2].astype(np.int32)
+        d = dict(seed=seed, ntri=ntri, fov=np.array(fov, np.float64), H=H, W=W, origin=org, overlap=overlap,
+                 n_faces=f.shape[0], verts_sha256=np.frombuffer(bytes.fromhex(sha(v)), np.uint8),
+                 faces_sha256=np.frombuffer(bytes.fromhex(sha(f)), np.uint8), n_hits=int(hit.sum()))
+        if full:
+            d.update(range=rg.reshape(-1), tri=tri, label=label, endrem=rm.reshape(-1), endpoints=ep)
+        else:
+            idx = np.arange(0, H * W, max(1, (H * W) // 4096))
+            d.update(sample_idx=idx.astype(np.int64), range=rg.reshape(-1)[idx], tri=tri[idx], label=label[idx],
+                     endrem=rm.reshape(-1)[idx], endpoints=ep[idx],
+                     range_sha256=np.frombuffer(bytes.fromhex(sha(rg)), np.uint8),
+                     tri_sha256=np.frombuffer(bytes.fromhex(sha(tri)), np.uint8),
+                     label_sha256=np.frombuffer(bytes.fromhex(sha(label)), np.uint8))
+        np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **d)
+        print(tag, "faces", f.shape[0], "hits", int(hit.sum()), "of", H * W)
+
+    scene_case("f4_2k_16x64", 0, 2000, (3, -25), 16, 64, (0, 0, 0), True)
+    scene_case("f4_50k_64x256", 1, 50000, (3, -25), 64, 256, (0, 0, 0), True)
+    scene_case("f4_50k_offset_32x128", 2, 50000, (10, -30), 32, 128, (1.5, -2.25, 0.4), True)
+    scene_case("f4_20k_overlap_32x128", 3, 20000, (3, -25), 32, 128, (0, 0, 0), True, overlap=True)
+    scene_case("f5_c1_200k_64x1024", 0, 200000, (3, -25), 64, 1024, (0, 0, 0), False)
+    scene_case("f5_c2_1m_64x2048", 0, 1000000, (3, -25), 64, 2048, (0, 0, 0), False)
+
+    # ---- F6: spherical projections (laserscan.py:202-292, :294-391) ------------------------------------
+    color_dict = {0: [0, 0, 0], 10: [245, 150, 100], 40: [255, 0, 255], 48: [75, 0, 75], 50: [0, 200, 255],
+                  70: [0, 175, 0], 80: [150, 240, 255]}
+    f6 = {}
+    for tag, dtype, beams in (("f32", np.float32, None), ("f64", np.float64, None), ("f64_beams", np.float64, True)):
+        H, W, fu, fd = 16, 128, 3.0, -25.0
+        pts, rem_p, lab = synth_cloud(7, 5000, dtype=dtype, fov_up=fu, fov_down=fd)
+        pts[100] = 0  # depth == 0 -> removed
+        pts[200:210] = pts[300:310]  # duplicates: equal depth in the same cell pins the tie rule
+        beam_angles = list(np.deg2rad(np.linspace(fu, fd, H))) if beams else None
+        for fn in ("do_range_projection", "do_range_projection_new"):
+            scan = ls.SemLaserScan(H, W, 300, color_dict, None, beam_angles)
+            scan.points = pts.copy()
+            scan.remissions = rem_p.copy()
+            scan.label = lab.copy()
+            scan.colorize()
+            getattr(scan, fn)(fu, fd, remove=True)
+            key = f"{tag}_{'old' if fn == 'do_range_projection' else 'new'}"
+            f6[f"{key}_proj_range"] = np.asarray(scan.proj_range)
+            f6[f"{key}_proj_remissions"] = np.asarray(scan.proj_remissions)
+            f6[f"{key}_points_kept"] = np.asarray(scan.points)
+            f6[f"{key}_unproj_range"] = np.asarray(scan.unproj_range)
+            if fn == "do_range_projection":
+                f6[f"{key}_proj_idx"] = np.asarray(scan.proj_idx)
+                f6[f"{key}_proj_xyz"] = np.asarray(scan.proj_xyz)
+                f6[f"{key}_proj_mask"] = np.asarray(scan.proj_mask)
+            else:
+                f6[f"{key}_index"] = np.asarray(scan.index)
+                f6[f"{key}_label_image"] = np.asarray(scan.label_image)
+                f6[f"{key}_proj_x"] = np.asarray(scan.proj_x)
+                f6[f"{key}_proj_y"] = np.asarray(scan.proj_y)
+        f6[f"{tag}_points"] = pts
+        f6[f"{tag}_rem"] = rem_p
+        f6[f"{tag}_label"] = lab
+        if beams:
+            f6[f"{tag}_beam_angles"] = np.array(beam_angles)
+    f6["H"], f6["W"], f6["fov_up"], f6["fov_down"] = 16, 128, 3.0, -25.0
+    np.savez_compressed(os.path.join(HERE, "f6_range_projection.npz"), **f6)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
