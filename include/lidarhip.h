@@ -122,6 +122,55 @@ int lt_scene_status(lt_scene* scene);
 /* Free the workspace.  Replaces the delete loop RayTracer.cpp:110-113 and BVH::~BVH (BVH.cpp:112-114). */
 int lt_scene_destroy(lt_scene* scene);
 
+/* ---- scan model: rays and spherical projection ------------------------------------------------ */
+
+/* Unit ray direction per (beam, azimuth) cell into a DEVICE buffer rays[H*W*3] (f32, row-major
+ * h*W + w).  Replaces MultiSemLaserScan.create_rays (auxiliary/laserscan.py:1092-1119), quirks
+ * included: linspace(0, 360, W) holds both end points, beam_angles are ignored, float64
+ * trigonometry is cast to float32 last.  fov_up / fov_down in degrees. */
+int lt_create_rays_dev(double fov_up, double fov_down, int H, int W, float* rays, void* stream);
+
+#define LT_PROJ_REMOVE 1u /* `remove=True`: drop depth == 0 and points whose proj_y is outside [0, 1]   */
+#define LT_PROJ_NEW 2u    /* do_range_projection_new: depth == 0 is always dropped (laserscan.py:306-309) */
+
+/*
+ * lt_range_projection_dev -- point cloud -> H x W spherical image, closest point per cell (atomic
+ * z-min, lowest point index among equal depths).  Replaces LaserScan.do_range_projection
+ * (auxiliary/laserscan.py:202-292), do_range_projection_new(method="depth") (:294-391) and
+ * SemLaserScan.do_label_projection[_new] (:645-649, :672-676).
+ *
+ *   points      [n,3] f32 (is_f64 = 0) or f64 (is_f64 = 1) -- arithmetic is done in that dtype, as
+ *               numpy does for the array the reference holds; rem [n] f32 and label [n] u32 may be NULL
+ *   fov_up/down degrees (down negative); beam_angles: HOST array of n_beams radians or NULL
+ *   color_lut   DEVICE [lut_len,3] f32 or NULL (SemLaserScan.color_lut)
+ *   *_kept      per-point outputs COMPACTED to the points that survive the removals, in input
+ *               order (what remove_points leaves in self.points / remissions / label, plus depth
+ *               = unproj_range, integer and float pixel coordinates); capacity n; any may be NULL
+ *   *_img       [H*W] images: idx = index into the compacted arrays (-1 empty), range, xyz [H*W,3],
+ *               remission, label, color [H*W,3], mask = (idx > 0) as the reference computes it;
+ *               empty cells receive range_init / rem_init / xyz_init (reference: -1 for the old
+ *               variant, 0 / -1 for the new one), label 0, color 0
+ *   n_kept      HOST int: number of surviving points (the call synchronises `stream`)
+ * All array pointers are DEVICE pointers except beam_angles and n_kept.
+ */
+int lt_range_projection_dev(const void* points, int is_f64, const float* rem, const unsigned* label, int n,
+                            double fov_up, double fov_down, int H, int W, const double* beam_angles,
+                            int n_beams, unsigned flags, const float* color_lut, int lut_len,
+                            void* points_kept, float* rem_kept, unsigned* label_kept, void* depth_kept,
+                            int* proj_x_kept, int* proj_y_kept, void* proj_xf_kept, void* proj_yf_kept,
+                            int* idx_img, float* range_img, float* xyz_img, float* rem_img, int* label_img,
+                            float* color_img, float* mask_img, float range_init, float rem_init,
+                            float xyz_init, int* n_kept, void* stream);
+
+/* Same with HOST pointers throughout (uploads, runs lt_range_projection_dev, downloads). */
+int lt_range_projection(const void* points, int is_f64, const float* rem, const unsigned* label, int n,
+                        double fov_up, double fov_down, int H, int W, const double* beam_angles, int n_beams,
+                        unsigned flags, const float* color_lut, int lut_len, void* points_kept,
+                        float* rem_kept, unsigned* label_kept, void* depth_kept, int* proj_x_kept,
+                        int* proj_y_kept, void* proj_xf_kept, void* proj_yf_kept, int* idx_img,
+                        float* range_img, float* xyz_img, float* rem_img, int* label_img, float* color_img,
+                        float* mask_img, float range_init, float rem_init, float xyz_init, int* n_kept);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 
 /* Message of the last error raised on the calling thread ("" if none). */

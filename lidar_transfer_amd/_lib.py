@@ -15,11 +15,13 @@ LT_OK = 0
 LT_TRACE_WRITE_MISSES = 1
 LT_TRACE_COUNT = 2
 LT_TRACE_NORM_EXACT = 4
+LT_PROJ_REMOVE = 1
+LT_PROJ_NEW = 2
 
 #: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
            "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy", "lt_last_error",
-           "lt_version"]
+           "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection"]
 
 
 class Stats(C.Structure):
@@ -81,9 +83,15 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.lt_last_error.restype = C.c_char_p
     lib.lt_version.restype = C.c_char_p
-    if hasattr(lib, "lt_create_rays_dev"):
-        lib.lt_create_rays_dev.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
-        lib.lt_create_rays_dev.restype = C.c_int
+    lib.lt_create_rays_dev.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
+    lib.lt_create_rays_dev.restype = C.c_int
+    proj = [vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.c_int, C.c_uint, vp, C.c_int,
+            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float,
+            C.POINTER(C.c_int)]
+    lib.lt_range_projection.argtypes = proj
+    lib.lt_range_projection.restype = C.c_int
+    lib.lt_range_projection_dev.argtypes = proj + [vp]
+    lib.lt_range_projection_dev.restype = C.c_int
     _lib = lib
     return lib
 

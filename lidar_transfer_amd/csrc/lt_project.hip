@@ -1,0 +1,458 @@
+// lt_project.hip -- point cloud -> spherical range image with atomic z-min on gfx950.
+//
+// Replaces the numpy / pure-Python projections of the reference's scan model:
+//   LaserScan.do_range_projection        auxiliary/laserscan.py:202-292  (argsort by depth, scatter)
+//   LaserScan.do_range_projection_new    auxiliary/laserscan.py:294-391  (per-point Python z-min loop)
+//   SemLaserScan.do_label_projection[_new]  auxiliary/laserscan.py:645-649, :672-676
+// and create_rays (auxiliary/laserscan.py:1092-1119) as a device kernel.
+//
+// Semantics: the closest point of a cell wins; among equal depths the LOWEST point index wins --
+// exactly the `_new` loop (`depth[i] < range_image[...]`, laserscan.py:376) and one valid outcome of
+// the unstable argsort of the old variant.  Implemented as two order-independent atomic passes:
+// atomicMin of the depth bits per cell (positive IEEE doubles order like unsigned integers), then
+// atomicMin of the point index among the points that equal the cell minimum.
+//
+// Arithmetic follows numpy's dtype rules for the array the reference holds: float32 when the scan
+// was read from file (laserscan.py:131-136), float64 after a pose was applied (laserscan.py:98-104).
+// float32 transcendental results are the correctly rounded value (computed in double, rounded once).
+#include "lt_internal.h"
+#include <math.h>
+#include <mutex>
+
+#define LT_EMPTY_IDX 0x7F7F7F7F  // hipMemset(0x7F) pattern: larger than any point index
+
+template <typename T>
+struct proj_out {
+  int cell;   // py * W + px, or -1 when the point is dropped
+  T depth, xf, yf;
+  int px, py;
+};
+
+__device__ __forceinline__ float lt_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ double lt_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float lt_asin(float q) { return (float)asin((double)q); }
+__device__ __forceinline__ double lt_asin(double q) { return asin(q); }
+__device__ __forceinline__ float lt_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double lt_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float lt_floor(float v) { return floorf(v); }
+__device__ __forceinline__ double lt_floor(double v) { return floor(v); }
+
+// one point through laserscan.py:214-262 (resp. :304-351); all constants pre-rounded to T by the host
+template <typename T>
+__device__ __forceinline__ proj_out<T> project_point(T x, T y, T z, T pi_t, T abs_fov_down, T fov, int H, int W,
+                                                     const double* __restrict__ beams, int n_beams,
+                                                     bool drop_zero, bool drop_outside) {
+  proj_out<T> o;
+  const T depth = lt_sqrt((x * x + y * y) + z * z);  // np.linalg.norm(points, 2, axis=1)
+  T yaw = -lt_atan2(y, x);
+  T pitch = lt_asin(z / depth);
+  if (n_beams > 0) {  // nearest hard-coded beam angle, first minimum (laserscan.py:233-238)
+    double best = fabs((double)pitch - beams[0]);
+    int bi = 0;
+    for (int k = 1; k < n_beams; ++k) {
+      const double dlt = fabs((double)pitch - beams[k]);
+      if (dlt < best) { best = dlt; bi = k; }
+    }
+    pitch = (T)beams[bi];
+  }
+  T px = (T)0.5 * (yaw / pi_t + (T)1.0);
+  T py = (T)1.0 - (pitch + abs_fov_down) / fov;
+  bool keep = true;
+  if (drop_zero && depth == (T)0) keep = false;
+  if (drop_outside && !(py >= (T)0 && py <= (T)1)) keep = false;
+  if (!(depth == depth) || !(px == px) || !(py == py)) keep = false;  // NaN never reaches an image
+  px *= (T)W;
+  py *= (T)H;
+  o.xf = px;
+  o.yf = py;
+  T fx = lt_floor(px), fy = lt_floor(py);
+  fx = fx < (T)(W - 1) ? fx : (T)(W - 1);
+  fx = fx > (T)0 ? fx : (T)0;
+  fy = fy < (T)(H - 1) ? fy : (T)(H - 1);
+  fy = fy > (T)0 ? fy : (T)0;
+  o.px = (int)fx;
+  o.py = (int)fy;
+  o.depth = depth;
+  o.cell = keep ? o.py * W + o.px : -1;
+  return o;
+}
+
+// pass 1: project, z-min of the depth bits, per-workgroup count of kept points
+template <typename T>
+__global__ __launch_bounds__(256) void k_project(const T* __restrict__ pts, int n, T pi_t, T abs_fov_down, T fov,
+                                                 int H, int W, const double* __restrict__ beams, int n_beams,
+                                                 int drop_zero, int drop_outside, int round_key,
+                                                 int* __restrict__ cell,
+                                                 double* __restrict__ depth_d, T* __restrict__ xf,
+                                                 T* __restrict__ yf, unsigned long long* __restrict__ cellmin,
+                                                 int* __restrict__ blockcount) {
+  __shared__ int wcnt[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool keep = false;
+  if (i < n) {
+    const proj_out<T> o = project_point<T>(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], pi_t,
+                                           abs_fov_down, fov, H, W, beams, n_beams, drop_zero, drop_outside);
+    cell[i] = o.cell;
+    depth_d[i] = (double)o.depth;
+    xf[i] = o.xf;
+    yf[i] = o.yf;
+    keep = o.cell >= 0;
+    // `_new` keeps its running minimum in a float32 image (laserscan.py:366, :376): the cell minimum is
+    // taken over the float32-ROUNDED depths there
+    const double key = round_key ? (double)(float)o.depth : (double)o.depth;
+    if (keep) atomicMin(&cellmin[o.cell], (unsigned long long)__double_as_longlong(key));
+  }
+  const unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcount[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// exclusive scan of the workgroup counts (single workgroup), total -> blockcount[nblocks]
+__global__ __launch_bounds__(1024) void k_scan_counts(int* __restrict__ blockcount, int nblocks) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? blockcount[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (i < nblocks) blockcount[i] = carry + woff + inc - v;
+    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+    carry = carry_s;
+  }
+  if (threadIdx.x == 0) blockcount[nblocks] = carry;
+}
+
+// pass 2: compacted index of every kept point (stable), compacted per-point outputs, index z-min
+template <typename T>
+__global__ __launch_bounds__(256) void k_assign(const T* __restrict__ pts, const float* __restrict__ rem,
+                                                const unsigned* __restrict__ label, int n, int W,
+                                                const int* __restrict__ cell, const double* __restrict__ depth_d,
+                                                const T* __restrict__ xf, const T* __restrict__ yf,
+                                                const unsigned long long* __restrict__ cellmin,
+                                                const int* __restrict__ blockoff, int round_key,
+                                                int* __restrict__ idxmin, int* __restrict__ idxlast,
+                                                int* __restrict__ orig_of, T* __restrict__ pts_k,
+                                                float* __restrict__ rem_k, unsigned* __restrict__ label_k,
+                                                T* __restrict__ depth_k, int* __restrict__ px_k,
+                                                int* __restrict__ py_k, T* __restrict__ xf_k, T* __restrict__ yf_k) {
+  __shared__ int wcnt[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = i < n ? cell[i] : -1;
+  const bool keep = c >= 0;
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wcnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = blockoff[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += wcnt[w];
+  if (!keep) return;
+  const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+  orig_of[k] = i;
+  const double d = depth_d[i];
+  if (pts_k) {
+    pts_k[3 * (size_t)k] = pts[3 * (size_t)i];
+    pts_k[3 * (size_t)k + 1] = pts[3 * (size_t)i + 1];
+    pts_k[3 * (size_t)k + 2] = pts[3 * (size_t)i + 2];
+  }
+  if (rem_k && rem) rem_k[k] = rem[i];
+  if (label_k && label) label_k[k] = label[i];
+  if (depth_k) depth_k[k] = (T)d;
+  if (px_k) px_k[k] = c % W;
+  if (py_k) py_k[k] = c / W;
+  if (xf_k) xf_k[k] = xf[i];
+  if (yf_k) yf_k[k] = yf[i];
+  const double key = round_key ? (double)(float)d : d;
+  const unsigned long long mbits = cellmin[c];
+  if ((unsigned long long)__double_as_longlong(key) == mbits) {
+    atomicMin(&idxmin[c], k);
+    // `depth[i] < range_image[cell]` compares a float64 depth with the float32-rounded minimum: every
+    // later point of the minimum's float32 bucket that rounded UP replaces the incumbent (see k_resolve)
+    if (round_key && d < __longlong_as_double((long long)mbits)) atomicMax(&idxlast[c], k);
+  }
+}
+
+// pass 3: one thread per cell gathers the winner (laserscan.py:283-292, :376-382, :645-649)
+template <typename T>
+__global__ __launch_bounds__(256) void k_resolve(const T* __restrict__ pts, const float* __restrict__ rem,
+                                                 const unsigned* __restrict__ label, const double* __restrict__ depth_d,
+                                                 const int* __restrict__ idxmin, const int* __restrict__ idxlast,
+                                                 const int* __restrict__ orig_of, int ncells, const float* __restrict__ lut, int lut_len,
+                                                 float range_init, float rem_init, float xyz_init,
+                                                 int* __restrict__ idx_img, float* __restrict__ range_img,
+                                                 float* __restrict__ xyz_img, float* __restrict__ rem_img,
+                                                 int* __restrict__ label_img, float* __restrict__ color_img,
+                                                 float* __restrict__ mask_img) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  // winner of the reference's sequential loop: the first point of the minimum bucket, unless later points
+  // of that bucket lie below the float32 minimum -- then the last of those (idxlast is -1 otherwise and
+  // always for float32 input, where rounding is the identity)
+  const int first = idxmin[c], last = idxlast[c];
+  const int k = (last >= 0 && last != first) ? last : first;
+  const bool has = first != LT_EMPTY_IDX;
+  const int i = has ? orig_of[k] : 0;
+  if (idx_img) idx_img[c] = has ? k : -1;
+  if (range_img) range_img[c] = has ? (float)depth_d[i] : range_init;
+  if (xyz_img) {
+    xyz_img[3 * (size_t)c] = has ? (float)pts[3 * (size_t)i] : xyz_init;
+    xyz_img[3 * (size_t)c + 1] = has ? (float)pts[3 * (size_t)i + 1] : xyz_init;
+    xyz_img[3 * (size_t)c + 2] = has ? (float)pts[3 * (size_t)i + 2] : xyz_init;
+  }
+  if (rem_img) rem_img[c] = (has && rem) ? rem[i] : rem_init;
+  const unsigned lab = (has && label) ? label[i] : 0u;
+  if (label_img) label_img[c] = (int)lab;
+  if (color_img) {
+    const bool ok = has && lut && (int)lab < lut_len;
+    color_img[3 * (size_t)c] = ok ? lut[3 * (size_t)lab] : 0.f;
+    color_img[3 * (size_t)c + 1] = ok ? lut[3 * (size_t)lab + 1] : 0.f;
+    color_img[3 * (size_t)c + 2] = ok ? lut[3 * (size_t)lab + 2] : 0.f;
+  }
+  if (mask_img) mask_img[c] = (has && k > 0) ? 1.f : 0.f;  // proj_idx > 0 (sic, laserscan.py:292)
+}
+
+// ---- create_rays (laserscan.py:1092-1119): float64 trigonometry, cast to float32 last ---------------------
+__global__ __launch_bounds__(256) void k_create_rays(double fov_up, double fov_down, int H, int W,
+                                                     float* __restrict__ rays) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * W) return;
+  const int h = idx / W, w = idx - h * W;
+  // np.linspace(a, b, n)[i] = a + i * ((b - a) / (n - 1)), last element forced to b
+  double yaw_deg = W > 1 ? (w == W - 1 ? 360.0 : 0.0 + w * (360.0 / (W - 1))) : 0.0;
+  yaw_deg += 180.0;
+  if (yaw_deg > 360.0) yaw_deg -= 360.0;
+  const double yaw = yaw_deg / 180. * M_PI;
+  double pd = H > 1 ? (h == H - 1 ? fov_down : fov_up + h * ((fov_down - fov_up) / (H - 1))) : fov_up;
+  const double p = M_PI / 2 - pd / 180. * M_PI;
+  const double sp = sin(p);
+  rays[3 * (size_t)idx] = (float)(sp * cos(-yaw));
+  rays[3 * (size_t)idx + 1] = (float)(sp * sin(-yaw));
+  rays[3 * (size_t)idx + 2] = (float)(cos(p) * 1.0);
+}
+
+extern "C" int lt_create_rays_dev(double fov_up, double fov_down, int H, int W, float* rays, void* stream) {
+  if (H <= 0 || W <= 0 || !rays) {
+    lt_set_error("lt_create_rays_dev: invalid argument (H=%d W=%d)", H, W);
+    return LT_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(k_create_rays, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, fov_up, fov_down,
+                     H, W, rays);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
+// ---- host orchestration -------------------------------------------------------------------------------------
+namespace {
+struct proj_ws {
+  int device = -1;
+  size_t cap_n = 0, cap_cells = 0;
+  int* cell = nullptr;
+  double* depth_d = nullptr;
+  void* xf = nullptr;
+  void* yf = nullptr;
+  int* blockcount = nullptr;
+  int* orig_of = nullptr;
+  unsigned long long* cellmin = nullptr;
+  int* idxmin = nullptr;
+  int* idxlast = nullptr;
+  double* beams = nullptr;
+};
+std::mutex g_pmu;
+proj_ws g_pws;
+
+void pws_free(proj_ws& w) {
+  void* ps[] = {w.cell, w.depth_d, w.xf, w.yf, w.blockcount, w.orig_of, w.cellmin, w.idxmin, w.idxlast, w.beams};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+  w = proj_ws();
+}
+
+int pws_reserve(proj_ws& w, int device, size_t n, size_t cells) {
+  if (w.device == device && n <= w.cap_n && cells <= w.cap_cells) return LT_OK;
+  if (w.device >= 0) {
+    LT_HIP(hipDeviceSynchronize());
+    pws_free(w);
+  }
+  const size_t cn = n + n / 4 + 1024, cc = cells + 1024;
+  LT_HIP(hipMalloc((void**)&w.cell, cn * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&w.depth_d, cn * sizeof(double)));
+  LT_HIP(hipMalloc(&w.xf, cn * sizeof(double)));
+  LT_HIP(hipMalloc(&w.yf, cn * sizeof(double)));
+  LT_HIP(hipMalloc((void**)&w.blockcount, (cn / 256 + 2) * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&w.orig_of, cn * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&w.cellmin, cc * sizeof(unsigned long long)));
+  LT_HIP(hipMalloc((void**)&w.idxmin, cc * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&w.idxlast, cc * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&w.beams, 1024 * sizeof(double)));
+  w.device = device;
+  w.cap_n = cn;
+  w.cap_cells = cc;
+  return LT_OK;
+}
+
+template <typename T>
+int run_projection(proj_ws& w, const T* pts, const float* rem, const unsigned* label, int n, double fov_up_deg,
+                   double fov_down_deg, int H, int W, int n_beams, unsigned flags, const float* lut, int lut_len,
+                   T* pts_k, float* rem_k, unsigned* label_k, T* depth_k, int* px_k, int* py_k, T* xf_k, T* yf_k,
+                   int* idx_img, float* range_img, float* xyz_img, float* rem_img, int* label_img, float* color_img,
+                   float* mask_img, float range_init, float rem_init, float xyz_init, int* n_kept, hipStream_t st) {
+  // laser parameters exactly as laserscan.py:207-209 (python floats), then rounded once to the array dtype
+  const double fu = fov_up_deg / 180.0 * M_PI, fd = fov_down_deg / 180.0 * M_PI;
+  const double fov = fabs(fd) + fabs(fu);
+  const int cells = H * W;
+  const int nb = (n + 255) / 256;
+  LT_HIP(hipMemsetAsync(w.cellmin, 0xFF, (size_t)cells * sizeof(unsigned long long), st));
+  LT_HIP(hipMemsetAsync(w.idxmin, 0x7F, (size_t)cells * sizeof(int), st));
+  LT_HIP(hipMemsetAsync(w.idxlast, 0xFF, (size_t)cells * sizeof(int), st));
+  const int round_key = (flags & LT_PROJ_NEW) ? 1 : 0;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_project<T>, dim3(nb), dim3(256), 0, st, pts, n, (T)M_PI, (T)fabs(fd), (T)fov, H, W,
+                       (const double*)w.beams, n_beams, (flags & (LT_PROJ_REMOVE | LT_PROJ_NEW)) ? 1 : 0,
+                       (flags & LT_PROJ_REMOVE) ? 1 : 0, round_key, w.cell, w.depth_d, (T*)w.xf, (T*)w.yf, w.cellmin,
+                       w.blockcount);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.blockcount, nb);
+    hipLaunchKernelGGL(k_assign<T>, dim3(nb), dim3(256), 0, st, pts, rem, label, n, W, (const int*)w.cell,
+                       (const double*)w.depth_d, (const T*)w.xf, (const T*)w.yf,
+                       (const unsigned long long*)w.cellmin, (const int*)w.blockcount, round_key, w.idxmin,
+                       w.idxlast, w.orig_of, pts_k,
+                       rem_k, label_k, depth_k, px_k, py_k, xf_k, yf_k);
+  }
+  hipLaunchKernelGGL(k_resolve<T>, dim3((cells + 255) / 256), dim3(256), 0, st, pts, rem, label,
+                     (const double*)w.depth_d, (const int*)w.idxmin, (const int*)w.idxlast, (const int*)w.orig_of,
+                     cells, lut, lut_len,
+                     range_init, rem_init, xyz_init, idx_img, range_img, xyz_img, rem_img, label_img, color_img,
+                     mask_img);
+  LT_HIP(hipGetLastError());
+  int kept = 0;
+  if (n > 0) LT_HIP(hipMemcpyAsync(&kept, w.blockcount + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+  LT_HIP(hipStreamSynchronize(st));
+  if (n_kept) *n_kept = kept;
+  return LT_OK;
+}
+}  // namespace
+
+extern "C" int lt_range_projection_dev(const void* points, int is_f64, const float* rem, const unsigned* label,
+                                       int n, double fov_up, double fov_down, int H, int W,
+                                       const double* beam_angles, int n_beams, unsigned flags,
+                                       const float* color_lut, int lut_len, void* points_kept, float* rem_kept,
+                                       unsigned* label_kept, void* depth_kept, int* proj_x_kept, int* proj_y_kept,
+                                       void* proj_xf_kept, void* proj_yf_kept, int* idx_img, float* range_img,
+                                       float* xyz_img, float* rem_img, int* label_img, float* color_img,
+                                       float* mask_img, float range_init, float rem_init, float xyz_init,
+                                       int* n_kept, void* stream) {
+  if (n < 0 || H <= 0 || W <= 0 || (n > 0 && !points) || n_beams < 0 || n_beams > 1024 ||
+      (n_beams > 0 && !beam_angles)) {
+    lt_set_error("lt_range_projection: invalid argument (n=%d H=%d W=%d n_beams=%d)", n, H, W, n_beams);
+    return LT_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lock(g_pmu);
+  int dev = 0;
+  LT_HIP(hipGetDevice(&dev));
+  LT_CHECK(pws_reserve(g_pws, dev, (size_t)n, (size_t)H * W));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_beams > 0)
+    LT_HIP(hipMemcpyAsync(g_pws.beams, beam_angles, n_beams * sizeof(double), hipMemcpyHostToDevice, st));
+  if (is_f64)
+    return run_projection<double>(g_pws, (const double*)points, rem, label, n, fov_up, fov_down, H, W, n_beams, flags,
+                                  color_lut, lut_len, (double*)points_kept, rem_kept, label_kept, (double*)depth_kept,
+                                  proj_x_kept, proj_y_kept, (double*)proj_xf_kept, (double*)proj_yf_kept, idx_img,
+                                  range_img, xyz_img, rem_img, label_img, color_img, mask_img, range_init, rem_init,
+                                  xyz_init, n_kept, st);
+  return run_projection<float>(g_pws, (const float*)points, rem, label, n, fov_up, fov_down, H, W, n_beams, flags,
+                               color_lut, lut_len, (float*)points_kept, rem_kept, label_kept, (float*)depth_kept,
+                               proj_x_kept, proj_y_kept, (float*)proj_xf_kept, (float*)proj_yf_kept, idx_img,
+                               range_img, xyz_img, rem_img, label_img, color_img, mask_img, range_init, rem_init,
+                               xyz_init, n_kept, st);
+}
+
+// Host-pointer convenience: stages everything through device buffers, same semantics.
+extern "C" int lt_range_projection(const void* points, int is_f64, const float* rem, const unsigned* label, int n,
+                                   double fov_up, double fov_down, int H, int W, const double* beam_angles,
+                                   int n_beams, unsigned flags, const float* color_lut, int lut_len,
+                                   void* points_kept, float* rem_kept, unsigned* label_kept, void* depth_kept,
+                                   int* proj_x_kept, int* proj_y_kept, void* proj_xf_kept, void* proj_yf_kept,
+                                   int* idx_img, float* range_img, float* xyz_img, float* rem_img, int* label_img,
+                                   float* color_img, float* mask_img, float range_init, float rem_init,
+                                   float xyz_init, int* n_kept) {
+  if (n < 0 || H <= 0 || W <= 0 || (n > 0 && !points)) {
+    lt_set_error("lt_range_projection: invalid argument (n=%d H=%d W=%d)", n, H, W);
+    return LT_ERR_INVALID_ARG;
+  }
+  const size_t es = is_f64 ? 8 : 4, cells = (size_t)H * W, N = (size_t)n;
+  // one staging allocation: inputs | per-point outputs | images
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz[] = {al(N * 3 * es), al(N * 4), al(N * 4), al((size_t)(lut_len > 0 ? lut_len : 0) * 12),
+                       al(N * 3 * es), al(N * 4), al(N * 4), al(N * es), al(N * 4), al(N * 4), al(N * es), al(N * es),
+                       al(cells * 4), al(cells * 4), al(cells * 12), al(cells * 4), al(cells * 4), al(cells * 12),
+                       al(cells * 4)};
+  size_t total = 256;
+  for (size_t s : sz) total += s;
+  char* base = nullptr;
+  LT_HIP(hipMalloc((void**)&base, total));
+  char* p[19];
+  {
+    size_t off = 0;
+    for (int k = 0; k < 19; ++k) { p[k] = base + off; off += sz[k]; }
+  }
+  int rc = LT_OK;
+  auto H2D = [&](void* d, const void* h, size_t b) {
+    if (rc == LT_OK && h && b && hipMemcpy(d, h, b, hipMemcpyHostToDevice) != hipSuccess) {
+      lt_set_error("lt_range_projection: H2D copy failed");
+      rc = LT_ERR_HIP;
+    }
+  };
+  H2D(p[0], points, N * 3 * es);
+  H2D(p[1], rem, N * 4);
+  H2D(p[2], label, N * 4);
+  H2D(p[3], color_lut, (size_t)(lut_len > 0 ? lut_len : 0) * 12);
+  int kept = 0;
+  if (rc == LT_OK)
+    rc = lt_range_projection_dev(p[0], is_f64, rem ? (float*)p[1] : nullptr, label ? (unsigned*)p[2] : nullptr, n,
+                                 fov_up, fov_down, H, W, beam_angles, n_beams, flags,
+                                 (color_lut && lut_len > 0) ? (float*)p[3] : nullptr, lut_len,
+                                 points_kept ? p[4] : nullptr, rem_kept ? (float*)p[5] : nullptr,
+                                 label_kept ? (unsigned*)p[6] : nullptr, depth_kept ? p[7] : nullptr,
+                                 proj_x_kept ? (int*)p[8] : nullptr, proj_y_kept ? (int*)p[9] : nullptr,
+                                 proj_xf_kept ? p[10] : nullptr, proj_yf_kept ? p[11] : nullptr,
+                                 idx_img ? (int*)p[12] : nullptr, range_img ? (float*)p[13] : nullptr,
+                                 xyz_img ? (float*)p[14] : nullptr, rem_img ? (float*)p[15] : nullptr,
+                                 label_img ? (int*)p[16] : nullptr, color_img ? (float*)p[17] : nullptr,
+                                 mask_img ? (float*)p[18] : nullptr, range_init, rem_init, xyz_init, &kept, nullptr);
+  auto D2H = [&](void* h, const void* d, size_t b) {
+    if (rc == LT_OK && h && b && hipMemcpy(h, d, b, hipMemcpyDeviceToHost) != hipSuccess) {
+      lt_set_error("lt_range_projection: D2H copy failed");
+      rc = LT_ERR_HIP;
+    }
+  };
+  const size_t K = (size_t)kept;
+  D2H(points_kept, p[4], K * 3 * es);
+  D2H(rem_kept, p[5], K * 4);
+  D2H(label_kept, p[6], K * 4);
+  D2H(depth_kept, p[7], K * es);
+  D2H(proj_x_kept, p[8], K * 4);
+  D2H(proj_y_kept, p[9], K * 4);
+  D2H(proj_xf_kept, p[10], K * es);
+  D2H(proj_yf_kept, p[11], K * es);
+  D2H(idx_img, p[12], cells * 4);
+  D2H(range_img, p[13], cells * 4);
+  D2H(xyz_img, p[14], cells * 12);
+  D2H(rem_img, p[15], cells * 4);
+  D2H(label_img, p[16], cells * 4);
+  D2H(color_img, p[17], cells * 12);
+  D2H(mask_img, p[18], cells * 4);
+  (void)hipFree(base);
+  if (n_kept) *n_kept = kept;
+  return rc;
+}

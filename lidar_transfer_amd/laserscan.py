@@ -22,3 +22,177 @@ def create_rays(fov_up, fov_down, H, W):
     beams[:, :, 1] = sp[:, None] * np.sin(-yaw)[None, :]
     beams[:, :, 2] = cp[:, None] * np.ones(W)[None, :]
     return np.ascontiguousarray(beams.reshape(H * W, 3).astype(np.float32))
+
+
+def create_rays_device(fov_up, fov_down, H, W, device=None, stream=None):
+    """:func:`create_rays` computed by the HIP kernel into a ``torch`` tensor ``[H*W, 3] f32`` on the GPU."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    out = torch.empty((H * W, 3), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev) if stream is None else stream
+    with torch.cuda.device(dev):
+        _lib.check(lib.lt_create_rays_dev(float(fov_up), float(fov_down), int(H), int(W), out.data_ptr(),
+                                          C.c_void_p(st.cuda_stream)), "lt_create_rays_dev")
+    return out
+
+
+class LaserScan:
+    """Spherical projection part of the reference's ``LaserScan`` (auxiliary/laserscan.py:14-292),
+    computed by ``liblidarhip.so`` (``lt_range_projection``, HIP atomic z-min).
+
+    Same attribute names, dtypes and "no data" values as the reference's ``reset()``
+    (laserscan.py:28-53).  File I/O, pose handling and visualisation are out of scope: set
+    ``points`` ([N,3] float32 or float64), ``remissions`` ([N] float32) directly.
+    """
+
+    def __init__(self, H, W, transformation=None, beam_angles=None):
+        self.proj_H = H
+        self.proj_W = W
+        self.beam_angles = beam_angles
+        self.reset()
+
+    def reset(self):
+        H, W = self.proj_H, self.proj_W
+        self.points = np.zeros((0, 3), dtype=np.float32)
+        self.remissions = np.zeros((0,), dtype=np.float32)
+        self.proj_range = np.full((H, W), -1, dtype=np.float32)
+        self.proj_xyz = np.full((H, W, 3), -1, dtype=np.float32)
+        self.proj_remissions = np.full((H, W), -1, dtype=np.float32)
+        self.proj_idx = np.full((H, W), -1, dtype=np.int32)
+        self.proj_x = np.zeros((0, 1), dtype=np.float32)
+        self.proj_y = np.zeros((0, 1), dtype=np.float32)
+        self.unproj_range = np.zeros((0, 1), dtype=np.float32)
+        self.proj_mask = np.zeros((H, W), dtype=np.int32)
+        self.label = np.zeros((0,), dtype=np.uint32)
+        self.label_color = np.zeros((0, 3), dtype=np.float32)
+
+    def size(self):
+        return self.points.shape[0]
+
+    def __len__(self):
+        return self.size()
+
+    # ---- shared driver ---------------------------------------------------------------------------------
+    def _project(self, fov_up, fov_down, flags, range_init, rem_init, xyz_init, color_lut=None):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        H, W = self.proj_H, self.proj_W
+        pts = np.ascontiguousarray(self.points)
+        if pts.dtype not in (np.float32, np.float64):
+            pts = pts.astype(np.float64)
+        is64 = pts.dtype == np.float64
+        n = pts.shape[0]
+        rem = np.ascontiguousarray(self.remissions, dtype=np.float32) if len(self.remissions) == n else None
+        lab = np.ascontiguousarray(self.label, dtype=np.uint32) if len(getattr(self, "label", ())) == n else None
+        lut = np.ascontiguousarray(color_lut, dtype=np.float32) if color_lut is not None else None
+        beams = np.ascontiguousarray(self.beam_angles, dtype=np.float64) if self.beam_angles else None
+        ft = pts.dtype
+        o = dict(points=np.empty((n, 3), ft), rem=np.empty(n, np.float32), label=np.empty(n, np.uint32),
+                 depth=np.empty(n, ft), px=np.empty(n, np.int32), py=np.empty(n, np.int32), xf=np.empty(n, ft),
+                 yf=np.empty(n, ft), idx=np.empty((H, W), np.int32), range=np.empty((H, W), np.float32),
+                 xyz=np.empty((H, W, 3), np.float32), remi=np.empty((H, W), np.float32),
+                 labi=np.empty((H, W), np.int32), col=np.empty((H, W, 3), np.float32),
+                 mask=np.empty((H, W), np.float32))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+        kept = C.c_int(0)
+        rc = lib.lt_range_projection(vp(pts), int(is64), vp(rem), vp(lab), n, float(fov_up), float(fov_down), H, W,
+                                     vp(beams), 0 if beams is None else len(beams), flags, vp(lut),
+                                     0 if lut is None else lut.shape[0], vp(o["points"]),
+                                     vp(o["rem"]) if rem is not None else None,
+                                     vp(o["label"]) if lab is not None else None, vp(o["depth"]), vp(o["px"]),
+                                     vp(o["py"]), vp(o["xf"]), vp(o["yf"]), vp(o["idx"]), vp(o["range"]), vp(o["xyz"]),
+                                     vp(o["remi"]), vp(o["labi"]), vp(o["col"]), vp(o["mask"]), range_init, rem_init,
+                                     xyz_init, C.byref(kept))
+        _lib.check(rc, "lt_range_projection")
+        k = kept.value
+        # what remove_points (laserscan.py:139-148) leaves behind
+        self.points = o["points"][:k]
+        if rem is not None:
+            self.remissions = o["rem"][:k]
+        if lab is not None:
+            self.label = o["label"][:k]
+            if hasattr(self, "color_lut") and len(self.label_color) == n:
+                self.label_color = self.color_lut[self.label].reshape((-1, 3))  # colorize() of the kept points
+        for key in ("depth", "px", "py", "xf", "yf"):
+            o[key] = o[key][:k]
+        return o
+
+    def do_range_projection(self, fov_up, fov_down, remove=False):
+        """Mirror of laserscan.py:202-292 (closest point per cell; lowest index among equal depths)."""
+        from . import _lib
+        o = self._project(fov_up, fov_down, _lib.LT_PROJ_REMOVE if remove else 0, -1.0, -1.0, -1.0)
+        self.unproj_range = o["depth"].copy()
+        self.depth = o["depth"]
+        self.proj_range = o["range"]
+        self.proj_xyz = o["xyz"]
+        self.proj_remissions = o["remi"]
+        self.proj_idx = o["idx"]
+        self.proj_x = o["px"]
+        self.proj_y = o["py"]
+        self.proj_mask = o["mask"]
+        self._last = o
+
+    def do_range_projection_new(self, fov_up, fov_down, remove=False, method="depth"):
+        """Mirror of laserscan.py:294-391, ``method="depth"`` (the only branch any caller reaches)."""
+        if method != "depth":
+            raise ValueError("only method='depth' is on the reference's call paths (laserscan.py:841, :952)")
+        from . import _lib
+        lut = getattr(self, "color_lut", None)
+        o = self._project(fov_up, fov_down, _lib.LT_PROJ_NEW | (_lib.LT_PROJ_REMOVE if remove else 0), 0.0, -1.0, 0.0,
+                          color_lut=lut)
+        self.index = o["idx"]
+        self.range_image = o["range"]
+        self.proj_range = self.range_image
+        self.proj_remissions = o["remi"]
+        self.label_image = o["labi"].astype(np.float64)[:, :, None]
+        self.label_color_image = o["col"].astype(np.float64)
+        n = o["px"].shape[0]
+        if n:  # numpy fancy indexing with -1 wraps to the last point (laserscan.py:384-388)
+            self.proj_y = o["py"][self.index]
+            self.proj_x = o["px"][self.index]
+            self.proj_y_float = o["yf"][self.index]
+            self.proj_x_float = o["xf"][self.index]
+        self.unproj_range = o["depth"].copy()
+        self._last = o
+
+
+class SemLaserScan(LaserScan):
+    """Label part of the reference's ``SemLaserScan`` (auxiliary/laserscan.py:537-676)."""
+
+    def __init__(self, H, W, nclasses, color_dict=None, transformation=None, beam_angles=None):
+        super().__init__(H, W, transformation, beam_angles)
+        self.nclasses = nclasses
+        self.color_dict = color_dict or {}
+        max_key = max([k + 1 for k in self.color_dict] + [0])
+        self.color_lut = np.zeros((max_key + 100, 3), dtype=np.float32)
+        for key, value in self.color_dict.items():
+            self.color_lut[key] = np.array(value, np.float32) / 255.0
+        self.proj_label = np.zeros((H, W), dtype=np.int32)
+        self.proj_color = np.zeros((H, W, 3), dtype=np.float64)
+
+    def colorize(self):
+        self.label_color = self.color_lut[self.label].reshape((-1, 3))
+
+    def do_label_projection(self):
+        """laserscan.py:645-649 -- the label/colour of the winning point was gathered by the resolve kernel."""
+        o = self._last
+        mask = self.proj_idx >= 0
+        self.proj_label = np.where(mask, o["labi"], 0).astype(np.int32)
+        self.proj_color = np.where(mask[:, :, None], self._color_of(o), 0.0)
+
+    def do_label_projection_new(self):
+        """laserscan.py:672-676."""
+        o = self._last
+        mask = self.index >= 0
+        self.proj_label = np.where(mask, o["labi"], 0).astype(np.int32)
+        self.proj_color = np.where(mask[:, :, None], self._color_of(o), 0.0)
+
+    def _color_of(self, o):
+        return self.color_lut[np.clip(o["labi"], 0, self.color_lut.shape[0] - 1)].astype(np.float64)
