@@ -1,0 +1,66 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the scan-parallel driver: partitioning and the
+single gather reproduce the single-process result byte for byte."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lidar_transfer_amd.dist import partition, render_scans, scan_indices
+
+
+def test_scan_indices_follow_the_reference_batch_loop():
+    assert scan_indices(10) == list(range(10))
+    assert scan_indices(10, nscans=5) == [2, 3, 4, 5]          # automatic offset nscans//2, stop at n-(nscans-1)
+    assert scan_indices(4541, nscans=1, offset=0, batch_interval=10)[-1] == 4540
+    assert scan_indices(100, nscans=3, offset=7, batch_interval=10) == list(range(7, 98, 10))
+    assert scan_indices(3, nscans=5) == []
+
+
+def test_partition_blocks():
+    items = list(range(11))
+    parts = [partition(items, 4, r) for r in range(4)]
+    assert sum(parts, []) == items and [len(p) for p in parts] == [3, 3, 3, 2]
+    assert partition([], 2, 1) == [] and partition([5], 2, 1) == [] and partition([5], 2, 0) == [5]
+
+
+def _fake_render(idx):
+    g = torch.Generator().manual_seed(idx)
+    return {"range": torch.rand(8 * 16, generator=g), "label": torch.randint(0, 260, (8 * 16, 3), generator=g,
+                                                                              dtype=torch.int32)}
+
+
+def _worker(rank, world, port, indices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = render_scans(indices, _fake_render, ("range", "label"))
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in out.items()})
+    else:
+        assert out["range"] is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 2, 1])
+def test_render_scans_two_ranks_equals_one(n):
+    indices = list(range(3, 3 + n))
+    single = render_scans(indices, _fake_render, ("range", "label"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, indices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got["range"], single["range"].numpy())
+    assert np.array_equal(got["label"], single["label"].numpy())

@@ -243,3 +243,24 @@ def test_golden_synthetic_scenes(path):
         ulp = np.spacing(np.abs(g["range"][diff]).astype(np.float32))
         assert np.all(rg[diff] <= g["range"][diff]) and np.all(g["range"][diff] - rg[diff] <= 2 * ulp)
         assert diff.size <= 0.02 * idx.size
+
+
+def test_throw_rays_at_mesh_tuple_matches_reference_layout():
+    """fusion.throw_rays_at_mesh returns the reference's 7-tuple (fusion_lidar.py:453-455) and, on the
+    golden scene, the reference's images."""
+    from lidar_transfer_amd.fusion import MeshVolume, unpack_deform
+    g = np.load(os.path.join(GOLD, "f4_2k_16x64.npz"))
+    v, f, c, r = synth_scene(int(g["seed"]), int(g["ntri"]))
+    H, W = int(g["H"]), int(g["W"])
+    rays = create_rays(g["fov"][0], g["fov"][1], H, W)
+    vol = MeshVolume(v, f, c.astype(np.uint8), r)  # get_mesh hands out uint8 colours (fusion_lidar.py:422-423)
+    ep, rc, verts, colors, faces, rg, rm = vol.throw_rays_at_mesh(rays, np.zeros(3, np.float32), H, W, None)
+    assert ep.shape == (H * W, 3) and ep.dtype == np.float32 and rc.shape == (H * W, 3) and rc.dtype == np.int32
+    assert rg.shape == (H, W) and rm.shape == (H, W) and verts is v and faces is f
+    _assert_bits(rg.reshape(-1), g["range"], "range")
+    _assert_bits(rm.reshape(-1), g["endrem"], "endrem")
+    assert np.array_equal(rc[:, 2], g["label"])
+    assert np.array_equal(vol.last_tri_image.reshape(-1), g["tri"])
+    lut = np.arange(300 * 3, dtype=np.float32).reshape(300, 3)
+    label_image, proj_color = unpack_deform(rc, lut, H, W)
+    assert label_image.shape == (H, W) and proj_color.shape == (H, W, 3)
