@@ -32,9 +32,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
-# algorithmic bytes per unit (DESIGN.md "Roofline"): one BVH node = 64 B, one triangle record = 48 B,
+# algorithmic bytes per unit (DESIGN.md "Roofline"): one 4-wide BVH node = 128 B, one triangle record = 48 B,
 # per ray 12 B direction in + 44 B out (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
-B_NODE, B_TRI, B_RAY = 64, 48, 12 + 44 + 40
+B_NODE, B_TRI, B_RAY = 128, 48, 12 + 44 + 40
 
 
 def parse():
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "4")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=0, help="reference runs for the CPU baseline (0 = auto)")
@@ -218,7 +218,7 @@ def main():
             "trace_only_Mrays_s": round(R / (trace_ms * 1e-3) / 1e6, 2),
             "phase_ms": {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"},
             "hit_fraction": round(hits / R, 4),
-            "roofline": {"kernel": "k_trace", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_trace4", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "avg_kernel_ms": round(trace_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "nodes_per_ray": round(n_nodes / R, 2), "tris_per_ray": round(n_tris / R, 2)},

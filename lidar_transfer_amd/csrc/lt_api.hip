@@ -35,6 +35,8 @@ static void ws_free(lt_scene* s) {
   if (s->tris) (void)hipFree(s->tris);
   if (s->seg) (void)hipFree(s->seg);
   if (s->nodes) (void)hipFree(s->nodes);
+  if (s->nodes4) (void)hipFree(s->nodes4);
+  s->nodes4 = nullptr;
   s->hist = nullptr; s->tris = nullptr; s->seg = nullptr; s->nodes = nullptr;
   s->cap_faces = 0;
 }
@@ -57,6 +59,7 @@ int lt_scene_reserve(lt_scene* s, int n_faces) {
   LT_CHECK(dev_alloc(&s->tris, 3 * cap));
   LT_CHECK(dev_alloc(&s->seg, 4 * np));
   LT_CHECK(dev_alloc(&s->nodes, 4 * cap));
+  LT_CHECK(dev_alloc(&s->nodes4, 8 * cap));
   s->cap_faces = (int)cap;
   return LT_OK;
 }
@@ -69,7 +72,7 @@ int lt_scene_reserve_rays(lt_scene* s, int n_rays) {
     (void)hipFree(s->overflow);
     s->overflow = nullptr;
   }
-  LT_CHECK(dev_alloc(&s->overflow, (size_t)n_rays * (LT_STACK_MAX - LT_STACK_LDS)));
+  LT_CHECK(dev_alloc(&s->overflow, (size_t)n_rays * (LT_STACK4_MAX - LT_STACK4_LDS)));  // >= the binary kernel's 32
   s->cap_rays = n_rays;
   return LT_OK;
 }
@@ -91,7 +94,7 @@ extern "C" int lt_scene_create(lt_scene** out, int device) {
   int rc = dev_alloc(&s->partial, 6 * LT_BOUNDS_BLOCKS);
   if (rc == LT_OK) rc = dev_alloc(&s->params, 8);
   if (rc == LT_OK) rc = dev_alloc(&s->flags, 4);
-  if (rc == LT_OK) rc = dev_alloc(&s->counters, 4);
+  if (rc == LT_OK) rc = dev_alloc(&s->counters, 8 + 2 * LT_DBG_WAVES);
   if (rc == LT_OK && hipMemset(s->flags, 0, 4 * sizeof(unsigned)) != hipSuccess) rc = LT_ERR_HIP;
   for (int k = 0; rc == LT_OK && k < 10; ++k) {
     if (hipEventCreate(&s->ev[k]) != hipSuccess) {
@@ -212,6 +215,15 @@ extern "C" int lt_scene_trace_dev(lt_scene* s, const float* rays, const float* o
   LT_HIP(hipSetDevice(s->device));
   return lt_trace_launch(s, rays, origin, n_rays, height, endpoints, endcolors, range, endrem, tri, flags,
                          (hipStream_t)stream, stats);
+}
+
+// debug helper (not part of the documented ABI): wave start/end clocks of the last LT_TRACE_COUNT launch
+extern "C" int lt_debug_wave_times(lt_scene* s, unsigned long long* out, int n_waves) {
+  if (!s || !out || n_waves < 0 || n_waves > LT_DBG_WAVES) return LT_ERR_INVALID_ARG;
+  LT_HIP(hipSetDevice(s->device));
+  LT_HIP(hipDeviceSynchronize());
+  LT_HIP(hipMemcpy(out, s->counters + 8, (size_t)n_waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return LT_OK;
 }
 
 extern "C" int lt_scene_status(lt_scene* s) {

@@ -12,6 +12,7 @@
 //                boxes of every node come from O(log) segment-tree range queries
 #include "lt_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define WAVE 64
 
@@ -396,7 +397,10 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint32_t* __restrict__ 
   }
   const int g = i + s * d + (d < 0 ? -1 : 0);
   const int first = min(i, j), last = max(i, j);
-  if (last - first + 1 <= LT_LEAF_MAX && i != 0) return;  // swallowed by a leaf of an ancestor
+  if (last - first + 1 <= LT_LEAF_MAX && i != 0) {  // swallowed by a leaf of an ancestor: mark dead
+    nodes[4 * (size_t)i + 3] = make_float4(__int_as_float(0x7fffffff), __int_as_float(0x7fffffff), 0.f, 0.f);
+    return;
+  }
   const int lc = g - first + 1, rc = last - g;
   const int c0 = lc <= LT_LEAF_MAX ? leaf_ref(first, lc) : g;
   const int c1 = rc <= LT_LEAF_MAX ? leaf_ref(g + 1, rc) : g + 1;
@@ -408,6 +412,140 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint32_t* __restrict__ 
   N[1] = make_float4(h0.y, h0.z, l1.x, l1.y);
   N[2] = make_float4(l1.z, h1.x, h1.y, h1.z);
   N[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+}
+
+// ---- 4-wide collapse: node i = children of its internal children (leaves stay) -----------------------------
+// Every live binary node gets a 128-B wide twin with the same index: 4 x { (mn.xyz, mx.x), (mx.yz, ref, -) }.
+// A quad of lanes reads it as one contiguous cache line, one child per lane (lt_trace.hip, k_trace4).
+__global__ __launch_bounds__(256) void k_collapse4(const float4* __restrict__ nodes, int n_nodes,
+                                                   float4* __restrict__ nodes4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes) return;
+  const float4* N = nodes + 4 * (size_t)i;
+  const float4 q3 = N[3];
+  const int c[2] = {__float_as_int(q3.x), __float_as_int(q3.y)};
+  if (c[0] == 0x7fffffff) return;  // dead slot
+  const float4 q0 = N[0], q1 = N[1], q2 = N[2];
+  const float inf = INFINITY;
+  const float4 e_lo = make_float4(inf, inf, inf, inf);                        // mn = mx = +inf: never hit
+  const float4 e_hi = make_float4(inf, inf, __int_as_float(0x7fffffff), 0.f);
+  const bool in0 = c[0] >= 0, in1 = c[1] >= 0;
+  // entries contributed by child 0 (A0, A1) and child 1 (B0, B1); the second one exists only for internal children
+  float4 a0l = make_float4(q0.x, q0.y, q0.z, q0.w), a0h = make_float4(q1.x, q1.y, __int_as_float(c[0]), 0.f);
+  float4 a1l = e_lo, a1h = e_hi;
+  float4 b0l = make_float4(q1.z, q1.w, q2.x, q2.y), b0h = make_float4(q2.z, q2.w, __int_as_float(c[1]), 0.f);
+  float4 b1l = e_lo, b1h = e_hi;
+  if (in0) {
+    const float4* M = nodes + 4 * (size_t)c[0];
+    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+    a0l = make_float4(m0.x, m0.y, m0.z, m0.w); a0h = make_float4(m1.x, m1.y, m3.x, 0.f);
+    a1l = make_float4(m1.z, m1.w, m2.x, m2.y); a1h = make_float4(m2.z, m2.w, m3.y, 0.f);
+  }
+  if (in1) {
+    const float4* M = nodes + 4 * (size_t)c[1];
+    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+    b0l = make_float4(m0.x, m0.y, m0.z, m0.w); b0h = make_float4(m1.x, m1.y, m3.x, 0.f);
+    b1l = make_float4(m1.z, m1.w, m2.x, m2.y); b1h = make_float4(m2.z, m2.w, m3.y, 0.f);
+  }
+  float4* O = nodes4 + 8 * (size_t)i;
+  O[0] = a0l; O[1] = a0h;
+  O[2] = in0 ? a1l : b0l; O[3] = in0 ? a1h : b0h;
+  O[4] = in0 ? b0l : b1l; O[5] = in0 ? b0h : b1h;   // (!in0): B1 is the empty entry unless child 1 is internal
+  O[6] = in0 ? b1l : e_lo; O[7] = in0 ? b1h : e_hi;
+}
+
+// ---- Karras topology straight into 4-wide nodes (default path) -------------------------------------------
+// Node i finds its own key range and split as k_hierarchy does; because the ranges of its two children
+// are then known, their splits need no range search -- one binary search each -- and the up to four
+// grandchild ranges become the entries of the 128-B node.  The sorted keys around the workgroup are
+// staged in LDS: most searches never leave that window, which removes the dependent L2 round trips that
+// dominated the binary kernel.
+#define LT_HWIN 512  // keys staged on each side of the workgroup's 256 nodes
+
+struct key_window {
+  const uint32_t* lds;   // window copy
+  const uint32_t* keys;  // global sorted keys
+  int lo, hi, n;         // window = [lo, hi)
+};
+
+__device__ __forceinline__ uint32_t kw_key(const key_window& kw, int j) {
+  return (j >= kw.lo && j < kw.hi) ? kw.lds[j - kw.lo] : kw.keys[j];
+}
+__device__ __forceinline__ int kw_delta(const key_window& kw, int i, uint32_t ki, int j) {
+  if (j < 0 || j >= kw.n) return -1;
+  const uint32_t kj = kw_key(kw, j);
+  return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
+}
+// split of the key range [a, b] (b > a): largest g in [a, b) with delta(a, g) > delta(a, b) ... Karras 2012
+__device__ __forceinline__ int kw_split(const key_window& kw, int a, int b) {
+  const uint32_t ka = kw_key(kw, a);
+  const int dn = kw_delta(kw, a, ka, b);
+  const int l = b - a;
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (s + t < l && kw_delta(kw, a, ka, a + s + t) > dn) s += t;
+    if (t == 1) break;
+  }
+  return a + s;
+}
+
+__device__ __forceinline__ void put_entry(float4* __restrict__ O, int k, const float4 lo, const float4 hi, int ref) {
+  O[2 * k] = make_float4(lo.x, lo.y, lo.z, hi.x);
+  O[2 * k + 1] = make_float4(hi.y, hi.z, __int_as_float(ref), 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_hierarchy4(const uint32_t* __restrict__ keys, int n, int np,
+                                                    const float4* __restrict__ seg, float4* __restrict__ nodes4) {
+  __shared__ uint32_t wkeys[256 + 2 * LT_HWIN];
+  const int i0 = blockIdx.x * 256;
+  key_window kw;
+  kw.lds = wkeys; kw.keys = keys; kw.n = n;
+  kw.lo = max(i0 - LT_HWIN, 0);
+  kw.hi = min(i0 + 256 + LT_HWIN, n);
+  for (int k = threadIdx.x; k < kw.hi - kw.lo; k += 256) wkeys[k] = keys[kw.lo + k];
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  const float inf = INFINITY;
+  const float4 e_lo = make_float4(inf, inf, inf, 0.f), e_hi = make_float4(inf, inf, inf, 0.f);  // mn = mx = +inf
+  if (n == 1) {
+    if (i == 0) {
+      put_entry(nodes4, 0, seg[2 * (size_t)np], seg[2 * (size_t)np + 1], leaf_ref(0, 1));
+      for (int k = 1; k < 4; ++k) put_entry(nodes4, k, e_lo, e_hi, 0x7fffffff);
+    }
+    return;
+  }
+  if (i >= n - 1) return;
+  const uint32_t ki = wkeys[i - kw.lo];
+  const int d = (kw_delta(kw, i, ki, i + 1) - kw_delta(kw, i, ki, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = kw_delta(kw, i, ki, i - d);
+  int lmax = 2;
+  while (kw_delta(kw, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (kw_delta(kw, i, ki, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int first = min(i, j), last = max(i, j);
+  if (last - first + 1 <= LT_LEAF_MAX && i != 0) return;  // swallowed by a leaf of an ancestor: never referenced
+  const int g = kw_split(kw, first, last);
+  float4* O = nodes4 + 8 * (size_t)i;
+  int ne = 0;
+  float4 lo, hi;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const int a = side == 0 ? first : g + 1, b = side == 0 ? g : last;
+    if (b - a + 1 <= LT_LEAF_MAX) {
+      range_box(seg, np, a, b, lo, hi);
+      put_entry(O, ne++, lo, hi, leaf_ref(a, b - a + 1));
+    } else {
+      const int gc = kw_split(kw, a, b);
+      const int lc = gc - a + 1, rc = b - gc;
+      range_box(seg, np, a, gc, lo, hi);
+      put_entry(O, ne++, lo, hi, lc <= LT_LEAF_MAX ? leaf_ref(a, lc) : gc);
+      range_box(seg, np, gc + 1, b, lo, hi);
+      put_entry(O, ne++, lo, hi, rc <= LT_LEAF_MAX ? leaf_ref(gc + 1, rc) : gc + 1);
+    }
+  }
+  for (; ne < 4; ++ne) put_entry(O, ne, e_lo, e_hi, 0x7fffffff);
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------
@@ -459,8 +597,13 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
       if (np / sub > 1) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, stream, s->seg, np / sub);
     }
     LT_MARK();  // 5
-    hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n, np,
-                       s->seg, s->nodes);
+    if (lt_binary_path()) {  // A/B: binary nodes for k_trace (one ray per lane)
+      hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n, np,
+                         s->seg, s->nodes);
+    } else {
+      hipLaunchKernelGGL(k_hierarchy4, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n,
+                         np, s->seg, s->nodes4);
+    }
     LT_MARK();  // 6
     LT_HIP(hipGetLastError());
   }

@@ -44,6 +44,8 @@ void lt_set_error(const char* fmt, ...);
 #define LT_SEG_SUB 512         // segment-tree leaves reduced per workgroup
 #define LT_STACK_LDS 32        // per-ray stack entries kept in LDS; deeper entries spill to HBM
 #define LT_STACK_MAX 64        // Karras depth bound for 62-bit unique keys
+#define LT_STACK4_LDS 40       // quad traversal (4-wide nodes): stack entries per ray kept in LDS
+#define LT_STACK4_MAX 104      // 40 + 64 spill entries: <= 3 pushes per level, <= 31 levels of a collapsed Karras tree
 
 struct lt_scene {
   int device;
@@ -63,7 +65,8 @@ struct lt_scene {
   uint32_t* hist;       // [256 * n_sort_blocks + 256 digit totals]
   float4* tris;         // [3 * n_faces]
   float4* seg;          // [2 * 2 * np]
-  float4* nodes;        // [4 * max(n_faces - 1, 1)]
+  float4* nodes;        // [4 * max(n_faces - 1, 1)]   binary nodes (64 B)
+  float4* nodes4;       // [8 * max(n_faces - 1, 1)]   4-wide nodes (128 B), same numbering
   float* partial;       // per-workgroup bounds partials [6 * LT_BOUNDS_BLOCKS]
   float* params;        // device: lo.xyz, scale, pad
   unsigned* flags;      // device: [0] error bits
@@ -78,11 +81,13 @@ struct lt_scene {
 };
 
 #define LT_BOUNDS_BLOCKS 256
+#define LT_DBG_WAVES 16384   // wave start/end clocks kept by a LT_TRACE_COUNT launch (debug)
 #define LT_FLAG_BAD_INDEX 1u
 
 int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats);
 int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_rays, int height,
                     float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
                     unsigned flags, hipStream_t stream, lt_stats* stats);
+bool lt_binary_path();  // LIDARHIP_TRACE=binary: one ray per lane over binary nodes (A/B cross-check)
 int lt_scene_reserve(lt_scene* s, int n_faces);
 int lt_scene_reserve_rays(lt_scene* s, int n_rays);

@@ -14,6 +14,8 @@
 // The closest hit is the minimum over (t, face index), independent of traversal order.
 #include "lt_internal.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #define LT_TABLE_ATTR __device__
 #include "lt_rsqrt_sse_table.h"
 
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void k_trace(
     int* __restrict__ overflow, unsigned long long* __restrict__ counters) {
   __shared__ int stack[4][LT_STACK_LDS][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long t_start = COUNT ? (unsigned long long)clock64() : 0ull;
   // XCD-aware tile assignment: workgroup b runs on XCD b % 8; give XCD x the x-th eighth of the
   // (column-major) tile list, i.e. one azimuth sector.  gridDim.x is a multiple of 8.
   const int nb = gridDim.x;
@@ -193,8 +196,236 @@ __global__ __launch_bounds__(256) void k_trace(
       atomicAdd(&counters[1], vt);
       atomicAdd(&counters[2], vh);
       atomicAdd(&counters[3], vo);
+      const int wg = blockIdx.x * 4 + wave;  // debug: wave start / end clock (tools/wave_times.py)
+      if (wg < LT_DBG_WAVES) {
+        counters[8 + 2 * wg] = t_start;
+        counters[8 + 2 * wg + 1] = (unsigned long long)clock64();
+      }
     }
   }
+}
+
+// =====================================================================================================
+// Quad traversal over the 4-wide nodes: FOUR LANES PER RAY.
+//
+// A 64x2048 scan is only 131 072 rays = 2 waves per SIMD with one ray per lane: far too few to hide the
+// ~1 us dependent node fetch of a pointer-chasing traversal on 256 CUs.  Spreading a ray over a quad of
+// lanes gives 8 waves per SIMD (full occupancy), halves the number of dependent steps (4-wide nodes), and
+// turns the leaf loop into one step:
+//   * node step: the quad reads one 128-B node as a single cache line, lane j tests child j; hits are
+//     ranked by entry distance with DPP quad broadcasts; the nearest becomes the next node, the others
+//     are pushed so that the nearer one is popped first;
+//   * leaf step: lane j runs Moller-Trumbore on triangle j of the leaf (<= 4), then a quad min over
+//     (t, face index).
+// The per-ray stack is shared by the quad: LDS [depth][16 rays], spill to HBM beyond LT_STACK4_LDS.
+// Results do not depend on the traversal order (min over (t, face)), so this kernel is bit-identical to
+// k_trace and to the brute-force oracle.
+// =====================================================================================================
+#define LT_Q_BCAST(k) ((k) | ((k) << 2) | ((k) << 4) | ((k) << 6))
+#define LT_Q_XOR1 0xB1  // quad_perm [1,0,3,2]
+#define LT_Q_XOR2 0x4E  // quad_perm [2,3,0,1]
+
+template <int CTRL>
+__device__ __forceinline__ int qperm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float qperm_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+#define LT_TILE4_H 2
+#define LT_TILE4_W 8
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace4(
+    const float4* __restrict__ nodes4, const float4* __restrict__ tris, const float* __restrict__ rays, float ox,
+    float oy, float oz, int H, int W, int n_faces, const int* __restrict__ faces, const int* __restrict__ colors,
+    const float* __restrict__ rem, float* __restrict__ endpoints, int* __restrict__ endcolors,
+    float* __restrict__ range, float* __restrict__ endrem, int* __restrict__ tri_out, unsigned flags,
+    int* __restrict__ overflow, unsigned long long* __restrict__ counters) {
+  __shared__ int stack[4][LT_STACK4_LDS][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 3, q = lane >> 2;
+  const int nb = gridDim.x;
+  const int lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);  // XCD x owns the x-th azimuth sector
+  const int tiles_h = (H + LT_TILE4_H - 1) / LT_TILE4_H, tiles_w = (W + LT_TILE4_W - 1) / LT_TILE4_W;
+  const int wt = lb * 4 + wave;
+  const int tile_x = wt / tiles_h, tile_y = wt - tile_x * tiles_h;
+  const int h = tile_y * LT_TILE4_H + (q >> 3), w = tile_x * LT_TILE4_W + (q & 7);
+  const bool active = tile_x < tiles_w && h < H && w < W;
+  const size_t ray = (size_t)h * W + w;
+
+  float dx = 0.f, dy = 0.f, dz = 1.f;
+  if (active) {
+    const float rx = rays[3 * ray], ry = rays[3 * ray + 1], rz = rays[3 * ray + 2];
+    const float D = (rx * rx + ry * ry) + rz * rz;  // normalize, Vector3.h:73-89
+    const float r0 = (flags & LT_TRACE_NORM_EXACT) ? 1.0f / sqrtf(D) : rsqrt_sse(D);
+    const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
+    dx = rx * r; dy = ry * r; dz = rz * r;
+  }
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+
+  float best_t = 999999999.f;
+  int best_face = 0x7fffffff;
+  int sp = 0;
+  int cur = (active && n_faces > 0) ? 0 : LT_DONE;
+  unsigned n_nodes = 0, n_tris = 0, n_ovf = 0;
+  const float eps = 0.000001f;
+  int* spill = overflow + ray * (LT_STACK4_MAX - LT_STACK4_LDS);
+
+  while (true) {
+    // ---- descend through 4-wide nodes (cur, sp, best_* are uniform within a quad) -----------------------
+    while (cur >= 0) {
+      const float4* N = nodes4 + 8 * (size_t)cur + 2 * j;
+      const float4 a = N[0], b = N[1];
+      if (COUNT && j == 0) ++n_nodes;
+      const float l1x = (a.x - ox) * ix, l2x = (a.w - ox) * ix;
+      const float l1y = (a.y - oy) * iy, l2y = (b.x - oy) * iy;
+      const float l1z = (a.z - oz) * iz, l2z = (b.y - oz) * iz;
+      const float tn = fmaxf(fmaxf(fminf(l1x, l2x), fminf(l1y, l2y)), fmaxf(fminf(l1z, l2z), 0.0f));
+      const float tf = fminf(fminf(fmaxf(l1x, l2x), fmaxf(l1y, l2y)), fminf(fmaxf(l1z, l2z), best_t));
+      const int hit = tn <= tf ? 1 : 0;
+      const int ref = __float_as_int(b.z);
+      // rank of this child among the hit children of the quad (by tn, then lane)
+      const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
+      const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);
+      const int h0 = qperm_i<LT_Q_BCAST(0)>(hit), h1 = qperm_i<LT_Q_BCAST(1)>(hit);
+      const int h2 = qperm_i<LT_Q_BCAST(2)>(hit), h3 = qperm_i<LT_Q_BCAST(3)>(hit);
+      const int nh = h0 + h1 + h2 + h3;
+      const int rank = (h0 & ((t0 < tn) | ((t0 == tn) & (0 < j)))) + (h1 & ((t1 < tn) | ((t1 == tn) & (1 < j)))) +
+                       (h2 & ((t2 < tn) | ((t2 == tn) & (2 < j)))) + (h3 & ((t3 < tn) | ((t3 == tn) & (3 < j))));
+      if (nh == 0) {
+        if (sp > 0) {
+          --sp;
+          cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
+        } else {
+          cur = LT_DONE;
+        }
+      } else {
+        // nearest child -> next node (OR-reduce the single rank-0 reference over the quad)
+        int nxt = (hit && rank == 0) ? ref : 0;
+        nxt |= qperm_i<LT_Q_XOR1>(nxt);
+        nxt |= qperm_i<LT_Q_XOR2>(nxt);
+        if (hit && rank > 0) {  // rank 1 ends on top of the stack
+          const int slot = sp + (nh - 1 - rank);
+          if (slot < LT_STACK4_LDS) {
+            stack[wave][slot][q] = ref;
+          } else {
+            spill[slot - LT_STACK4_LDS] = ref;
+            if (COUNT) ++n_ovf;
+          }
+        }
+        sp += nh - 1;
+        cur = nxt;
+      }
+    }
+    if (cur == LT_DONE) break;
+    // ---- leaf: one triangle per lane (Triangle.h:27-50 operation order) ---------------------------------
+    {
+      const int lref = ~cur;
+      const int start = lref & 0x0fffffff, cnt = (lref >> 28) + 1;
+      float t = INFINITY;
+      int f = 0x7fffffff;
+      if (j < cnt) {
+        const float4* T = tris + 3 * (size_t)(start + j);
+        const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+        if (COUNT) ++n_tris;
+        const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+        const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
+        const float aa = (e1x * hx + e1y * hy) + e1z * hz;
+        if (!(aa < eps && aa > -eps)) {
+          const float inv_a = 1.0f / aa;
+          const float sx = ox - t0.x, sy = oy - t0.y, sz = oz - t0.z;
+          const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
+          if (!(u < 0 || u > 1)) {
+            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+            const float v = ((dx * qx + dy * qy) + dz * qz) * inv_a;
+            if (!(v < 0 || u + v > 1)) {
+              const float tt = ((e2x * qx + e2y * qy) + e2z * qz) * inv_a;
+              if (!(tt < eps) && tt == tt) {  // NaN t is never recorded by the reference either (BVH.cpp:59)
+                t = tt;
+                f = __float_as_int(t2.y);
+              }
+            }
+          }
+        }
+      }
+      // quad min over (t, face)
+      {
+        const float ot = qperm_f<LT_Q_XOR1>(t);
+        const int of = qperm_i<LT_Q_XOR1>(f);
+        if (ot < t || (ot == t && of < f)) { t = ot; f = of; }
+      }
+      {
+        const float ot = qperm_f<LT_Q_XOR2>(t);
+        const int of = qperm_i<LT_Q_XOR2>(f);
+        if (ot < t || (ot == t && of < f)) { t = ot; f = of; }
+      }
+      if (t < best_t || (t == best_t && f < best_face)) {
+        best_t = t;
+        best_face = f;
+      }
+    }
+    if (sp > 0) {
+      --sp;
+      cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
+    } else {
+      cur = LT_DONE;
+    }
+  }
+
+  // ---- write-back by lane 0 of the quad (RayTracer.cpp:73-90) ----------------------------------------------
+  const bool hit = best_face != 0x7fffffff;
+  if (active && j == 0) {
+    if (hit) {
+      const int i0 = faces[3 * (size_t)best_face], i1 = faces[3 * (size_t)best_face + 1],
+                i2 = faces[3 * (size_t)best_face + 2];
+      if (endpoints) {
+        endpoints[3 * ray] = ox + dx * best_t;
+        endpoints[3 * ray + 1] = oy + dy * best_t;
+        endpoints[3 * ray + 2] = oz + dz * best_t;
+      }
+      if (endcolors) {
+        endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
+        endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
+        endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+      }
+      if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
+      if (range) range[ray] = best_t;
+      if (tri_out) tri_out[ray] = best_face;
+    } else if (flags & LT_TRACE_WRITE_MISSES) {
+      if (endpoints) { endpoints[3 * ray] = 0.f; endpoints[3 * ray + 1] = 0.f; endpoints[3 * ray + 2] = 0.f; }
+      if (endcolors) { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+      if (endrem) endrem[ray] = 0.f;
+      if (range) range[ray] = 0.f;
+      if (tri_out) tri_out[ray] = -1;
+    }
+  }
+  if (COUNT) {
+    unsigned long long vn = n_nodes, vt = n_tris, vh = (active && hit && j == 0) ? 1u : 0u, vo = n_ovf;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vn += __shfl_xor(vn, o, 64);
+      vt += __shfl_xor(vt, o, 64);
+      vh += __shfl_xor(vh, o, 64);
+      vo += __shfl_xor(vo, o, 64);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters[0], vn);
+      atomicAdd(&counters[1], vt);
+      atomicAdd(&counters[2], vh);
+      atomicAdd(&counters[3], vo);
+    }
+  }
+}
+
+bool lt_binary_path() {
+  static const bool v = []() {
+    const char* e = getenv("LIDARHIP_TRACE");
+    return e && strcmp(e, "binary") == 0;
+  }();
+  return v;
 }
 
 int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_rays, int height, float* endpoints,
@@ -217,18 +448,33 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
   if (W > 0) {
     LT_CHECK(lt_scene_reserve_rays(s, W * H));
     if (count) LT_HIP(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
-    const int tiles = ((H + LT_TILE_H - 1) / LT_TILE_H) * ((W + LT_TILE_W - 1) / LT_TILE_W);
-    int nblocks = (tiles + 3) / 4;
-    nblocks = (nblocks + 7) & ~7;
+    const bool binary_path = lt_binary_path();
     if (timed) LT_HIP(hipEventRecord(s->ev[7], stream));
-    if (count)
-      hipLaunchKernelGGL(k_trace<true>, dim3(nblocks), dim3(256), 0, stream, s->nodes, s->tris, rays, origin[0],
-                         origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints, endcolors,
-                         range, endrem, tri, flags, s->overflow, s->counters);
-    else
-      hipLaunchKernelGGL(k_trace<false>, dim3(nblocks), dim3(256), 0, stream, s->nodes, s->tris, rays, origin[0],
-                         origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints, endcolors,
-                         range, endrem, tri, flags, s->overflow, s->counters);
+    if (binary_path) {
+      const int tiles = ((H + LT_TILE_H - 1) / LT_TILE_H) * ((W + LT_TILE_W - 1) / LT_TILE_W);
+      int nblocks = (tiles + 3) / 4;
+      nblocks = (nblocks + 7) & ~7;
+      if (count)
+        hipLaunchKernelGGL(k_trace<true>, dim3(nblocks), dim3(256), 0, stream, s->nodes, s->tris, rays, origin[0],
+                           origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints,
+                           endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+      else
+        hipLaunchKernelGGL(k_trace<false>, dim3(nblocks), dim3(256), 0, stream, s->nodes, s->tris, rays, origin[0],
+                           origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints,
+                           endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+    } else {
+      const int tiles = ((H + LT_TILE4_H - 1) / LT_TILE4_H) * ((W + LT_TILE4_W - 1) / LT_TILE4_W);
+      int nblocks = (tiles + 3) / 4;
+      nblocks = (nblocks + 7) & ~7;
+      if (count)
+        hipLaunchKernelGGL(k_trace4<true>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays, origin[0],
+                           origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints,
+                           endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+      else
+        hipLaunchKernelGGL(k_trace4<false>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays,
+                           origin[0], origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem,
+                           endpoints, endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+    }
     if (timed) LT_HIP(hipEventRecord(s->ev[8], stream));
     LT_HIP(hipGetLastError());
   }

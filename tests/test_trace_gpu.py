@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): hit triangle / label bit-exact, range within 1e-
 HIP kernels reproduce the reference's float32 operation order (no FMA), we hold them to MORE than
 that against our oracle: every output bit-identical to the brute-force closest hit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -144,9 +146,14 @@ def test_scene_api_device_resident(oracle):
                               norm=oracle.NORM_SSE_TABLE)
     for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
         _assert_bits(out[k].cpu().numpy(), ref[k], k)
-    # identical tree -> identical work counters as the CPU model of the structure
-    assert out["stats"]["nodes_visited"] == ref["stats"]["nodes_popped"]
-    assert out["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
+    if os.environ.get("LIDARHIP_TRACE") == "binary":
+        # identical tree -> identical work counters as the CPU model of the binary structure
+        assert out["stats"]["nodes_visited"] == ref["stats"]["nodes_popped"]
+        assert out["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
+    else:  # 4-wide nodes: fewer, fatter node visits than the binary model
+        assert 0 < out["stats"]["nodes_visited"] < ref["stats"]["nodes_popped"]
+        assert out["stats"]["tris_tested"] > 0
+    assert out["stats"]["stack_overflows"] == 0 and out["stats"]["n_hits"] == int((ref["tri"] >= 0).sum())
     # rebuild with another mesh in the same workspace, then trace twice (determinism)
     v2, f2, c2, r2 = synth_scene(9, 20000)
     t2 = [torch.from_numpy(x).to(dev) for x in (v2, f2, c2, r2)]
