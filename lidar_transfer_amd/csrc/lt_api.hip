@@ -55,7 +55,7 @@ int lt_scene_reserve(lt_scene* s, int n_faces) {
     LT_CHECK(dev_alloc(&s->keys[k], cap));
     LT_CHECK(dev_alloc(&s->vals[k], cap));
   }
-  LT_CHECK(dev_alloc(&s->hist, 256 * nb + 256));
+  LT_CHECK(dev_alloc(&s->hist, 1024 * nb + 1024));  // LT_RD digits x tiles + digit totals
   LT_CHECK(dev_alloc(&s->tris, 3 * cap));
   LT_CHECK(dev_alloc(&s->seg, 4 * np));
   LT_CHECK(dev_alloc(&s->nodes, 4 * cap));

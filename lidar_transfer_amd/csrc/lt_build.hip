@@ -5,7 +5,7 @@
 // and needs no agent-scope fences):
 //   k_bounds     vertex AABB partials per workgroup                      (HBM stream of verts)
 //   k_morton     reduce partials, centroid -> 30-bit Morton key, val = face id
-//   4 x { k_hist, k_scan, k_scatter }   stable LSD radix sort, 8-bit digits, LDS ranking
+//   3 x { k_hist, k_scan, k_scatter }   stable LSD radix sort, 10-bit digits, LDS ranking
 //   k_gather     sorted triangle records (v0,e1,e2,face) + padded leaf boxes
 //   k_seg_sub / k_seg_top   min/max segment tree over the leaf boxes (coalesced AABB reduction)
 //   k_hierarchy  Karras radix-tree topology by binary search on the sorted keys; both child
@@ -127,26 +127,36 @@ __global__ __launch_bounds__(256) void k_morton(const float* __restrict__ verts,
   vals[i] = (uint32_t)i;
 }
 
-// ---- LSD radix sort, 8-bit digits -----------------------------------------------------------------
-// One workgroup owns LT_SORT_TILE consecutive keys per pass.  hist is digit-major: hist[d * nb + b].
+// ---- LSD radix sort: 3 passes of 10-bit digits over the 30-bit Morton key --------------------------------
+// One workgroup owns LT_SORT_TILE consecutive keys per pass.  hist is digit-major: hist[d * nb + b],
+// followed by the LT_RD digit totals.
+#define LT_RB 10
+#define LT_RD (1 << LT_RB)
+#define LT_DPT (LT_RD / LT_SORT_THREADS)  // digits owned per thread (4)
+
 __global__ __launch_bounds__(LT_SORT_THREADS) void k_hist(const uint32_t* __restrict__ keys, int n, int shift,
                                                          uint32_t* __restrict__ hist, int nb) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  __shared__ uint32_t h[LT_RD];
+#pragma unroll
+  for (int k = 0; k < LT_DPT; ++k) h[k * LT_SORT_THREADS + threadIdx.x] = 0;
   __syncthreads();
   const int base = blockIdx.x * LT_SORT_TILE;
 #pragma unroll
   for (int k = 0; k < LT_SORT_TILE / LT_SORT_THREADS; ++k) {
     const int e = base + k * LT_SORT_THREADS + threadIdx.x;
-    if (e < n) atomicAdd(&h[(keys[e] >> shift) & 255u], 1u);
+    if (e < n) atomicAdd(&h[(keys[e] >> shift) & (LT_RD - 1u)], 1u);
   }
   __syncthreads();
-  hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < LT_DPT; ++k) {
+    const int d = k * LT_SORT_THREADS + threadIdx.x;
+    hist[(size_t)d * nb + blockIdx.x] = h[d];
+  }
 }
 
 // Row scan: workgroup d turns hist[d*nb .. d*nb+nb) (the counts of digit d per tile) into its
-// exclusive prefix sum and stores the digit total in hist[256*nb + d].  The cross-digit prefix
-// (256 values) is redone by every k_scatter workgroup in LDS -- cheaper than another launch.
+// exclusive prefix sum and stores the digit total in hist[LT_RD*nb + d].  The cross-digit prefix
+// (LT_RD values) is redone by every k_scatter workgroup in LDS -- cheaper than another launch.
 __global__ __launch_bounds__(256) void k_scan(uint32_t* __restrict__ hist, int nb) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
@@ -171,11 +181,11 @@ __global__ __launch_bounds__(256) void k_scan(uint32_t* __restrict__ hist, int n
     __syncthreads();
     carry = carry_s;
   }
-  if (threadIdx.x == 0) hist[256 * (size_t)nb + blockIdx.x] = carry;
+  if (threadIdx.x == 0) hist[(size_t)LT_RD * nb + blockIdx.x] = carry;
 }
 
 // Stable scatter.  Wave w of the workgroup ranks the contiguous quarter [w*1024, (w+1)*1024) of the
-// tile in 16 rounds of 64 keys: lanes holding the same digit find each other with 8 ballots, the
+// tile in 16 rounds of 64 keys: lanes holding the same digit find each other with LT_RB ballots, the
 // running per-(wave, digit) count lives in LDS.  Order inside a tile is (wave, round, lane) = memory
 // order, so the sort is stable.
 __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
@@ -185,11 +195,13 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
                                                             const uint32_t* __restrict__ hist, int nb) {
   constexpr int ROUNDS = LT_SORT_TILE / LT_SORT_THREADS;  // 16
   constexpr int NW = LT_SORT_THREADS / 64;                 // 4
-  __shared__ uint32_t cnt[NW][256];
+  __shared__ uint32_t cnt[NW][LT_RD];
   __shared__ uint32_t wtot[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) cnt[w][threadIdx.x] = 0;
+  for (int w = 0; w < NW; ++w)
+#pragma unroll
+    for (int k = 0; k < LT_DPT; ++k) cnt[w][k * LT_SORT_THREADS + threadIdx.x] = 0;
   __syncthreads();
   volatile uint32_t* mycnt = cnt[wave];
   const int base = blockIdx.x * LT_SORT_TILE + wave * (ROUNDS * 64);
@@ -206,10 +218,10 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
   for (int r = 0; r < ROUNDS; ++r) {
     const int e = base + r * 64 + lane;
     const bool valid = e < n;
-    const uint32_t digit = (key[r] >> shift) & 255u;
+    const uint32_t digit = (key[r] >> shift) & (LT_RD - 1u);
     unsigned long long m = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < LT_RB; ++bit) {
       const bool b = (digit >> bit) & 1u;
       const unsigned long long bal = __ballot(b);
       m &= b ? bal : ~bal;
@@ -223,10 +235,15 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
     }
   }
   __syncthreads();
-  {  // thread d owns digit d: digit base (exclusive scan of the 256 totals) + tile base + prefix over the waves
-    const int d = threadIdx.x;
-    const uint32_t tot = hist[256 * (size_t)nb + d];
-    uint32_t inc = tot;
+  {  // thread t owns digits 4t .. 4t+3: digit base (exclusive scan of the totals) + tile base + prefix over waves
+    const int d0 = threadIdx.x * LT_DPT;
+    uint32_t tot[LT_DPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < LT_DPT; ++k) {
+      tot[k] = hist[(size_t)LT_RD * nb + d0 + k];
+      sum += tot[k];
+    }
+    uint32_t inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(inc, o, WAVE);
@@ -234,14 +251,18 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
     }
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    uint32_t dbase = inc - tot;
+    uint32_t dbase = inc - sum;
     for (int w = 0; w < wave; ++w) dbase += wtot[w];
-    uint32_t run = dbase + hist[d * nb + blockIdx.x];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t c = cnt[w][d];
-      cnt[w][d] = run;
-      run += c;
+    for (int k = 0; k < LT_DPT; ++k) {
+      uint32_t run = dbase + hist[(size_t)(d0 + k) * nb + blockIdx.x];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = cnt[w][d0 + k];
+        cnt[w][d0 + k] = run;
+        run += c;
+      }
+      dbase += tot[k];
     }
   }
   __syncthreads();
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(LT_SORT_THREADS) void k_scatter(const uint32_t* __r
   for (int r = 0; r < ROUNDS; ++r) {
     const int e = base + r * 64 + lane;
     if (e < n) {
-      const uint32_t pos = cnt[wave][(key[r] >> shift) & 255u] + rank[r];
+      const uint32_t pos = cnt[wave][(key[r] >> shift) & (LT_RD - 1u)] + rank[r];
       keys_out[pos] = key[r];
       vals_out[pos] = val[r];
     }
@@ -578,15 +599,15 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
     LT_MARK();  // 2
     const int nb = cdiv(n, LT_SORT_TILE);
     int cur = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 8 * pass;
+    for (int pass = 0; pass < 30 / LT_RB; ++pass) {
+      const int shift = LT_RB * pass;
       hipLaunchKernelGGL(k_hist, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], n, shift, s->hist, nb);
-      hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, stream, s->hist, nb);
+      hipLaunchKernelGGL(k_scan, dim3(LT_RD), dim3(256), 0, stream, s->hist, nb);
       hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], s->vals[cur],
                          s->keys[cur ^ 1], s->vals[cur ^ 1], n, shift, s->hist, nb);
       cur ^= 1;
     }
-    // 4 passes: sorted data is back in buffer 0
+    // sorted data is in buffer `cur`
     LT_MARK();  // 3
     hipLaunchKernelGGL(k_gather, dim3(cdiv(np, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n, np,
                        s->vals[cur], s->params, s->tris, s->seg);
