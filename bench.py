@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- virtual-LiDAR synthesis throughput on MI355X (one process per GPU).
 
-A *step* is one pass of the hot path over one scan: LBVH build over that scan's triangle mesh
-(the mesh changes every scan, exactly as in the reference where `BVH bvh(&objects)` is rebuilt
-per call, RayTracer.cpp:54) + one ray per (beam, azimuth) cell + hit write-back, with mesh, rays
-and images resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle
-scene, 64x2048 HDL-64E target, fov +3/-25), synthetic.
+A *step* is one pass of the hot path over one scan: a NEW triangle mesh (the mesh changes every scan;
+the reference rebuilds its BVH per call, RayTracer.cpp:54) -> closest hit of one ray per (beam, azimuth)
+cell -> range / colour(label) / remission / end point / triangle images, with mesh, rays and images
+resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle scene, 64x2048
+HDL-64E target, fov +3/-25), synthetic.
+
+Two MI355X-native strategies produce bit-identical images (tests/test_trace_gpu.py):
+  scatter (default)  single-origin triangle scatter: stream the mesh once, atomic z-min per ray
+                     (lt_scatter.hip); the ray set of the sensor model is binned once, before the clock,
+                     like the rays are uploaded once
+  lbvh               Morton/radix-sort/Karras LBVH build + quad traversal per scan (lt_build/lt_trace.hip)
+`value` is measured on --strategy (default scatter); the other one is reported beside it.
 
     python bench.py [--gpus N --steps K --warmup W]            # N=1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Scans shard over ranks (weak scaling: every rank renders K scans) with no data-path collective;
-the rendered range/label images are gathered ONCE over RCCL at the end of the timed region.
-Rank 0 prints one JSON line (contract in the task statement), with `roofline` for the dominant
-kernel and `cpu_baseline` = the real reference raytracer (oracle/_ref, prebuilt from
+Scans shard over ranks (weak scaling: every rank renders K scans), no data-path collective; the rendered
+range and colour/label images are gathered ONCE over RCCL at the end of the timed region.  Rank 0 prints
+one JSON line with `roofline` for the dominant kernel (HIP events around every launch of it inside the
+timed region) and `cpu_baseline` = the real reference raytracer (oracle/_ref, prebuilt from
 /root/reference) timed on this box's host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
@@ -32,21 +39,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
-# algorithmic bytes per unit (DESIGN.md "Roofline"): one 4-wide BVH node = 128 B, one triangle record = 48 B,
-# per ray 12 B direction in + 44 B out (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
-B_NODE, B_TRI, B_RAY = 128, 48, 12 + 44 + 40
+# ---- algorithmic bytes per unit ----------------------------------------------------
+# scatter, kernel k_sc_tris: per triangle 3 indices (12 B) + 3 vertices (36 B); per Moller-Trumbore test one
+# normalised direction (16 B) + the bin bookkeeping (8 B); per accepted hit one 8-B atomic
+SC_B_TRI, SC_B_TEST, SC_B_HIT = 48, 24, 8
+# lbvh, kernel k_trace4: one 4-wide node 128 B, one triangle record 48 B; per ray 12 B direction in + 44 B out
+# (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
+LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "4")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the short run of the other strategy")
     ap.add_argument("--cpu-reps", type=int, default=0, help="reference runs for the CPU baseline (0 = auto)")
     return ap.parse_args()
 
@@ -104,7 +117,7 @@ def main():
     import torch
     import torch.distributed as dist
     from lidar_transfer_amd.laserscan import create_rays
-    from lidar_transfer_amd.raytracer import Scene
+    from lidar_transfer_amd.raytracer import RaySet, Scene
     from lidar_transfer_amd.synth import WORKLOADS, synth_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,103 +145,133 @@ def main():
     origin = (0.0, 0.0, 0.0)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     workers = [Scene(local_rank) for _ in range(S)]
-    # every timed scan keeps its images (what a real job would gather / write)
-    range_all = torch.zeros((K, R), dtype=torch.float32, device=dev)
-    label_all = torch.zeros((K, R, 3), dtype=torch.int32, device=dev)
+    raysets = [RaySet(rays, H) for _ in range(S)]  # one per in-flight scan (each owns its z-min image)
     scratch = [workers[0].alloc_outputs(R) for _ in range(S)]
 
-    def step(i, slot=None, timed_events=None):
-        s = i % S
-        sc = workers[s]
-        out = dict(scratch[s])
-        if slot is not None:
-            out["range"] = range_all[slot]
-            out["endcolors"] = label_all[slot]
-        with torch.cuda.stream(streams[s]):
-            sc.set_mesh(*scenes[i % len(scenes)])
-            sc.build(stream=streams[s])
-            if timed_events is not None:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(streams[s])
-            sc.trace(rays, origin, H, out=out, stream=streams[s], write_misses=True)
-            if timed_events is not None:
-                e1.record(streams[s])
-                timed_events.append((e0, e1))
+    def run(strategy, K, Wm, keep):
+        """Timed region for one strategy; returns (seconds, mean dominant-kernel ms, images)."""
+        range_all = torch.zeros((K, R), dtype=torch.float32, device=dev) if keep else None
+        label_all = torch.zeros((K, R, 3), dtype=torch.int32, device=dev) if keep else None
+        # HIP events around every launch of the dominant kernel in the timed region (created and
+        # materialised before the clock starts; recorded by the library on the launch stream)
+        probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for e0, e1 in probes:
+            e0.record()
+            e1.record()
 
-    # one counting pass per scene (outside the clock): nodes / triangles per ray for the roofline
-    counts = []
+        def step(i, slot=None, timed=False):
+            s = i % S
+            sc = workers[s]
+            out = dict(scratch[s])
+            if slot is not None and keep:
+                out["range"] = range_all[slot]
+                out["endcolors"] = label_all[slot]
+            with torch.cuda.stream(streams[s]):
+                sc.set_mesh(*scenes[i % len(scenes)])
+                if timed:
+                    sc.set_probe(*probes[slot])
+                if strategy == "lbvh":
+                    sc.build(stream=streams[s])
+                    sc.trace(rays, origin, H, out=out, stream=streams[s], write_misses=True)
+                else:
+                    sc.render(raysets[s], origin, out=out, stream=streams[s], write_misses=True)
+
+        for i in range(Wm):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i, slot=i, timed=True)
+        for st in streams:
+            st.synchronize()
+        if world > 1 and keep:  # the single RCCL gather of the rendered images (range + colour/label)
+            gathered_r = torch.empty((world, K, R), dtype=torch.float32, device=dev)
+            gathered_l = torch.empty((world, K, R, 3), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered_r, range_all)
+            dist.all_gather_into_tensor(gathered_l, label_all)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probes])) if probes else float("nan")
+        hits = int((range_all[K - 1] > 0).sum().item()) if keep else -1
+        return dt, kern_ms, hits
+
+    # ---- counting passes (outside the clock): work per scan for the roofline ------------------------------
+    cnt = {"scatter": [], "lbvh": []}
     for i in range(len(scenes)):
         workers[0].set_mesh(*scenes[i])
-        workers[0].build()
-        o = workers[0].trace(rays, origin, H, out=scratch[0], count=True)
-        counts.append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
-    phase = workers[0].build(stats=True)
+        o = workers[0].render(raysets[0], origin, out=scratch[0], count=True)
+        cnt["scatter"].append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
+        if args.strategy == "lbvh" or not args.no_other:
+            workers[0].build()
+            o = workers[0].trace(rays, origin, H, out=scratch[0], count=True)
+            cnt["lbvh"].append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
+    phase = workers[0].build(stats=True) if (args.strategy == "lbvh" or not args.no_other) else {}
     torch.cuda.synchronize()
 
-    for i in range(Wm):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    events = []
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(i, slot=i, timed_events=events)
-    for st in streams:
-        st.synchronize()
-    gathered = None
-    if world > 1:  # the single RCCL gather of the rendered images (range + vertex-0 colour/label)
-        gathered_r = torch.empty((world, K, R), dtype=torch.float32, device=dev) if True else None
-        gathered_l = torch.empty((world, K, R, 3), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gathered_r, range_all)
-        dist.all_gather_into_tensor(gathered_l, label_all)
-        gathered = (gathered_r, gathered_l)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def roofline(strategy, kern_ms):
+        c = np.mean(np.array(cnt[strategy], dtype=np.float64), axis=0)
+        if strategy == "scatter":
+            alg = n_faces * SC_B_TRI + c[1] * SC_B_TEST + c[2] * SC_B_HIT
+            extra = {"kernel": "k_sc_tris", "mt_tests_per_ray": round(c[1] / R, 2),
+                     "candidate_bins_per_triangle": round(c[0] / n_faces, 3)}
+        else:
+            alg = c[0] * LB_B_NODE + c[1] * LB_B_TRI + R * LB_B_RAY
+            extra = {"kernel": "k_trace4", "nodes_per_ray": round(c[0] / R, 2), "tris_per_ray": round(c[1] / R, 2)}
+        ach = alg / (kern_ms * 1e-3) / 1e9
+        d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_kernel_ms": round(kern_ms, 5),
+             "algorithmic_bytes_per_launch": int(alg)}
+        d.update(extra)
+        return d
 
-    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
-    hits = int((range_all[K - 1] > 0).sum().item())
+    dt, kern_ms, hits = run(args.strategy, K, Wm, keep=True)
+    other = None
+    if not args.no_other:
+        oname = "lbvh" if args.strategy == "scatter" else "scatter"
+        Ko = max(20, K // 4)
+        odt, okern, _ = run(oname, Ko, max(4, Wm // 4), keep=False)
+        other = {"strategy": oname, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
+                 "ms_per_step": round(odt / Ko * 1e3, 4), "steps": Ko, "roofline": roofline(oname, okern)}
 
     if rank == 0:
-        n_nodes = float(np.mean([c[0] for c in counts]))
-        n_tris = float(np.mean([c[1] for c in counts]))
-        alg_bytes = n_nodes * B_NODE + n_tris * B_TRI + R * B_RAY
-        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9
         value = world * K * R / dt / 1e6
         out = {
-            "metric": "Mrays/sec, LBVH build + ray cast per scan (mesh changes every scan)",
+            "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {H}x{W} rays vs {n_faces}-triangle synthetic scene "
-                                   f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan per step, "
+                                   f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan (new mesh) per step, "
                                    f"{len(scenes)} distinct scenes cycled",
+                       "strategy": args.strategy,
                        "parallelism": f"scan-parallel x{world}" + (", one all_gather of images" if world > 1 else ""),
                        "streams_per_gpu": S},
             "scans_per_s": round(world * K / dt, 2),
-            "trace_only_Mrays_s": round(R / (trace_ms * 1e-3) / 1e6, 2),
-            "phase_ms": {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"},
             "hit_fraction": round(hits / R, 4),
-            "roofline": {"kernel": "k_trace4", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "avg_kernel_ms": round(trace_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "nodes_per_ray": round(n_nodes / R, 2), "tris_per_ray": round(n_tris / R, 2)},
+            "roofline": roofline(args.strategy, kern_ms),
         }
+        if phase:
+            out["lbvh_phase_ms"] = {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"}
+        if other:
+            out["other_strategy"] = other
         if not args.no_cpu_baseline:
             cb = cpu_baseline(wl, 0, args.cpu_reps or 12)
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_baseline"] = round(value / world / cb["value"], 1)
         print(json.dumps(out), flush=True)
+    for rs in raysets:
+        rs.close()
     for wk in workers:
         wk.close()
     if world > 1:

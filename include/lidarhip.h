@@ -116,6 +116,34 @@ int lt_scene_trace_dev(lt_scene* scene, const float* rays, const float* origin, 
                        float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
                        unsigned flags, void* stream, lt_stats* stats);
 
+/* ---- single-origin fast path: ray set + triangle scatter ------------------------------------------ */
+
+typedef struct lt_rayset lt_rayset; /* opaque: normalised directions of one ray batch, binned by direction */
+
+/* Prepare a ray batch (DEVICE pointer rays[n_rays,3] f32) for lt_scene_render_dev: normalise the
+ * directions exactly as the trace kernel does (Vector3.h:73-89; flags & LT_TRACE_NORM_EXACT selects
+ * the seed) and bin them by azimuth x elevation.  A sensor model's rays do not change from scan to
+ * scan (create_rays, laserscan.py:1092-1119, depends only on the YAML), so one rayset serves a whole
+ * sequence.  `rays` is not referenced after the call has completed on `stream`. */
+int lt_rayset_create_dev(lt_rayset** rayset, const float* rays, int n_rays, int height, unsigned flags,
+                         void* stream);
+int lt_rayset_destroy(lt_rayset* rayset);
+
+/* Closest hit of every ray of `rayset`, all cast from `origin` (HOST pointer to 3 floats), against the
+ * scene's CURRENT mesh -- no BVH needed: the triangles are streamed once, each visits only the ray
+ * bins inside its angular bounds and merges hits by atomic min over (t, face).  Same outputs, flags and
+ * bit-identical results as lt_scene_build + lt_scene_trace_dev; replaces BVH::build + the ray loop
+ * (BVH.cpp:143-243, RayTracer.cpp:62-92) for the reference's only call pattern, one origin per call
+ * (RayTracer.cpp:58).  One render per rayset may be in flight at a time. */
+int lt_scene_render_dev(lt_scene* scene, lt_rayset* rayset, const float* origin, float* endpoints,
+                        int* endcolors, float* range, float* endrem, int* tri, unsigned flags, void* stream,
+                        lt_stats* stats);
+
+/* Measurement hook: record the caller's two hipEvent_t (passed as void*) on the launch stream immediately
+ * before and after the dominant kernel (k_sc_tris / k_trace4) of the NEXT lt_scene_render_dev /
+ * lt_scene_trace_dev call; one shot, no synchronisation.  bench.py uses it for the roofline figure. */
+int lt_scene_set_probe(lt_scene* scene, void* ev_start, void* ev_stop);
+
 /* Synchronise the scene's last stream and report deferred device-side errors (LT_ERR_BAD_INDEX). */
 int lt_scene_status(lt_scene* scene);
 

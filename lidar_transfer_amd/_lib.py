@@ -21,7 +21,8 @@ LT_PROJ_NEW = 2
 #: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
            "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy", "lt_last_error",
-           "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection"]
+           "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection", "lt_rayset_create_dev",
+           "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_set_probe"]
 
 
 class Stats(C.Structure):
@@ -83,6 +84,14 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.lt_last_error.restype = C.c_char_p
     lib.lt_version.restype = C.c_char_p
+    lib.lt_rayset_create_dev.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_uint, vp]
+    lib.lt_rayset_create_dev.restype = C.c_int
+    lib.lt_rayset_destroy.argtypes = [vp]
+    lib.lt_rayset_destroy.restype = C.c_int
+    lib.lt_scene_render_dev.argtypes = [vp, vp, fp, vp, vp, vp, vp, vp, C.c_uint, vp, sp]
+    lib.lt_scene_render_dev.restype = C.c_int
+    lib.lt_scene_set_probe.argtypes = [vp, vp, vp]
+    lib.lt_scene_set_probe.restype = C.c_int
     lib.lt_create_rays_dev.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     lib.lt_create_rays_dev.restype = C.c_int
     proj = [vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.c_int, C.c_uint, vp, C.c_int,

@@ -226,6 +226,16 @@ extern "C" int lt_debug_wave_times(lt_scene* s, unsigned long long* out, int n_w
   return LT_OK;
 }
 
+extern "C" int lt_scene_set_probe(lt_scene* s, void* ev_start, void* ev_stop) {
+  if (!s) {
+    lt_set_error("lt_scene_set_probe: NULL scene");
+    return LT_ERR_INVALID_ARG;
+  }
+  s->probe[0] = (hipEvent_t)ev_start;
+  s->probe[1] = (hipEvent_t)ev_stop;
+  return LT_OK;
+}
+
 extern "C" int lt_scene_status(lt_scene* s) {
   if (!s) {
     lt_set_error("lt_scene_status: NULL scene");
@@ -316,11 +326,24 @@ extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float*
   // default is the replayed RSQRTSS seed of the reference's normalize() (Vector3.h:83).
   const char* nm = getenv("LIDARHIP_NORMALIZE");
   const unsigned norm_flag = (nm && strcmp(nm, "exact") == 0) ? LT_TRACE_NORM_EXACT : 0u;
-  LT_CHECK(lt_build_launch(s, stream, stats ? &st : nullptr));
-  LT_CHECK(lt_trace_launch(s, d_rays, origin, (int)R, height, endpoints ? d_end : nullptr,
-                           endcolors ? d_col : nullptr, range ? d_range : nullptr, endrem ? d_rem : nullptr,
-                           tri ? d_tri : nullptr, (stats ? LT_TRACE_COUNT : 0u) | norm_flag, stream,
-                           stats ? &st : nullptr));
+  // LIDARHIP_STRATEGY=lbvh: build the linear BVH and traverse it; default: single-origin triangle
+  // scatter (lt_scatter.hip) -- both produce identical images.
+  const char* sg = getenv("LIDARHIP_STRATEGY");
+  if (sg && strcmp(sg, "lbvh") == 0) {
+    LT_CHECK(lt_build_launch(s, stream, stats ? &st : nullptr));
+    LT_CHECK(lt_trace_launch(s, d_rays, origin, (int)R, height, endpoints ? d_end : nullptr,
+                             endcolors ? d_col : nullptr, range ? d_range : nullptr, endrem ? d_rem : nullptr,
+                             tri ? d_tri : nullptr, (stats ? LT_TRACE_COUNT : 0u) | norm_flag, stream,
+                             stats ? &st : nullptr));
+  } else {
+    lt_rayset* rs = nullptr;
+    LT_CHECK(lt_rayset_create_dev(&rs, d_rays, (int)R, height, norm_flag, stream));
+    const int rc = lt_scene_render_dev(s, rs, origin, endpoints ? d_end : nullptr, endcolors ? d_col : nullptr,
+                                       range ? d_range : nullptr, endrem ? d_rem : nullptr, tri ? d_tri : nullptr,
+                                       (stats ? LT_TRACE_COUNT : 0u), stream, stats ? &st : nullptr);
+    (void)lt_rayset_destroy(rs);  // synchronises
+    LT_CHECK(rc);
+  }
   if (R > 0) {
     if (endpoints) LT_HIP(hipMemcpyAsync(endpoints, d_end, R * 12, hipMemcpyDeviceToHost, stream));
     if (endcolors) LT_HIP(hipMemcpyAsync(endcolors, d_col, R * 12, hipMemcpyDeviceToHost, stream));

@@ -572,6 +572,23 @@ __global__ __launch_bounds__(256) void k_hierarchy4(const uint32_t* __restrict__
 // ---- host orchestration -----------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Stable LSD radix sort of n (key, value) pairs on the low `key_bits` bits; keys[0]/vals[0] hold the input,
+// *out_buffer tells which of the two ping-pong buffers holds the result.  hist: LT_RD * tiles + LT_RD words.
+void lt_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, int n, int key_bits, hipStream_t stream,
+                   int* out_buffer) {
+  const int nb = cdiv(n, LT_SORT_TILE);
+  int cur = 0;
+  for (int pass = 0; pass * LT_RB < key_bits; ++pass) {
+    const int shift = LT_RB * pass;
+    hipLaunchKernelGGL(k_hist, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, keys[cur], n, shift, hist, nb);
+    hipLaunchKernelGGL(k_scan, dim3(LT_RD), dim3(256), 0, stream, hist, nb);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, keys[cur], vals[cur], keys[cur ^ 1],
+                       vals[cur ^ 1], n, shift, hist, nb);
+    cur ^= 1;
+  }
+  *out_buffer = cur;
+}
+
 int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
   const int n = s->n_faces;
   s->built = 0;
@@ -597,16 +614,8 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
     hipLaunchKernelGGL(k_morton, dim3(cdiv(n, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n,
                        s->partial, s->params, s->keys[0], s->vals[0], s->flags);
     LT_MARK();  // 2
-    const int nb = cdiv(n, LT_SORT_TILE);
     int cur = 0;
-    for (int pass = 0; pass < 30 / LT_RB; ++pass) {
-      const int shift = LT_RB * pass;
-      hipLaunchKernelGGL(k_hist, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], n, shift, s->hist, nb);
-      hipLaunchKernelGGL(k_scan, dim3(LT_RD), dim3(256), 0, stream, s->hist, nb);
-      hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(LT_SORT_THREADS), 0, stream, s->keys[cur], s->vals[cur],
-                         s->keys[cur ^ 1], s->vals[cur ^ 1], n, shift, s->hist, nb);
-      cur ^= 1;
-    }
+    lt_sort_pairs(s->keys, s->vals, s->hist, n, 30, stream, &cur);
     // sorted data is in buffer `cur`
     LT_MARK();  // 3
     hipLaunchKernelGGL(k_gather, dim3(cdiv(np, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n, np,

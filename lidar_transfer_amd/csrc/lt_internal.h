@@ -75,6 +75,7 @@ struct lt_scene {
   int cap_rays;
   int built;
   hipStream_t last_stream;
+  hipEvent_t probe[2];   // caller's events to record around the dominant kernel of the next cast (one shot)
   hipEvent_t ev[10];
   int have_events;
   lt_stats stats;

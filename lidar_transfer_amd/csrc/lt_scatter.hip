@@ -1,0 +1,621 @@
+// lt_scatter.hip -- single-origin fast path: stream the TRIANGLES, scatter hits into the range image.
+//
+// Every call of the reference's `ctrace` casts all rays from ONE origin (RayTracer.cpp:58, :68).  For
+// that case the closest hit per ray can be computed without any hierarchy over the mesh: bin the rays
+// once by direction (azimuth x elevation), then stream the triangles -- each triangle computes a
+// conservative angular bounding rectangle as seen from the origin, visits the ray bins it overlaps, runs
+// the reference's Moller-Trumbore test (Triangle.h:27-50, identical float operations to lt_trace.hip)
+// against those rays only, and merges accepted hits with a 64-bit atomicMin on (t bits << 32 | face).
+// The result is, by construction, the minimum over (t, face index) of all accepted triangles -- the same
+// tree-independent definition the LBVH path implements, hence bit-identical images -- but the work is one
+// coalesced pass over the mesh (HBM-bound), with no sort, no tree and no dependent pointer chase.
+//
+//   rayset (built once per sensor model, reused across scans):
+//     k_rs_dirs    normalise (Vector3.h:73-89), azimuth/elevation, elevation range partials
+//     k_rs_keys    bin id per ray  ->  radix sort (k_hist/k_scan/k_scatter of lt_build.hip)
+//     k_rs_starts  first sorted slot of every bin
+//   per scan:
+//     k_sc_tris    one thread per triangle: bounds, candidate bins, MT, atomicMin; big triangles -> queue
+//     k_sc_large   one wave per queued triangle, lanes stride over its candidate rays
+//     k_sc_resolve one thread per ray: unpack (t, face), write-back (RayTracer.cpp:73-90), reset the cell
+#include "lt_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#define LT_TABLE_ATTR __device__
+#include "lt_rsqrt_sse_table.h"
+
+#define LT_PI_F 3.14159265358979f
+#define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define LT_SC_SMALL 48   // candidate bins handled inline by the triangle's own thread
+
+__device__ __forceinline__ float sc_rsqrt_sse(float x) {  // see lt_trace.hip:rsqrt_sse
+  const unsigned b = __float_as_uint(x);
+  const int e = (int)((b >> 23) & 255u);
+  if (e == 0) return INFINITY;
+  if (e == 255) return (b & 0x7fffffu) ? x : 0.0f;
+  const int p = (e - 127) & 1;
+  const int k = (e - 127 - p) / 2;
+  return __uint_as_float(LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((unsigned)k << 23));
+}
+
+struct rs_params {     // bin grid of a rayset
+  int nb_az, nb_el;
+  float az_scale;      // nb_az / 2pi
+  float el_lo, el_scale;
+};
+
+// ---- rayset -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rs_dirs(const float* __restrict__ rays, int n, unsigned flags,
+                                                 float4* __restrict__ dirs, float2* __restrict__ ang,
+                                                 float* __restrict__ partial) {
+  __shared__ float red[4][2];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float rx = rays[3 * (size_t)i], ry = rays[3 * (size_t)i + 1], rz = rays[3 * (size_t)i + 2];
+    const float D = (rx * rx + ry * ry) + rz * rz;
+    const float r0 = (flags & LT_TRACE_NORM_EXACT) ? 1.0f / sqrtf(D) : sc_rsqrt_sse(D);
+    const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
+    const float dx = rx * r, dy = ry * r, dz = rz * r;
+    dirs[i] = make_float4(dx, dy, dz, 0.f);
+    const float phi = atan2f(dy, dx), th = atan2f(dz, sqrtf(dx * dx + dy * dy));
+    ang[i] = make_float2(phi, th);
+    if (th == th) { lo = fminf(lo, th); hi = fmaxf(hi, th); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+    partial[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+  }
+}
+
+// reduce the elevation partials (every workgroup redoes it: 2 KB), publish the grid, bin id per ray
+__global__ __launch_bounds__(256) void k_rs_keys(const float2* __restrict__ ang, int n, int nb_az, int nb_el,
+                                                 const float* __restrict__ partial, rs_params* __restrict__ prm,
+                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  __shared__ float red[4][2];
+  float lo = partial[2 * threadIdx.x], hi = partial[2 * threadIdx.x + 1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
+  __syncthreads();
+  lo = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+  hi = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+  if (!(lo <= hi)) { lo = 0.f; hi = 0.f; }
+  lo -= 1e-5f;
+  hi += 1e-5f;
+  rs_params p;
+  p.nb_az = nb_az; p.nb_el = nb_el;
+  p.az_scale = (float)nb_az / (2.0f * LT_PI_F);
+  p.el_lo = lo;
+  p.el_scale = (float)nb_el / (hi - lo);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *prm = p;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 a = ang[i];
+  uint32_t key = (uint32_t)nb_az * (uint32_t)nb_el;  // NaN directions: one extra bin that no triangle visits
+  if (a.x == a.x && a.y == a.y) {
+    int ia = (int)floorf((a.x + LT_PI_F) * p.az_scale), ie = (int)floorf((a.y - p.el_lo) * p.el_scale);
+    ia = min(max(ia, 0), nb_az - 1);
+    ie = min(max(ie, 0), nb_el - 1);
+    key = (uint32_t)ie * (uint32_t)nb_az + (uint32_t)ia;
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+// bin_start[b] = first sorted slot whose key >= b, for b in [0, nbins]; keys are sorted
+__global__ __launch_bounds__(256) void k_rs_starts(const uint32_t* __restrict__ keys, int n, int nbins,
+                                                   int* __restrict__ bin_start) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p > n) return;
+  const int lo = p == 0 ? 0 : (int)min(keys[p - 1], (uint32_t)nbins) + 1;
+  const int hi = p == n ? nbins : (int)min(keys[p], (uint32_t)nbins);
+  for (int b = lo; b <= hi; ++b) bin_start[b] = p;
+}
+
+// ---- triangle scatter ------------------------------------------------------------------------------------
+struct tri_rec {
+  float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z;
+};
+
+// Moller-Trumbore with the reference's operation order (Triangle.h:27-50); returns t or NaN for "no hit"
+__device__ __forceinline__ float sc_mt(const tri_rec& T, float ox, float oy, float oz, float dx, float dy, float dz) {
+  const float eps = 0.000001f;
+  const float hx = dy * T.e2z - dz * T.e2y, hy = dz * T.e2x - dx * T.e2z, hz = dx * T.e2y - dy * T.e2x;
+  const float a = (T.e1x * hx + T.e1y * hy) + T.e1z * hz;
+  if (a < eps && a > -eps) return NAN;
+  const float inv_a = 1.0f / a;
+  const float sx = ox - T.v0x, sy = oy - T.v0y, sz = oz - T.v0z;
+  const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
+  if (u < 0 || u > 1) return NAN;
+  const float qx = sy * T.e1z - sz * T.e1y, qy = sz * T.e1x - sx * T.e1z, qz = sx * T.e1y - sy * T.e1x;
+  const float v = ((dx * qx + dy * qy) + dz * qz) * inv_a;
+  if (v < 0 || u + v > 1) return NAN;
+  const float t = ((T.e2x * qx + T.e2y * qy) + T.e2z * qz) * inv_a;
+  if (t < eps) return NAN;
+  return t;
+}
+
+__device__ __forceinline__ float seg_dist2d(float ax, float ay, float bx, float by) {  // |(0,0) - segment ab|
+  const float ex = bx - ax, ey = by - ay;
+  const float l2 = ex * ex + ey * ey;
+  float t = l2 > 0.f ? -(ax * ex + ay * ey) / l2 : 0.f;
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  const float cx = ax + t * ex, cy = ay + t * ey;
+  return sqrtf(cx * cx + cy * cy);
+}
+
+struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mod nb_az); elevation rows e0..e1
+
+// conservative angular bounds of a triangle seen from the origin -> bin rectangle (na == 0: nothing to do)
+__device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float y0, float z0, float x1, float y1,
+                                             float z1, float x2, float y2, float z2) {
+  bin_rect R;
+  R.na = 0; R.a0 = 0; R.e0 = 0; R.e1 = -1;
+  const float r0 = sqrtf(x0 * x0 + y0 * y0), r1 = sqrtf(x1 * x1 + y1 * y1), r2 = sqrtf(x2 * x2 + y2 * y2);
+  const float rho_max = fmaxf(r0, fmaxf(r1, r2));
+  const float zmin = fminf(z0, fminf(z1, z2)), zmax = fmaxf(z0, fmaxf(z1, z2));
+  // Where is the vertical axis through the origin relative to the triangle's xy-projection?
+  //   mixed signs of the three sub-areas  -> strictly outside: the azimuth extent is an arc < pi
+  //   all sub-areas ~ 0                   -> edge-on (projection is a segment): outside unless the segment
+  //                                          itself reaches the axis (rho_min ~ 0)
+  //   otherwise                           -> the axis pierces the triangle: every azimuth
+  const float c0 = x0 * y1 - x1 * y0, c1 = x1 * y2 - x2 * y1, c2 = x2 * y0 - x0 * y2;
+  const float tol = 1e-6f * (rho_max * rho_max) + 1e-12f;
+  const float cmin = fminf(c0, fminf(c1, c2)), cmax = fmaxf(c0, fmaxf(c1, c2));
+  const bool outside = cmin < -tol && cmax > tol;
+  const bool edge_on = cmin >= -tol && cmax <= tol;
+  const float rho_edges =
+      fminf(seg_dist2d(x0, y0, x1, y1), fminf(seg_dist2d(x1, y1, x2, y2), seg_dist2d(x2, y2, x0, y0)));
+  const bool pierced = !(outside || (edge_on && rho_edges > 1e-4f * rho_max + 1e-6f));
+  const float rho_min = pierced ? 0.f : rho_edges;
+  // angular padding: float rounding of atan2 and of the ray bins, plus the positional slop (<= ~1e-4 m) with
+  // which the float Moller-Trumbore test may accept a ray that passes just outside the triangle
+  const float d0 = sqrtf(r0 * r0 + z0 * z0), d1 = sqrtf(r1 * r1 + z1 * z1), d2 = sqrtf(r2 * r2 + z2 * z2);
+  const float e01 = sqrtf((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
+  const float e12 = sqrtf((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1));
+  const float e20 = sqrtf((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2) + (z0 - z2) * (z0 - z2));
+  const float dlo = fmaxf(fminf(d0, fminf(d1, d2)) - fmaxf(e01, fmaxf(e12, e20)), 0.05f);
+  const float pad = 3e-4f + 2e-4f / dlo;
+  // elevation: z / rho over the triangle
+  const float th_hi = (zmax > 0.f ? atan2f(zmax, rho_min) : atan2f(zmax, rho_max)) + pad;
+  const float th_lo = (zmin < 0.f ? atan2f(zmin, rho_min) : atan2f(zmin, rho_max)) - pad;
+  const float fe0 = floorf((th_lo - P.el_lo) * P.el_scale), fe1 = floorf((th_hi - P.el_lo) * P.el_scale);
+  if (!(fe1 >= 0.f) || !(fe0 <= (float)(P.nb_el - 1))) return R;  // outside the sensor's elevation range (or NaN)
+  R.e0 = (int)fmaxf(fe0, 0.f);
+  R.e1 = (int)fminf(fe1, (float)(P.nb_el - 1));
+  // azimuth: full circle when pierced, else the shortest arc holding the three vertex azimuths
+  if (pierced || rho_min <= 1e-4f * rho_max + 1e-6f) {
+    R.a0 = 0;
+    R.na = P.nb_az;
+    return R;
+  }
+  float p0 = atan2f(y0, x0), p1 = atan2f(y1, x1), p2 = atan2f(y2, x2);
+  float lo = fminf(p0, fminf(p1, p2)), hi = fmaxf(p0, fmaxf(p1, p2));
+  const float mid = (p0 + p1 + p2) - lo - hi;
+  const float g0 = mid - lo, g1 = hi - mid, g2 = 2.0f * LT_PI_F - (hi - lo);
+  float a_lo, a_hi;  // arc [a_lo, a_hi], a_hi may exceed pi (wraps)
+  if (g2 >= g0 && g2 >= g1) { a_lo = lo; a_hi = hi; }
+  else if (g0 >= g1) { a_lo = mid; a_hi = lo + 2.0f * LT_PI_F; }
+  else { a_lo = hi; a_hi = mid + 2.0f * LT_PI_F; }
+  a_lo -= pad;
+  a_hi += pad;
+  const float fa0 = floorf((a_lo + LT_PI_F) * P.az_scale), fa1 = floorf((a_hi + LT_PI_F) * P.az_scale);
+  int na = (int)(fa1 - fa0) + 1;
+  if (!(na >= 1)) return R;  // NaN
+  if (na >= P.nb_az) { R.a0 = 0; R.na = P.nb_az; return R; }
+  int a0 = (int)fa0 % P.nb_az;
+  if (a0 < 0) a0 += P.nb_az;
+  R.a0 = a0;
+  R.na = na;
+  return R;
+}
+
+// sdirs = normalised directions in bin order, ray index in .w (one dependent load less than dirs[bin_rays[k]])
+__device__ __forceinline__ void sc_test_bin(const tri_rec& T, int face, int bin, const int* __restrict__ bin_start,
+                                            const float4* __restrict__ sdirs, float ox, float oy, float oz,
+                                            unsigned long long* __restrict__ cell, unsigned& n_tests) {
+  const int s = bin_start[bin], e = bin_start[bin + 1];
+  for (int k = s; k < e; ++k) {
+    const float4 d = sdirs[k];
+    ++n_tests;
+    const float t = sc_mt(T, ox, oy, oz, d.x, d.y, d.z);
+    if (t == t)
+      atomicMin(&cell[__float_as_int(d.w)], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rs_sortdirs(const float4* __restrict__ dirs,
+                                                     const uint32_t* __restrict__ bin_rays, int n,
+                                                     float4* __restrict__ sdirs) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int ray = (int)bin_rays[k];
+  float4 d = dirs[ray];
+  d.w = __int_as_float(ray);
+  sdirs[k] = d;
+}
+
+#define LT_SC_BIG 4096  // candidate bins above which a triangle goes to the wave-per-triangle queue
+
+// One workgroup = 256 consecutive triangles.  Phase A: every thread sets up one triangle (record + bin
+// rectangle) in LDS and the workgroup prefix-sums the candidate counts.  Phase B: the (triangle, bin)
+// candidates of the whole workgroup are dealt round-robin to the threads, so every lane runs the same
+// number of Moller-Trumbore tests no matter how unevenly the triangles cover the image (near geometry
+// covers hundreds of cells, far geometry one or none).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                 int n_verts, int n_faces, float ox, float oy, float oz,
+                                                 const rs_params* __restrict__ prm, const int* __restrict__ bin_start,
+                                                 const float4* __restrict__ sdirs,
+                                                 unsigned long long* __restrict__ cell, int* __restrict__ large,
+                                                 int* __restrict__ large_count, unsigned* __restrict__ flags,
+                                                 unsigned long long* __restrict__ counters) {
+  __shared__ float tr[9][256];
+  __shared__ int ra0[256], rna[256], re0[256];
+  __shared__ int pre[257];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x * 256 + tid;
+  const rs_params P = *prm;
+  int cnt = 0;
+  if (f < n_faces) {
+    const int a = faces[3 * (size_t)f], b = faces[3 * (size_t)f + 1], c = faces[3 * (size_t)f + 2];
+    if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
+      const float* pa = verts + 3 * (size_t)a;
+      const float* pb = verts + 3 * (size_t)b;
+      const float* pc = verts + 3 * (size_t)c;
+      const float v0x = pa[0], v0y = pa[1], v0z = pa[2], v1x = pb[0], v1y = pb[1], v1z = pb[2];
+      const float v2x = pc[0], v2y = pc[1], v2z = pc[2];
+      const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
+                                  v2z - oz);
+      const int ne = R.e1 - R.e0 + 1;
+      if (R.na > 0 && ne > 0) {
+        const long long c64 = (long long)R.na * ne;
+        if (c64 > LT_SC_BIG) {
+          large[atomicAdd(large_count, 1)] = f;
+        } else {
+          cnt = (int)c64;
+          tr[0][tid] = v0x; tr[1][tid] = v0y; tr[2][tid] = v0z;
+          tr[3][tid] = v1x - v0x; tr[4][tid] = v1y - v0y; tr[5][tid] = v1z - v0z;
+          tr[6][tid] = v2x - v0x; tr[7][tid] = v2y - v0y; tr[8][tid] = v2z - v0z;
+          ra0[tid] = R.a0; rna[tid] = R.na; re0[tid] = R.e0;
+        }
+      }
+    } else {
+      atomicOr(flags, LT_FLAG_BAD_INDEX);
+    }
+  }
+  // exclusive prefix sum of cnt over the workgroup
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  pre[tid] = woff + inc - cnt;
+  if (tid == 255) pre[256] = woff + inc;
+  __syncthreads();
+  const int total = pre[256];
+  unsigned n_tests = 0, n_cand = 0;
+  for (int c = tid; c < total; c += 256) {
+    // triangle j of this candidate: largest j with pre[j] <= c
+    int j = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1)
+      if (pre[j + step] <= c) j += step;
+    const int local = c - pre[j];
+    const int na = rna[j];
+    const int row = local / na;
+    int az = ra0[j] + (local - row * na);
+    if (az >= P.nb_az) az -= P.nb_az;
+    tri_rec T;
+    T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
+    T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
+    T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
+    if (COUNT) ++n_cand;
+    sc_test_bin(T, blockIdx.x * 256 + j, (re0[j] + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+  }
+  if (COUNT) {
+    unsigned long long vt = n_tests, vc = n_cand;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vt += __shfl_xor(vt, o, 64); vc += __shfl_xor(vc, o, 64); }
+    if (lane == 0) { atomicAdd(&counters[1], vt); atomicAdd(&counters[0], vc); }
+  }
+}
+
+// one wave per queued (large) triangle; lanes stride over its candidate bins
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_sc_large(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                  float ox, float oy, float oz, const rs_params* __restrict__ prm,
+                                                  const int* __restrict__ bin_start,
+                                                  const float4* __restrict__ sdirs,
+                                                  unsigned long long* __restrict__ cell, const int* __restrict__ large,
+                                                  const int* __restrict__ large_count,
+                                                  unsigned long long* __restrict__ counters) {
+  const rs_params P = *prm;
+  const int n_large = *large_count;
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  unsigned n_tests = 0, n_cand = 0;
+  for (int q = wave0; q < n_large; q += nwaves) {
+    const int f = large[q];
+    const float* pa = verts + 3 * (size_t)faces[3 * (size_t)f];
+    const float* pb = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
+    const float* pc = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
+    tri_rec T;
+    T.v0x = pa[0]; T.v0y = pa[1]; T.v0z = pa[2];
+    const float v1x = pb[0], v1y = pb[1], v1z = pb[2], v2x = pc[0], v2y = pc[1], v2z = pc[2];
+    T.e1x = v1x - T.v0x; T.e1y = v1y - T.v0y; T.e1z = v1z - T.v0z;
+    T.e2x = v2x - T.v0x; T.e2y = v2y - T.v0y; T.e2z = v2z - T.v0z;
+    const bin_rect R = tri_bins(P, T.v0x - ox, T.v0y - oy, T.v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox,
+                                v2y - oy, v2z - oz);
+    const long long total = (long long)R.na * (R.e1 - R.e0 + 1);
+    for (long long w = lane; w < total; w += 64) {
+      const int e = R.e0 + (int)(w / R.na);
+      int az = R.a0 + (int)(w % R.na);
+      if (az >= P.nb_az) az -= P.nb_az;
+      if (COUNT) ++n_cand;
+      sc_test_bin(T, f, e * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+    }
+  }
+  if (COUNT) {
+    unsigned long long vt = n_tests, vc = n_cand;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vt += __shfl_xor(vt, o, 64); vc += __shfl_xor(vc, o, 64); }
+    if (lane == 0) { atomicAdd(&counters[1], vt); atomicAdd(&counters[0], vc); }
+  }
+}
+
+// one thread per ray: unpack the winning (t, face), write back as RayTracer.cpp:73-90, re-arm the cell
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_sc_resolve(unsigned long long* __restrict__ cell,
+                                                    const float4* __restrict__ dirs, int n_rays, float ox, float oy,
+                                                    float oz, const int* __restrict__ faces,
+                                                    const int* __restrict__ colors, const float* __restrict__ rem,
+                                                    float* __restrict__ endpoints, int* __restrict__ endcolors,
+                                                    float* __restrict__ range, float* __restrict__ endrem,
+                                                    int* __restrict__ tri_out, unsigned flags,
+                                                    int* __restrict__ large_count,
+                                                    unsigned long long* __restrict__ counters) {
+  const int ray = blockIdx.x * 256 + threadIdx.x;
+  if (ray == 0) *large_count = 0;
+  bool hit = false;
+  if (ray < n_rays) {
+    const unsigned long long key = cell[ray];
+    cell[ray] = LT_EMPTY_KEY;
+    hit = key != LT_EMPTY_KEY;
+    if (hit) {
+      const float t = __uint_as_float((unsigned)(key >> 32));
+      const int face = (int)(unsigned)(key & 0xFFFFFFFFull);
+      const float4 d = dirs[ray];
+      const int i0 = faces[3 * (size_t)face], i1 = faces[3 * (size_t)face + 1], i2 = faces[3 * (size_t)face + 2];
+      if (endpoints) {
+        endpoints[3 * (size_t)ray] = ox + d.x * t;
+        endpoints[3 * (size_t)ray + 1] = oy + d.y * t;
+        endpoints[3 * (size_t)ray + 2] = oz + d.z * t;
+      }
+      if (endcolors) {
+        endcolors[3 * (size_t)ray] = (int)(float)colors[3 * (size_t)i0];
+        endcolors[3 * (size_t)ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
+        endcolors[3 * (size_t)ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+      }
+      if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
+      if (range) range[ray] = t;
+      if (tri_out) tri_out[ray] = face;
+    } else if (flags & LT_TRACE_WRITE_MISSES) {
+      if (endpoints) { endpoints[3 * (size_t)ray] = 0.f; endpoints[3 * (size_t)ray + 1] = 0.f; endpoints[3 * (size_t)ray + 2] = 0.f; }
+      if (endcolors) { endcolors[3 * (size_t)ray] = 0; endcolors[3 * (size_t)ray + 1] = 0; endcolors[3 * (size_t)ray + 2] = 0; }
+      if (endrem) endrem[ray] = 0.f;
+      if (range) range[ray] = 0.f;
+      if (tri_out) tri_out[ray] = -1;
+    }
+  }
+  if (COUNT) {
+    unsigned long long vh = hit ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vh += __shfl_xor(vh, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&counters[2], vh);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+// sort kernels of lt_build.hip
+void lt_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, int n, int key_bits, hipStream_t stream,
+                   int* out_buffer);
+
+struct lt_rayset {
+  int device;
+  int n_rays, height, nb_az, nb_el;
+  unsigned norm_flags;
+  float4* dirs;
+  float2* ang;
+  float* partial;
+  rs_params* prm;
+  uint32_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;
+  int* bin_start;
+  uint32_t* bin_rays;  // = vals[sorted buffer]
+  float4* sdirs;       // directions in bin order, ray index in .w
+  unsigned long long* cell;
+  int* large;
+  int* large_count;
+  int cap_large;
+};
+
+static void rs_free(lt_rayset* r) {
+  void* ps[] = {r->sdirs, r->dirs, r->ang, r->partial, r->prm, r->keys[0], r->keys[1], r->vals[0], r->vals[1], r->hist,
+                r->bin_start, r->cell, r->large, r->large_count};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int lt_rayset_destroy(lt_rayset* r) {
+  if (!r) return LT_OK;
+  (void)hipSetDevice(r->device);
+  (void)hipDeviceSynchronize();
+  rs_free(r);
+  free(r);
+  return LT_OK;
+}
+
+extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_rays, int height, unsigned flags,
+                                    void* stream_) {
+  if (!out || n_rays < 0 || height <= 0 || (n_rays > 0 && !rays)) {
+    lt_set_error("lt_rayset_create_dev: invalid argument (n_rays=%d height=%d)", n_rays, height);
+    return LT_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  hipStream_t stream = (hipStream_t)stream_;
+  lt_rayset* r = (lt_rayset*)calloc(1, sizeof(lt_rayset));
+  if (!r) return LT_ERR_NO_MEMORY;
+  LT_HIP(hipGetDevice(&r->device));
+  const int W = n_rays / height;
+  const int n = W * height;  // RayTracer.cpp:56: rays beyond W * height are ignored
+  r->n_rays = n;
+  r->height = height;
+  r->norm_flags = flags & LT_TRACE_NORM_EXACT;
+  r->nb_az = W < 1 ? 1 : (W > 8192 ? 8192 : W);
+  r->nb_el = height > 4096 ? 4096 : height;
+  const size_t nbins = (size_t)r->nb_az * r->nb_el + 1;  // + the NaN bin
+  const size_t nn = n > 0 ? n : 1;
+  const int nb = (int)((nn + LT_SORT_TILE - 1) / LT_SORT_TILE);
+  int rc = LT_OK;
+#define RS_ALLOC(ptr, bytes)                                                  \
+  if (rc == LT_OK && hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {      \
+    lt_set_error("lt_rayset_create_dev: hipMalloc of %zu bytes failed", (size_t)(bytes)); \
+    rc = LT_ERR_NO_MEMORY;                                                    \
+  }
+  RS_ALLOC(r->dirs, nn * sizeof(float4));
+  RS_ALLOC(r->ang, nn * sizeof(float2));
+  RS_ALLOC(r->sdirs, nn * sizeof(float4));
+  RS_ALLOC(r->partial, 2 * 256 * sizeof(float));
+  RS_ALLOC(r->prm, sizeof(rs_params));
+  for (int k = 0; k < 2; ++k) {
+    RS_ALLOC(r->keys[k], nn * sizeof(uint32_t));
+    RS_ALLOC(r->vals[k], nn * sizeof(uint32_t));
+  }
+  RS_ALLOC(r->hist, ((size_t)1024 * nb + 1024) * sizeof(uint32_t));
+  RS_ALLOC(r->bin_start, (nbins + 1) * sizeof(int));
+  RS_ALLOC(r->cell, nn * sizeof(unsigned long long));
+  RS_ALLOC(r->large_count, 4 * sizeof(int));
+#undef RS_ALLOC
+  if (rc != LT_OK) {
+    rs_free(r);
+    free(r);
+    return rc;
+  }
+  LT_HIP(hipMemsetAsync(r->cell, 0xFF, nn * sizeof(unsigned long long), stream));
+  LT_HIP(hipMemsetAsync(r->large_count, 0, 4 * sizeof(int), stream));
+  hipLaunchKernelGGL(k_rs_dirs, dim3(256), dim3(256), 0, stream, rays, n, r->norm_flags, r->dirs, r->ang, r->partial);
+  hipLaunchKernelGGL(k_rs_keys, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, stream, r->ang, n,
+                     r->nb_az, r->nb_el, r->partial, r->prm, r->keys[0], r->vals[0]);
+  int buf = 0;
+  if (n > 0) lt_sort_pairs(r->keys, r->vals, r->hist, n, 30, stream, &buf);
+  r->bin_rays = r->vals[buf];
+  hipLaunchKernelGGL(k_rs_starts, dim3((n + 1 + 255) / 256), dim3(256), 0, stream, r->keys[buf], n, (int)nbins,
+                     r->bin_start);
+  if (n > 0)
+    hipLaunchKernelGGL(k_rs_sortdirs, dim3((n + 255) / 256), dim3(256), 0, stream, r->dirs, r->bin_rays, n, r->sdirs);
+  LT_HIP(hipGetLastError());
+  *out = r;
+  return LT_OK;
+}
+
+static int rs_reserve_large(lt_rayset* r, int n_faces) {
+  if (n_faces <= r->cap_large) return LT_OK;
+  if (r->large) {
+    LT_HIP(hipDeviceSynchronize());
+    (void)hipFree(r->large);
+    r->large = nullptr;
+  }
+  const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
+  LT_HIP(hipMalloc((void**)&r->large, cap * sizeof(int)));
+  r->cap_large = (int)cap;
+  return LT_OK;
+}
+
+// Render the scene's CURRENT mesh with the scatter strategy (no BVH needed).
+extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origin, float* endpoints, int* endcolors,
+                                   float* range, float* endrem, int* tri, unsigned flags, void* stream_,
+                                   lt_stats* stats) {
+  if (!s || !r || !origin) {
+    lt_set_error("lt_scene_render_dev: NULL scene / rayset / origin");
+    return LT_ERR_INVALID_ARG;
+  }
+  if (s->device != r->device) {
+    lt_set_error("lt_scene_render_dev: scene on device %d, rayset on device %d", s->device, r->device);
+    return LT_ERR_INVALID_ARG;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  LT_HIP(hipSetDevice(s->device));
+  s->last_stream = stream;
+  const int n = s->n_faces, R = r->n_rays;
+  const bool timed = stats != nullptr, count = (flags & LT_TRACE_COUNT) != 0;
+  s->stats.n_rays = R;
+  s->stats.n_faces = n;
+  if (R > 0) {
+    LT_CHECK(rs_reserve_large(r, n));
+    if (count) LT_HIP(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
+    if (timed) LT_HIP(hipEventRecord(s->ev[7], stream));
+    const float ox = origin[0], oy = origin[1], oz = origin[2];
+    if (n > 0) {
+      const dim3 g((n + 255) / 256), b(256);
+      if (count) {
+        hipLaunchKernelGGL(k_sc_tris<true>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
+                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->flags,
+                           s->counters);
+        hipLaunchKernelGGL(k_sc_large<true>, dim3(512), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
+                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
+      } else {
+        if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
+        hipLaunchKernelGGL(k_sc_tris<false>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
+                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->flags,
+                           s->counters);
+        if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
+        s->probe[0] = s->probe[1] = nullptr;
+        hipLaunchKernelGGL(k_sc_large<false>, dim3(512), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
+                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
+      }
+    }
+    if (count)
+      hipLaunchKernelGGL(k_sc_resolve<true>, dim3((R + 255) / 256), dim3(256), 0, stream, r->cell, r->dirs, R, ox, oy,
+                         oz, s->faces, s->colors, s->rem, endpoints, endcolors, range, endrem, tri, flags,
+                         r->large_count, s->counters);
+    else
+      hipLaunchKernelGGL(k_sc_resolve<false>, dim3((R + 255) / 256), dim3(256), 0, stream, r->cell, r->dirs, R, ox,
+                         oy, oz, s->faces, s->colors, s->rem, endpoints, endcolors, range, endrem, tri, flags,
+                         r->large_count, s->counters);
+    if (timed) LT_HIP(hipEventRecord(s->ev[8], stream));
+    LT_HIP(hipGetLastError());
+  }
+  if (timed || count) {
+    LT_HIP(hipStreamSynchronize(stream));
+    if (timed && R > 0) LT_HIP(hipEventElapsedTime(&s->stats.ms_trace, s->ev[7], s->ev[8]));
+    if (count && R > 0) {
+      unsigned long long c[4];
+      LT_HIP(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
+      s->stats.nodes_visited = c[0];  // candidate bins visited
+      s->stats.tris_tested = c[1];    // Moller-Trumbore evaluations
+      s->stats.n_hits = (int)c[2];
+      s->stats.stack_overflows = 0;
+    }
+    if (stats) *stats = s->stats;
+  }
+  return LT_OK;
+}

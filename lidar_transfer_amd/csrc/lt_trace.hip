@@ -470,10 +470,14 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
         hipLaunchKernelGGL(k_trace4<true>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays, origin[0],
                            origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints,
                            endcolors, range, endrem, tri, flags, s->overflow, s->counters);
-      else
+      else {
+        if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
         hipLaunchKernelGGL(k_trace4<false>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays,
                            origin[0], origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem,
                            endpoints, endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+        if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
+        s->probe[0] = s->probe[1] = nullptr;
+      }
     }
     if (timed) LT_HIP(hipEventRecord(s->ev[8], stream));
     LT_HIP(hipGetLastError());

@@ -171,6 +171,35 @@ class Scene:
             out["stats"] = st.asdict()
         return out
 
+    def render(self, rayset, origin, out=None, stream=None, write_misses=True, count=False, stats=False):
+        """Closest hits of a :class:`RaySet` against the CURRENT mesh with the single-origin scatter
+        strategy (``lt_scene_render_dev``): no BVH build; bit-identical to :meth:`build` + :meth:`trace`."""
+        if out is None:
+            out = self.alloc_outputs(rayset.n_rays)
+        org = (C.c_float * 3)(*[float(v) for v in origin])
+        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
+        st = _lib.Stats()
+
+        def p(k):
+            t = out.get(k)
+            return t.data_ptr() if t is not None else None
+
+        _lib.check(self._lib.lt_scene_render_dev(self._h, rayset._h, org, p("endpoints"), p("endcolors"), p("range"),
+                                                 p("endrem"), p("tri"), flags, self._stream(stream),
+                                                 C.byref(st) if (stats or count) else None), "lt_scene_render_dev")
+        if stats or count:
+            out = dict(out)
+            out["stats"] = st.asdict()
+        return out
+
+    def set_probe(self, ev_start, ev_stop):
+        """Record two ``torch.cuda.Event(enable_timing=True)`` around the dominant kernel of the next cast."""
+        for ev in (ev_start, ev_stop):  # materialise the underlying hipEvent_t
+            if not ev.cuda_event:
+                ev.record()
+        _lib.check(self._lib.lt_scene_set_probe(self._h, C.c_void_p(ev_start.cuda_event),
+                                                C.c_void_p(ev_stop.cuda_event)), "lt_scene_set_probe")
+
     def alloc_outputs(self, n_rays):
         torch = self._torch
         d = self.device
@@ -182,3 +211,37 @@ class Scene:
 
     def status(self):
         _lib.check(self._lib.lt_scene_status(self._h), "lt_scene_status")
+
+
+class RaySet:
+    """A ray batch prepared for :meth:`Scene.render` (``lt_rayset`` in include/lidarhip.h): directions
+    normalised like the reference (Vector3.h:73-89) and binned by azimuth x elevation.  One per sensor
+    model; reuse it for every scan."""
+
+    def __init__(self, rays, H, exact_normalize=False, stream=None):
+        import torch
+        if not isinstance(rays, torch.Tensor) or rays.dtype != torch.float32 or not rays.is_contiguous() \
+                or not rays.is_cuda:
+            raise ValueError("rays: contiguous float32 CUDA tensor [R, 3] expected")
+        self._lib = _lib.load()
+        self.n_rays = (rays.numel() // 3 // int(H)) * int(H)
+        self.H = int(H)
+        st = torch.cuda.current_stream(rays.device) if stream is None else stream
+        h = C.c_void_p()
+        with torch.cuda.device(rays.device):
+            _lib.check(self._lib.lt_rayset_create_dev(C.byref(h), rays.data_ptr(), rays.numel() // 3, int(H),
+                                                      _lib.LT_TRACE_NORM_EXACT if exact_normalize else 0,
+                                                      C.c_void_p(st.cuda_stream)), "lt_rayset_create_dev")
+            st.synchronize()
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_rayset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

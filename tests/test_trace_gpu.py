@@ -271,3 +271,77 @@ def test_throw_rays_at_mesh_tuple_matches_reference_layout():
     lut = np.arange(300 * 3, dtype=np.float32).reshape(300, 3)
     label_image, proj_color = unpack_deform(rc, lut, H, W)
     assert label_image.shape == (H, W) and proj_color.shape == (H, W, 3)
+
+
+# ---- the two strategies: LBVH build + quad traversal vs single-origin triangle scatter ---------------------
+def _both_strategies(v, f, c, r, rays, origin, H):
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    sc = Scene(0)
+    sc.set_mesh(*[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (v, f, c, r)])
+    trays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
+    rs = RaySet(trays, H)
+    a = sc.render(rs, origin, count=True)
+    sc.build()
+    b = sc.trace(trays, origin, H, count=True)
+    torch.cuda.synchronize()
+    a = {k: (x.cpu().numpy() if hasattr(x, "cpu") else x) for k, x in a.items()}
+    b = {k: (x.cpu().numpy() if hasattr(x, "cpu") else x) for k, x in b.items()}
+    rs.close()
+    sc.close()
+    return a, b
+
+
+def test_scatter_equals_lbvh_equals_bruteforce_on_adversarial_soup(oracle):
+    """Random triangle soup around the sensor: triangles pierced by the vertical axis, edge-on triangles,
+    triangles a few centimetres from the origin, huge triangles; rays in arbitrary (non-grid) directions
+    including straight up / down and the coordinate axes."""
+    rng = np.random.default_rng(42)
+    n = 3000
+    cen = rng.normal(size=(n, 3)) * rng.choice([0.05, 0.5, 5.0, 40.0], size=(n, 1))
+    size = rng.choice([0.01, 0.1, 1.0, 20.0], size=(n, 1, 1))
+    tri = cen[:, None, :] + rng.normal(size=(n, 3, 3)) * size
+    tri[:200, :, 1] = 0.0                      # edge-on: in the plane y = 0 through the sensor
+    tri[200:300, :, 2] = tri[200:300, :1, 2]   # horizontal triangles (many contain the vertical axis)
+    tri[300:320] = tri[300:320] * [1, 1, 0] + [0, 0, 3.0]
+    v = np.ascontiguousarray(tri.reshape(-1, 3).astype(np.float32))
+    f = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    c = np.stack([rng.integers(0, 255, 3 * n), rng.integers(0, 255, 3 * n), rng.integers(0, 260, 3 * n)], 1) \
+        .astype(np.int32)
+    r = rng.uniform(0, 1, 3 * n).astype(np.float32)
+    H, W = 8, 512
+    rays = rng.normal(size=(H * W, 3)).astype(np.float32)
+    rays[:6] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]]
+    rays[6:200, 1] = 0.0                       # rays inside the plane of the edge-on triangles
+    for origin in ((0.0, 0.0, 0.0), (0.3, -0.2, 0.1)):
+        a, b = _both_strategies(v, f, c, r, rays, origin, H)
+        ref = oracle.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE,
+                                  norm=oracle.NORM_SSE_TABLE)
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(a[k], ref[k], f"scatter {k} origin={origin}")
+            _assert_bits(b[k], ref[k], f"lbvh {k} origin={origin}")
+        assert a["stats"]["n_hits"] == b["stats"]["n_hits"] == int((ref["tri"] >= 0).sum()) > 100
+
+
+@pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
+                                            ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
+def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):
+    """BASELINE.json configurations at full size (0.2 M - 2.5 M triangles, up to 128x2048 rays): the two
+    independent strategies must produce identical images, bit for bit."""
+    from lidar_transfer_amd.synth import WORKLOADS
+    w = WORKLOADS[wl]
+    v, f, c, r = synth_scene(seed, w["tris"])
+    rays = create_rays(w["fov_up"], w["fov_down"], w["H"], w["W"])
+    a, b = _both_strategies(v, f, c, r, rays, origin, w["H"])
+    for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+        _assert_bits(a[k], b[k], f"{wl} {k}")
+    hits = int((a["tri"] >= 0).sum())
+    assert hits == a["stats"]["n_hits"] == b["stats"]["n_hits"] and hits > 0.5 * w["H"] * w["W"]
+    assert b["stats"]["stack_overflows"] == 0
+    # size-independent properties: a hit point lies on its ray at the reported range, inside the scene bounds
+    ok = a["tri"] >= 0
+    d = a["endpoints"][ok] - np.asarray(origin, np.float32)
+    assert np.allclose(np.linalg.norm(d, axis=1), a["range"][ok], rtol=2e-6)
+    assert np.all(np.abs(a["endpoints"][ok]) <= np.abs(v).max() + 1e-3)
+    assert np.all(a["range"][~ok] == 0) and np.all(a["endcolors"][~ok] == 0)
