@@ -18,7 +18,8 @@ Two MI355X-native strategies produce bit-identical images (tests/test_trace_gpu.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Scans shard over ranks (weak scaling: every rank renders K scans), no data-path collective; the rendered
-range and colour/label images are gathered ONCE over RCCL at the end of the timed region.  Rank 0 prints
+range and label images are gathered to rank 0 over RCCL inside the timed region (one logical gather, issued in
+8 chunks so that it overlaps the rendering of later scans).  Rank 0 prints
 one JSON line with `roofline` for the dominant kernel (HIP events around every launch of it inside the
 timed region) and `cpu_baseline` = the real reference raytracer (oracle/_ref, prebuilt from
 /root/reference) timed on this box's host cores on a bounded sample of the same workload.
@@ -56,7 +57,7 @@ def parse():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "4")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "8")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other strategy")
@@ -128,7 +129,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # also under `torchrun --nproc-per-node 1` (exercises the gather path)
         dist.init_process_group("nccl", device_id=dev)
     wl = dict(WORKLOADS[args.workload])
     H, W = wl["H"], wl["W"]
@@ -149,60 +150,117 @@ def main():
     scratch = [workers[0].alloc_outputs(R) for _ in range(S)]
 
     def run(strategy, K, Wm, keep):
-        """Timed region for one strategy; returns (seconds, mean dominant-kernel ms, images)."""
+        """Timed region for one strategy; returns (seconds, mean dominant-kernel ms, hits of the last scan)."""
+        dist_on = dist.is_initialized()
         range_all = torch.zeros((K, R), dtype=torch.float32, device=dev) if keep else None
-        label_all = torch.zeros((K, R, 3), dtype=torch.int32, device=dev) if keep else None
+        color_all = torch.zeros((K, R, 3), dtype=torch.int32, device=dev) if keep else None  # endcolors per scan
         # HIP events around every launch of the dominant kernel in the timed region (created and
         # materialised before the clock starts; recorded by the library on the launch stream)
         probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         for e0, e1 in probes:
             e0.record()
             e1.record()
+        # the gather of the rendered images (range f32 + label i32 = 8 B per ray) to rank 0 is ONE logical
+        # collective, issued in `n_chunks` pieces so that it overlaps the rendering of the following scans
+        # (grouped send/recv: 7 peers -> root over 7 separate xGMI links)
+        n_chunks = int(os.environ.get("LT_BENCH_GATHER_CHUNKS", "8")) if (dist_on and keep) else 1
+        do_gather = dist_on and keep and n_chunks > 0
+        n_chunks = max(n_chunks, 1)
+        bounds = [K * c // n_chunks for c in range(n_chunks + 1)]
+        recv = None
+        if do_gather and rank == 0:
+            recv = [(torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.float32, device=dev),
+                     torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.int32, device=dev))
+                    for c in range(n_chunks)]
+        works = []
+
+        # Host side of one step, kept as thin as a C++ driver would be: three calls into liblidarhip.so with
+        # precomputed handles and pointers (mesh pointer swap, probe events, one render / build+trace).
+        import ctypes as C
+        from lidar_transfer_amd import _lib
+        lib = _lib.load()
+        vp = C.c_void_p
+        org = (C.c_float * 3)(*origin)
+        sh = [vp(st.cuda_stream) for st in streams]
+        wh = [w._h for w in workers]
+        rh = [r._h for r in raysets]
+        mesh_args = [(vp(v.data_ptr()), vp(f.data_ptr()), vp(c.data_ptr()), vp(r.data_ptr()), v.numel() // 3,
+                      f.numel() // 3) for v, f, c, r in scenes]
+        pr = [(vp(a.cuda_event), vp(b.cuda_event)) for a, b in probes]
+        sp = [{k: vp(t.data_ptr()) for k, t in scratch[s].items()} for s in range(S)]
+        rng_p = [vp(range_all[k].data_ptr()) for k in range(K)] if keep else None
+        col_p = [vp(color_all[k].data_ptr()) for k in range(K)] if keep else None
+        rays_p = vp(rays.data_ptr())
+        FL = _lib.LT_TRACE_WRITE_MISSES
 
         def step(i, slot=None, timed=False):
             s = i % S
-            sc = workers[s]
-            out = dict(scratch[s])
-            if slot is not None and keep:
-                out["range"] = range_all[slot]
-                out["endcolors"] = label_all[slot]
-            with torch.cuda.stream(streams[s]):
-                sc.set_mesh(*scenes[i % len(scenes)])
-                if timed:
-                    sc.set_probe(*probes[slot])
-                if strategy == "lbvh":
-                    sc.build(stream=streams[s])
-                    sc.trace(rays, origin, H, out=out, stream=streams[s], write_misses=True)
-                else:
-                    sc.render(raysets[s], origin, out=out, stream=streams[s], write_misses=True)
+            h = wh[s]
+            o = sp[s]
+            p_rng = rng_p[slot] if (keep and slot is not None) else o["range"]
+            p_col = col_p[slot] if (keep and slot is not None) else o["endcolors"]
+            rc = lib.lt_scene_set_mesh_dev(h, *mesh_args[i % len(scenes)])
+            if timed:
+                rc |= lib.lt_scene_set_probe(h, *pr[slot])
+            if strategy == "lbvh":
+                rc |= lib.lt_scene_build(h, sh[s], None)
+                rc |= lib.lt_scene_trace_dev(h, rays_p, org, R, H, o["endpoints"], p_col, p_rng, o["endrem"], o["tri"],
+                                             FL, sh[s], None)
+            else:
+                rc |= lib.lt_scene_render_dev(h, rh[s], org, o["endpoints"], p_col, p_rng, o["endrem"], o["tri"], FL,
+                                              sh[s], None)
+            if rc:
+                _lib.check(rc, "bench step")
+
+        def gather_chunk(c):
+            c0, c1 = bounds[c], bounds[c + 1]
+            cur = torch.cuda.current_stream(dev)
+            for st in streams:  # the collective starts when this chunk's scans are done; later scans keep running
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
+            # deform's unpack for the whole chunk: label_image = ray_colors[:, :, 2] (laserscan.py:912)
+            label_chunk = color_all[c0:c1, :, 2].contiguous()
+            for k, src in enumerate((range_all[c0:c1], label_chunk)):
+                lst = [recv[c][k][r] for r in range(world)] if rank == 0 else None
+                works.append(dist.gather(src, gather_list=lst, dst=0, async_op=True))
 
         for i in range(Wm):
             step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if do_gather:  # warm-up of the collective too: RCCL sets up its peer-to-peer channels lazily
+            wbuf = torch.zeros((4, R), dtype=torch.float32, device=dev)
+            wl_ = [torch.empty_like(wbuf) for _ in range(world)] if rank == 0 else None
+            for _ in range(2):
+                dist.gather(wbuf, gather_list=wl_, dst=0)
+            torch.cuda.synchronize()
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        chunk = 0
         for i in range(K):
             step(i, slot=i, timed=True)
+            if do_gather and i + 1 == bounds[chunk + 1]:
+                gather_chunk(chunk)
+                chunk += 1
+        for wk in works:
+            wk.wait()
         for st in streams:
             st.synchronize()
-        if world > 1 and keep:  # the single RCCL gather of the rendered images (range + colour/label)
-            gathered_r = torch.empty((world, K, R), dtype=torch.float32, device=dev)
-            gathered_l = torch.empty((world, K, R, 3), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(gathered_r, range_all)
-            dist.all_gather_into_tensor(gathered_l, label_all)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probes])) if probes else float("nan")
         hits = int((range_all[K - 1] > 0).sum().item()) if keep else -1
+        if recv is not None:  # rank 0 really holds every rank's images
+            assert torch.equal(recv[-1][0][0, -1], range_all[K - 1])
         return dt, kern_ms, hits
 
     # ---- counting passes (outside the clock): work per scan for the roofline ------------------------------
@@ -254,7 +312,7 @@ def main():
                                    f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan (new mesh) per step, "
                                    f"{len(scenes)} distinct scenes cycled",
                        "strategy": args.strategy,
-                       "parallelism": f"scan-parallel x{world}" + (", one all_gather of images" if world > 1 else ""),
+                       "parallelism": f"scan-parallel x{world}" + (", range+label images gathered to rank 0 over RCCL (8 chunks, overlapped)" if dist.is_initialized() else ""),
                        "streams_per_gpu": S},
             "scans_per_s": round(world * K / dt, 2),
             "hit_fraction": round(hits / R, 4),
@@ -274,7 +332,7 @@ def main():
         rs.close()
     for wk in workers:
         wk.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -146,13 +146,29 @@ __device__ __forceinline__ float sc_mt(const tri_rec& T, float ox, float oy, flo
   return t;
 }
 
+// The angular bounds below only have to be CONSERVATIVE (they are padded by >= 3e-4 rad), so they use the
+// hardware approximations (1 ulp rcp / sqrt) and a degree-11 minimax arctangent (max error 2e-6 rad) instead
+// of the IEEE sequences the triangle test itself needs: k_sc_tris is VALU bound.
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float f_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mx > 0.f ? mn * f_rcp(mx) : 0.f;
+  const float q = a * a;
+  float r = a * (0.99997726f + q * (-0.33262347f + q * (0.19354346f + q * (-0.11643287f + q * (0.05265332f + q * -0.01172120f)))));
+  r = ay > ax ? 1.57079632679f - r : r;
+  r = x < 0.f ? 3.14159265359f - r : r;
+  return y < 0.f ? -r : r;
+}
+
 __device__ __forceinline__ float seg_dist2d(float ax, float ay, float bx, float by) {  // |(0,0) - segment ab|
   const float ex = bx - ax, ey = by - ay;
   const float l2 = ex * ex + ey * ey;
-  float t = l2 > 0.f ? -(ax * ex + ay * ey) / l2 : 0.f;
+  float t = l2 > 0.f ? -(ax * ex + ay * ey) * f_rcp(l2) : 0.f;
   t = fminf(fmaxf(t, 0.f), 1.f);
   const float cx = ax + t * ex, cy = ay + t * ey;
-  return sqrtf(cx * cx + cy * cy);
+  return f_sqrt(cx * cx + cy * cy);
 }
 
 struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mod nb_az); elevation rows e0..e1
@@ -162,7 +178,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
                                              float z1, float x2, float y2, float z2) {
   bin_rect R;
   R.na = 0; R.a0 = 0; R.e0 = 0; R.e1 = -1;
-  const float r0 = sqrtf(x0 * x0 + y0 * y0), r1 = sqrtf(x1 * x1 + y1 * y1), r2 = sqrtf(x2 * x2 + y2 * y2);
+  const float r0 = f_sqrt(x0 * x0 + y0 * y0), r1 = f_sqrt(x1 * x1 + y1 * y1), r2 = f_sqrt(x2 * x2 + y2 * y2);
   const float rho_max = fmaxf(r0, fmaxf(r1, r2));
   const float zmin = fminf(z0, fminf(z1, z2)), zmax = fmaxf(z0, fmaxf(z1, z2));
   // Where is the vertical axis through the origin relative to the triangle's xy-projection?
@@ -181,15 +197,15 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   const float rho_min = pierced ? 0.f : rho_edges;
   // angular padding: float rounding of atan2 and of the ray bins, plus the positional slop (<= ~1e-4 m) with
   // which the float Moller-Trumbore test may accept a ray that passes just outside the triangle
-  const float d0 = sqrtf(r0 * r0 + z0 * z0), d1 = sqrtf(r1 * r1 + z1 * z1), d2 = sqrtf(r2 * r2 + z2 * z2);
-  const float e01 = sqrtf((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
-  const float e12 = sqrtf((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1));
-  const float e20 = sqrtf((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2) + (z0 - z2) * (z0 - z2));
+  const float d0 = f_sqrt(r0 * r0 + z0 * z0), d1 = f_sqrt(r1 * r1 + z1 * z1), d2 = f_sqrt(r2 * r2 + z2 * z2);
+  const float e01 = f_sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
+  const float e12 = f_sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1));
+  const float e20 = f_sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2) + (z0 - z2) * (z0 - z2));
   const float dlo = fmaxf(fminf(d0, fminf(d1, d2)) - fmaxf(e01, fmaxf(e12, e20)), 0.05f);
-  const float pad = 3e-4f + 2e-4f / dlo;
+  const float pad = 3e-4f + 2e-4f * f_rcp(dlo);
   // elevation: z / rho over the triangle
-  const float th_hi = (zmax > 0.f ? atan2f(zmax, rho_min) : atan2f(zmax, rho_max)) + pad;
-  const float th_lo = (zmin < 0.f ? atan2f(zmin, rho_min) : atan2f(zmin, rho_max)) - pad;
+  const float th_hi = (zmax > 0.f ? f_atan2(zmax, rho_min) : f_atan2(zmax, rho_max)) + pad;
+  const float th_lo = (zmin < 0.f ? f_atan2(zmin, rho_min) : f_atan2(zmin, rho_max)) - pad;
   const float fe0 = floorf((th_lo - P.el_lo) * P.el_scale), fe1 = floorf((th_hi - P.el_lo) * P.el_scale);
   if (!(fe1 >= 0.f) || !(fe0 <= (float)(P.nb_el - 1))) return R;  // outside the sensor's elevation range (or NaN)
   R.e0 = (int)fmaxf(fe0, 0.f);
@@ -200,7 +216,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
     R.na = P.nb_az;
     return R;
   }
-  float p0 = atan2f(y0, x0), p1 = atan2f(y1, x1), p2 = atan2f(y2, x2);
+  float p0 = f_atan2(y0, x0), p1 = f_atan2(y1, x1), p2 = f_atan2(y2, x2);
   float lo = fminf(p0, fminf(p1, p2)), hi = fmaxf(p0, fmaxf(p1, p2));
   const float mid = (p0 + p1 + p2) - lo - hi;
   const float g0 = mid - lo, g1 = hi - mid, g2 = 2.0f * LT_PI_F - (hi - lo);
@@ -312,23 +328,40 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
   __syncthreads();
   const int total = pre[256];
   unsigned n_tests = 0, n_cand = 0;
-  for (int c = tid; c < total; c += 256) {
-    // triangle j of this candidate: largest j with pre[j] <= c
+  // every thread takes one contiguous chunk of the candidate list: a single binary search, then it walks
+  // (triangle, row, column) incrementally -- no division, no search per candidate
+  const int per = (total + 255) >> 8;
+  int c = tid * per;
+  const int cend = min(c + per, total);
+  if (c < cend) {
     int j = 0;
 #pragma unroll
     for (int step = 128; step >= 1; step >>= 1)
       if (pre[j + step] <= c) j += step;
-    const int local = c - pre[j];
-    const int na = rna[j];
-    const int row = local / na;
-    int az = ra0[j] + (local - row * na);
-    if (az >= P.nb_az) az -= P.nb_az;
+    int na = rna[j];
+    int row = (c - pre[j]) / na;
+    int col = (c - pre[j]) - row * na;
+    int nxt = pre[j + 1];
     tri_rec T;
     T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
     T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
     T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
-    if (COUNT) ++n_cand;
-    sc_test_bin(T, blockIdx.x * 256 + j, (re0[j] + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+    int a0 = ra0[j], e0 = re0[j];
+    for (; c < cend; ++c) {
+      if (c == nxt) {  // next triangle with candidates
+        do { ++j; nxt = pre[j + 1]; } while (nxt <= c);
+        na = rna[j]; a0 = ra0[j]; e0 = re0[j];
+        row = 0; col = 0;
+        T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
+        T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
+        T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
+      }
+      int az = a0 + col;
+      if (az >= P.nb_az) az -= P.nb_az;
+      if (COUNT) ++n_cand;
+      sc_test_bin(T, blockIdx.x * 256 + j, (e0 + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+      if (++col == na) { col = 0; ++row; }
+    }
   }
   if (COUNT) {
     unsigned long long vt = n_tests, vc = n_cand;
@@ -580,7 +613,7 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
         hipLaunchKernelGGL(k_sc_tris<true>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
                            r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->flags,
                            s->counters);
-        hipLaunchKernelGGL(k_sc_large<true>, dim3(512), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
+        hipLaunchKernelGGL(k_sc_large<true>, dim3(64), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
                            r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
       } else {
         if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
@@ -589,7 +622,7 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
                            s->counters);
         if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
         s->probe[0] = s->probe[1] = nullptr;
-        hipLaunchKernelGGL(k_sc_large<false>, dim3(512), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
+        hipLaunchKernelGGL(k_sc_large<false>, dim3(64), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
                            r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
       }
     }
