@@ -286,8 +286,11 @@ def main():
             alg = c[0] * LB_B_NODE + c[1] * LB_B_TRI + R * LB_B_RAY
             extra = {"kernel": "k_trace4", "nodes_per_ray": round(c[0] / R, 2), "tris_per_ray": round(c[1] / R, 2)}
         ach = alg / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
+        # MI355X_MICROARCH.md HBM section); collected on workload C2 only
+        traffic = {"scatter": 53.8e6, "lbvh": None}[strategy] if args.workload == "C2" else None
         d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_kernel_ms": round(kern_ms, 5),
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
              "algorithmic_bytes_per_launch": int(alg)}
         d.update(extra)
         return d

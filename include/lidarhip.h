@@ -47,17 +47,17 @@ extern "C" {
 typedef struct lt_stats {
   float ms_bounds;     /* scene bounds reduction                                        */
   float ms_morton;     /* centroid Morton codes                                         */
-  float ms_sort;       /* LSD radix sort (4 passes)                                     */
+  float ms_sort;       /* LSD radix sort (3 passes of 10-bit digits)                    */
   float ms_gather;     /* sorted triangle records + padded leaf boxes                   */
   float ms_segtree;    /* min/max segment tree over the leaf boxes                      */
-  float ms_hierarchy;  /* Karras topology + child boxes                                 */
+  float ms_hierarchy;  /* Karras topology into 4-wide nodes + child boxes               */
   float ms_build;      /* whole build, first to last kernel                             */
-  float ms_trace;      /* ray-cast kernel                                               */
+  float ms_trace;      /* ray-cast kernel(s): k_trace4, or the scatter sequence         */
   int n_faces;
   int n_nodes;         /* node slots (n_faces - 1)                                      */
   int n_rays;
   int n_hits;          /* valid after a LT_TRACE_COUNT trace                            */
-  unsigned long long nodes_visited; /* internal nodes fetched, summed over rays         */
+  unsigned long long nodes_visited; /* 4-wide nodes fetched (lbvh) / candidate bins (scatter) */
   unsigned long long tris_tested;   /* Moller-Trumbore evaluations, summed over rays    */
   unsigned long long stack_overflows; /* rays that spilled past the LDS stack           */
 } lt_stats;
