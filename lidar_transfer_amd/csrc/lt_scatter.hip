@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
                                                  unsigned long long* __restrict__ counters) {
   __shared__ float tr[9][256];
   __shared__ int ra0[256], rna[256], re0[256];
+  __shared__ float rinv[256];
   __shared__ int pre[257];
   __shared__ int wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
           tr[3][tid] = v1x - v0x; tr[4][tid] = v1y - v0y; tr[5][tid] = v1z - v0z;
           tr[6][tid] = v2x - v0x; tr[7][tid] = v2y - v0y; tr[8][tid] = v2z - v0z;
           ra0[tid] = R.a0; rna[tid] = R.na; re0[tid] = R.e0;
+          rinv[tid] = 1.0f / (float)R.na;
         }
       }
     } else {
@@ -328,40 +330,26 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
   __syncthreads();
   const int total = pre[256];
   unsigned n_tests = 0, n_cand = 0;
-  // every thread takes one contiguous chunk of the candidate list: a single binary search, then it walks
-  // (triangle, row, column) incrementally -- no division, no search per candidate
-  const int per = (total + 255) >> 8;
-  int c = tid * per;
-  const int cend = min(c + per, total);
-  if (c < cend) {
-    int j = 0;
+  // Candidates are dealt ROUND-ROBIN: in every iteration the 64 lanes of a wave hold 64 consecutive
+  // candidates = consecutive bins of a few neighbouring triangles, so the bin_start look-ups, the direction
+  // loads (directions are stored in bin order) and the atomics of a wave fall into a handful of cache lines.
+  // (A contiguous chunk per thread needs no search but made every lane touch its own lines: L2 bound.)
+  for (int c = tid; c < total; c += 256) {
+    int j = 0;  // triangle of this candidate: largest j with pre[j] <= c
 #pragma unroll
     for (int step = 128; step >= 1; step >>= 1)
       if (pre[j + step] <= c) j += step;
-    int na = rna[j];
-    int row = (c - pre[j]) / na;
-    int col = (c - pre[j]) - row * na;
-    int nxt = pre[j + 1];
+    const int local = c - pre[j];
+    const int na = rna[j];
+    const int row = (int)(((float)local + 0.5f) * rinv[j]);  // local / na, exact for local < 4096
+    int az = ra0[j] + (local - row * na);
+    if (az >= P.nb_az) az -= P.nb_az;
     tri_rec T;
     T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
     T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
     T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
-    int a0 = ra0[j], e0 = re0[j];
-    for (; c < cend; ++c) {
-      if (c == nxt) {  // next triangle with candidates
-        do { ++j; nxt = pre[j + 1]; } while (nxt <= c);
-        na = rna[j]; a0 = ra0[j]; e0 = re0[j];
-        row = 0; col = 0;
-        T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
-        T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
-        T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
-      }
-      int az = a0 + col;
-      if (az >= P.nb_az) az -= P.nb_az;
-      if (COUNT) ++n_cand;
-      sc_test_bin(T, blockIdx.x * 256 + j, (e0 + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
-      if (++col == na) { col = 0; ++row; }
-    }
+    if (COUNT) ++n_cand;
+    sc_test_bin(T, blockIdx.x * 256 + j, (re0[j] + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
   }
   if (COUNT) {
     unsigned long long vt = n_tests, vc = n_cand;
