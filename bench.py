@@ -325,7 +325,7 @@ def main():
             out["lbvh_phase_ms"] = {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"}
         if other:
             out["other_strategy"] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             cb = cpu_baseline(wl, 0, args.cpu_reps or 12)
             out["cpu_baseline"] = cb
             if cb:

@@ -199,6 +199,34 @@ int lt_range_projection(const void* points, int is_f64, const float* rem, const 
                         float* range_img, float* xyz_img, float* rem_img, int* label_img, float* color_img,
                         float* mask_img, float range_init, float rem_init, float xyz_init, int* n_kept);
 
+/* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
+
+/* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new
+ * (auxiliary/laserscan.py:475-501).  range_img [H*W] f32, proj_x / proj_y [H*W] int32 (or float64 when
+ * coords_are_f64: the `preserve_float` branch), back_points [H*W,3] f64 -- all DEVICE pointers. */
+int lt_reverse_projection_dev(const float* range_img, const void* proj_x, const void* proj_y,
+                              int coords_are_f64, double fov_up, double fov_down, int H, int W,
+                              double* back_points, void* stream);
+
+/* Pack a rendered scan in SemanticKITTI layout; replaces the filtering and the per-point struct.pack loops
+ * of MultiSemLaserScan.write (auxiliary/laserscan.py:1133-1178).  Keeps, in order, the cells with
+ * (index == NULL or index[i] > 0) and label[i] >= 0 and x + y + z != 0.  points [n,3] f32 or f64,
+ * rem [n] f32, label [n] i32, out_bin [n,4] f32 (x, y, z, remission), out_label [n] u32 -- DEVICE
+ * pointers; *n_out (HOST) = number of points written (the call synchronises `stream`). */
+int lt_pack_scan_dev(const void* points, int is_f64, const float* rem, const int* label, const int* index, int n,
+                     float* out_bin, unsigned* out_label, int* n_out, void* stream);
+
+/* Masked comparison of a source and a target image; replaces the array part of compare()
+ * (auxiliary/laserscan.py:1181-1301) and iouEval.addBatch (auxiliary/np_ioueval.py:31-47): cells whose
+ * source colour is black or whose source label is 0 are background in both images;
+ * conf[target * n_labels + source] counts raw label pairs (u64, n_labels^2); range_diff / rem_diff are the
+ * squared differences [n] (may be NULL); src_masked / tgt_masked the masked label images (may be NULL);
+ * *sq_sum (DEVICE double) = sum of range_diff (MSE = sq_sum / n).  All DEVICE pointers, asynchronous. */
+int lt_compare_dev(const int* src_label, const float* src_color, const int* tgt_label, const float* src_range,
+                   const float* tgt_range, const float* src_rem, const float* tgt_rem, int n, int n_labels,
+                   unsigned long long* conf, float* range_diff, float* rem_diff, int* src_masked, int* tgt_masked,
+                   double* sq_sum, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 
 /* Message of the last error raised on the calling thread ("" if none). */

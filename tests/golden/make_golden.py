@@ -202,6 +202,67 @@ def main():
             f6[f"{tag}_beam_angles"] = np.array(beam_angles)
     f6["H"], f6["W"], f6["fov_up"], f6["fov_down"] = 16, 128, 3.0, -25.0
     np.savez_compressed(os.path.join(HERE, "f6_range_projection.npz"), **f6)
+    # ---- F7: what follows the render -- reverse projection, write(), compare() -----------------------------
+    import tempfile
+    f7 = {}
+    H, W, fu, fd = 16, 128, 3.0, -25.0
+    pts, rem_p, lab = synth_cloud(11, 4000, dtype=np.float64, fov_up=fu, fov_down=fd)
+    src = ls.SemLaserScan(H, W, 20, color_dict, None, None)
+    src.points, src.remissions, src.label = pts.copy(), rem_p.copy(), lab.copy()
+    src.colorize()
+    src.do_range_projection_new(fu, fd, remove=True)
+    src.do_label_projection_new()
+    for pf in (False, True):
+        src.do_reverse_projection_new(fu, fd, preserve_float=pf)
+        f7[f"back_points_{'float' if pf else 'int'}"] = np.asarray(src.back_points)
+    f7.update(range_image=np.asarray(src.range_image), proj_x=np.asarray(src.proj_x), proj_y=np.asarray(src.proj_y),
+              proj_x_float=np.asarray(src.proj_x_float), proj_y_float=np.asarray(src.proj_y_float),
+              index=np.asarray(src.index), label_image=np.asarray(src.label_image),
+              proj_remissions=np.asarray(src.proj_remissions), H=H, W=W, fov_up=fu, fov_down=fd)
+
+    def run_write(obj, idx):
+        with tempfile.TemporaryDirectory() as d:
+            os.makedirs(os.path.join(d, "velodyne"))
+            os.makedirs(os.path.join(d, "labels"))
+            obj.write(d, idx)
+            return (np.fromfile(os.path.join(d, "velodyne", str(idx).zfill(6) + ".bin"), np.uint8),
+                    np.fromfile(os.path.join(d, "labels", str(idx).zfill(6) + ".label"), np.uint8))
+
+    ms = object.__new__(ls.MultiSemLaserScan)   # 'cp' adaption: write() reads self.merged
+    ms.adaption = "cp"
+    ms.merged = src
+    f7["cp_bin_bytes"], f7["cp_label_bytes"] = run_write(ms, 7)
+    g4 = np.load(os.path.join(HERE, "f4_50k_64x256.npz"))  # mesh adaption: images of a raytraced scan
+    ms2 = object.__new__(ls.MultiSemLaserScan)
+    ms2.adaption = "mesh"
+    ms2.back_points = g4["endpoints"]
+    ms2.label_image = g4["label"].reshape(int(g4["H"]), int(g4["W"]))
+    ms2.proj_remissions = g4["endrem"].reshape(int(g4["H"]), int(g4["W"]))
+    f7["mesh_bin_bytes"], f7["mesh_label_bytes"] = run_write(ms2, 3)
+
+    # compare(): a source scan against a perturbed re-rendering of itself
+    s_old = ls.SemLaserScan(H, W, 20, color_dict, None, None)
+    s_old.points, s_old.remissions, s_old.label = pts.copy(), rem_p.copy(), lab.copy()
+    s_old.colorize()
+    s_old.do_range_projection(fu, fd, remove=True)
+    s_old.do_label_projection()
+    rng2 = np.random.default_rng(5)
+    tgt = types.SimpleNamespace(adaption="mesh")
+    tl = np.array(s_old.proj_label)
+    flip = rng2.uniform(size=tl.shape) < 0.1
+    tl[flip] = rng2.choice(np.array([10, 40, 48, 50, 70, 80]), int(flip.sum()))
+    tgt.label_image = tl
+    tgt.proj_color = s_old.color_lut[tl].astype(np.float64)
+    tgt.proj_range = (np.array(s_old.proj_range) + rng2.normal(0, 0.05, tl.shape)).astype(np.float32)
+    tgt.proj_remissions = np.clip(np.array(s_old.proj_remissions) + rng2.normal(0, 0.05, tl.shape), 0, 1) \
+        .astype(np.float32)
+    f7.update(cmp_source_label=np.array(s_old.proj_label), cmp_source_color=np.array(s_old.proj_color),
+              cmp_source_range=np.array(s_old.proj_range), cmp_source_rem=np.array(s_old.proj_remissions),
+              cmp_target_label=np.array(tgt.label_image), cmp_target_range=np.array(tgt.proj_range),
+              cmp_target_rem=np.array(tgt.proj_remissions))
+    label_diff, range_diff, rem_diff, m_iou, m_acc, mse = ls.compare(s_old, tgt)
+    f7.update(cmp_range_diff=range_diff, cmp_rem_diff=rem_diff, cmp_m_iou=m_iou, cmp_m_acc=m_acc, cmp_mse=mse)
+    np.savez_compressed(os.path.join(HERE, "f7_post.npz"), **f7)
     print("golden vectors written to", HERE)
 
 
