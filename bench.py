@@ -173,6 +173,7 @@ def main():
                      torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.int32, device=dev))
                     for c in range(n_chunks)]
         works = []
+        use_allgather = os.environ.get("LT_BENCH_COLLECTIVE", "gather") == "allgather"
 
         # Host side of one step, kept as thin as a C++ driver would be: three calls into liblidarhip.so with
         # precomputed handles and pointers (mesh pointer swap, probe events, one render / build+trace).
@@ -222,8 +223,13 @@ def main():
             # deform's unpack for the whole chunk: label_image = ray_colors[:, :, 2] (laserscan.py:912)
             label_chunk = color_all[c0:c1, :, 2].contiguous()
             for k, src in enumerate((range_all[c0:c1], label_chunk)):
-                lst = [recv[c][k][r] for r in range(world)] if rank == 0 else None
-                works.append(dist.gather(src, gather_list=lst, dst=0, async_op=True))
+                if use_allgather:  # LT_BENCH_COLLECTIVE=allgather: every rank receives everything (ring-bound)
+                    ag = recv[c][k] if rank == 0 else torch.empty((world,) + tuple(src.shape), dtype=src.dtype,
+                                                                  device=dev)
+                    works.append(dist.all_gather_into_tensor(ag, src.contiguous(), async_op=True))
+                else:
+                    lst = [recv[c][k][r] for r in range(world)] if rank == 0 else None
+                    works.append(dist.gather(src, gather_list=lst, dst=0, async_op=True))
 
         for i in range(Wm):
             step(i)
@@ -232,7 +238,10 @@ def main():
             wbuf = torch.zeros((4, R), dtype=torch.float32, device=dev)
             wl_ = [torch.empty_like(wbuf) for _ in range(world)] if rank == 0 else None
             for _ in range(2):
-                dist.gather(wbuf, gather_list=wl_, dst=0)
+                if use_allgather:
+                    dist.all_gather_into_tensor(torch.empty((world * 4, R), dtype=torch.float32, device=dev), wbuf)
+                else:
+                    dist.gather(wbuf, gather_list=wl_, dst=0)
             torch.cuda.synchronize()
         if dist_on:
             dist.barrier()

@@ -199,6 +199,28 @@ int lt_range_projection(const void* points, int is_f64, const float* rem, const 
                         float* range_img, float* xyz_img, float* rem_img, int* label_img, float* color_img,
                         float* mask_img, float range_init, float rem_init, float xyz_init, int* n_kept);
 
+/* ---- before the render: class-aware TSDF fusion of range images (device-resident volumes) -------- */
+
+typedef struct lt_tsdf lt_tsdf; /* opaque: four float32 volumes [dim_x][dim_y][dim_z] (tsdf, weight, colour, rem) */
+
+#define LT_TSDF_MERGE 1u /* class-aware update, the branch the reference runs (fusion_lidar.py:177, :191-228) */
+
+/* vol_bnds = {xmin, xmax, ymin, ymax, zmin, zmax} (metres), fov in degrees.  Replaces TSDFVolume.__init__
+ * (auxiliary/fusion_lidar.py:23-63): dims = ceil(extent / voxel_size), truncation = 5 voxels,
+ * tsdf = 1, weight = colour = remission = 0. */
+int lt_tsdf_create(lt_tsdf** vol, const double* vol_bnds, double voxel_size, double fov_up, double fov_down,
+                   int device);
+int lt_tsdf_reset(lt_tsdf* vol, void* stream);
+/* Integrate one spherical observation: color_im = labels folded into one float per pixel as
+ * fusion_lidar.py:262-264, depth_im, rem_im -- DEVICE pointers [im_h * im_w] f32.  Replaces the pycuda kernel
+ * `integrate` (fusion_lidar.py:66-229) and its launch loop (:267-287); like that kernel it ignores cam_pose. */
+int lt_tsdf_integrate_dev(lt_tsdf* vol, const float* color_im, const float* depth_im, const float* rem_im,
+                          int im_h, int im_w, float obs_weight, unsigned flags, void* stream);
+/* Device pointers of the volumes (TSDFVolume.get_volume, fusion_lidar.py:395-400, without the copies). */
+int lt_tsdf_volumes(lt_tsdf* vol, int* dims, float* origin, float** tsdf, float** weight, float** color,
+                    float** rem);
+int lt_tsdf_destroy(lt_tsdf* vol);
+
 /* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
 
 /* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new

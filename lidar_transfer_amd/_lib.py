@@ -17,13 +17,15 @@ LT_TRACE_COUNT = 2
 LT_TRACE_NORM_EXACT = 4
 LT_PROJ_REMOVE = 1
 LT_PROJ_NEW = 2
+LT_TSDF_MERGE = 1
 
 #: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
            "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy", "lt_last_error",
            "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection", "lt_rayset_create_dev",
            "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
-           "lt_pack_scan_dev", "lt_compare_dev"]
+           "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
+           "lt_tsdf_volumes", "lt_tsdf_destroy"]
 
 
 class Stats(C.Structure):
@@ -97,6 +99,13 @@ def load():
     lib.lt_pack_scan_dev.restype = C.c_int
     lib.lt_compare_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.lt_compare_dev.restype = C.c_int
+    lib.lt_tsdf_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_int]
+    lib.lt_tsdf_reset.argtypes = [vp, vp]
+    lib.lt_tsdf_integrate_dev.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint, vp]
+    lib.lt_tsdf_volumes.argtypes = [vp, ip, fp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.lt_tsdf_destroy.argtypes = [vp]
+    for name in ("lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev", "lt_tsdf_volumes", "lt_tsdf_destroy"):
+        getattr(lib, name).restype = C.c_int
     lib.lt_scene_set_probe.argtypes = [vp, vp, vp]
     lib.lt_scene_set_probe.restype = C.c_int
     lib.lt_create_rays_dev.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]

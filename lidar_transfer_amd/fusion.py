@@ -71,3 +71,98 @@ class MeshVolume:
         return self._mesh
 
     throw_rays_at_mesh = throw_rays_at_mesh
+
+
+class TSDFVolume:
+    """Device-resident mirror of the reference's ``TSDFVolume`` fusion part
+    (auxiliary/fusion_lidar.py:21-63 constructor, :252-287 ``integrate``, :395-400 ``get_volume``).
+
+    Same constructor and ``integrate`` signature; the four volumes live in HBM (``lt_tsdf``) and every
+    ``integrate`` is one launch of the HIP kernel -- no per-launch image round trip, no grid loop.
+    ``merge=True`` (default) is the class-aware branch the reference runs.  Marching cubes (``get_mesh``) is
+    consumed unchanged from the reference / skimage and is out of scope here.
+    """
+
+    def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, device=None, merge=True):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        self._lib = _lib.load()
+        self._C, self._torch, self._libmod = C, torch, _lib
+        self.fov_up, self.fov_down = fov_up, fov_down
+        self.merge = merge
+        self._vol_bnds = np.array(vol_bnds, dtype=np.float64).reshape(3, 2)
+        self._voxel_size = float(voxel_size)
+        self._trunc_margin = self._voxel_size * 5
+        self._vol_dim = np.ceil((self._vol_bnds[:, 1] - self._vol_bnds[:, 0]) / self._voxel_size).astype(int)
+        bnds_in = self._vol_bnds.copy()  # the library derives the dimensions from the bounds as given (:33-34)
+        self._vol_bnds[:, 1] = self._vol_bnds[:, 0] + self._vol_dim * self._voxel_size
+        self._vol_origin = self._vol_bnds[:, 0].copy().astype(np.float32)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        bnds = (C.c_double * 6)(*bnds_in.reshape(-1))
+        h = C.c_void_p()
+        _lib.check(self._lib.lt_tsdf_create(C.byref(h), bnds, self._voxel_size, float(fov_up), float(fov_down),
+                                            self.device.index), "lt_tsdf_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_tsdf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def integrate(self, color_im, depth_im, rem_im, cam_pose=None, obs_weight=1.):
+        """``color_im [H,W,3]`` (label image, three channels), ``depth_im``, ``rem_im`` ``[H,W]``; numpy or CUDA
+        tensors.  ``cam_pose`` is accepted and ignored, as by the reference kernel (fusion_lidar.py:253-256)."""
+        torch, C = self._torch, self._C
+
+        def dev(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(self.device, torch.float32).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+        c = dev(color_im)
+        # Fold RGB color image into a single channel image (fusion_lidar.py:261-264), float32 like the reference
+        folded = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()
+        d, r = dev(depth_im), dev(rem_im)
+        st = torch.cuda.current_stream(self.device)
+        self._libmod.check(self._lib.lt_tsdf_integrate_dev(self._h, folded.data_ptr(), d.data_ptr(), r.data_ptr(),
+                                                           d.shape[0], d.shape[1], float(obs_weight),
+                                                           self._libmod.LT_TSDF_MERGE if self.merge else 0,
+                                                           C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_dev")
+        st.synchronize()  # the temporaries above must outlive the kernel
+
+    def get_volume(self):
+        """``(tsdf, color, rem)`` as float32 numpy arrays ``[dx,dy,dz]`` (fusion_lidar.py:395-400)."""
+        t, w, c, r = self.get_volume_tensors()
+        return t.cpu().numpy(), c.cpu().numpy(), r.cpu().numpy()
+
+    def get_volume_tensors(self):
+        """Zero-copy ``torch`` views of the four device volumes (tsdf, weight, color, rem)."""
+        torch, C = self._torch, self._C
+        dims = (C.c_int * 3)()
+        org = (C.c_float * 3)()
+        ptrs = [C.c_void_p() for _ in range(4)]
+        self._libmod.check(self._lib.lt_tsdf_volumes(self._h, dims, org, *[C.byref(p) for p in ptrs]),
+                           "lt_tsdf_volumes")
+        n = int(dims[0]) * int(dims[1]) * int(dims[2])
+        out = []
+        for p in ptrs:
+            out.append(_wrap_device_pointer(torch, p.value, n, self.device).view(int(dims[0]), int(dims[1]), int(dims[2])))
+        return out
+
+
+def _wrap_device_pointer(torch, ptr, n, device):
+    """torch tensor over a raw device pointer (no copy, no ownership) via the CUDA array interface."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(h, device=device)

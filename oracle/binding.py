@@ -54,6 +54,9 @@ def _lib():
         lib.lto_normalize_rays.argtypes = [fp, C.c_int, C.c_int, fp]
         lib.lto_normalize_rays.restype = None
         lib.lto_num_threads.restype = C.c_int
+        lib.lto_tsdf_integrate.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, C.c_float, C.c_int, C.c_int,
+                                           C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.c_int]
+        lib.lto_tsdf_integrate.restype = None
         _oracle = lib
     return _oracle
 
@@ -148,3 +151,19 @@ def normalize_rays(rays, norm=NORM_EXACT):
 
 def num_threads() -> int:
     return int(_lib().lto_num_threads())
+
+
+def tsdf_integrate(vols, dims, origin, voxel_size, fov_up, fov_down, color_im, depth_im, rem_im, obs_weight=1.0,
+                   merge=True):
+    """In-place update of ``vols = (tsdf, weight, color, rem)`` (float32 [dx,dy,dz] C-order) by the C
+    restatement of the reference's CUDA kernel (fusion_lidar.py:66-229)."""
+    lib = _lib()
+    fp = C.POINTER(C.c_float)
+    for v in vols:
+        assert v.dtype == np.float32 and v.flags["C_CONTIGUOUS"]
+    H, W = depth_im.shape
+    ims = [np.ascontiguousarray(x, dtype=np.float32) for x in (color_im, depth_im, rem_im)]
+    org = np.ascontiguousarray(origin, dtype=np.float32)
+    lib.lto_tsdf_integrate(*[v.ctypes.data_as(fp) for v in vols], int(dims[0]), int(dims[1]), int(dims[2]),
+                           org.ctypes.data_as(fp), float(voxel_size), int(H), int(W), float(voxel_size * 5), float(obs_weight), float(fov_up), float(fov_down),
+                           *[x.ctypes.data_as(fp) for x in ims], int(bool(merge)))

@@ -263,6 +263,28 @@ def main():
     label_diff, range_diff, rem_diff, m_iou, m_acc, mse = ls.compare(s_old, tgt)
     f7.update(cmp_range_diff=range_diff, cmp_rem_diff=rem_diff, cmp_m_iou=m_iou, cmp_m_acc=m_acc, cmp_mse=mse)
     np.savez_compressed(os.path.join(HERE, "f7_post.npz"), **f7)
+
+    # ---- F8: TSDF integrate, the reference's numpy CPU mode (fusion_lidar.py:289-392; = the `merge == false`
+    # branch of the CUDA kernel without remissions).  The CUDA kernel itself cannot be run here. ---------------
+    Ht, Wt, fut, fdt = 32, 256, 3.0, -25.0
+    ptsT, remT, labT = synth_cloud(21, 30000, dtype=np.float64, rmin=3.0, rmax=14.0, fov_up=fut, fov_down=fdt)
+    sc = ls.SemLaserScan(Ht, Wt, 300, color_dict, None, None)
+    sc.points, sc.remissions, sc.label = ptsT.copy(), remT.copy(), labT.copy()
+    sc.colorize()
+    sc.do_range_projection(fut, fdt, remove=True)
+    sc.do_label_projection()
+    label3 = np.stack([np.zeros_like(sc.proj_label), np.zeros_like(sc.proj_label), sc.proj_label], 2).astype(np.float32)
+    depth_im = np.where(sc.proj_range > 0, sc.proj_range, 0).astype(np.float32)
+    rem_im = np.where(sc.proj_remissions > 0, sc.proj_remissions, 0).astype(np.float32)
+    bnds = np.array([[-16.0, 16.0], [-16.0, 16.0], [-4.0, 4.0]])
+    fl.FUSION_GPU_MODE = 0
+    vol = fl.TSDFVolume(bnds.copy(), 0.25, fut, fdt)
+    for _ in range(2):
+        vol.integrate(label3, depth_im, rem_im, np.eye(4), obs_weight=1.)
+    tsdf, col, _ = vol.get_volume()
+    np.savez_compressed(os.path.join(HERE, "f8_tsdf_cpu_mode.npz"), bnds=bnds, voxel=0.25, fov_up=fut, fov_down=fdt,
+                        label3=label3, depth_im=depth_im, rem_im=rem_im, tsdf=tsdf, weight=vol._weight_vol_cpu,
+                        color=col)
     print("golden vectors written to", HERE)
 
 
