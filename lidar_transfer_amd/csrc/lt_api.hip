@@ -1,6 +1,7 @@
 // lt_api.hip -- C-ABI entry points of liblidarhip.so (declared in include/lidarhip.h).
 #include "lt_internal.h"
 #include <mutex>
+#include <vector>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -262,6 +263,12 @@ static lt_scene* g_scene = nullptr;
 static int g_scene_dev = -1;
 static void* g_io = nullptr;
 static size_t g_io_bytes = 0;
+// ray set of the previous call: a sensor model's rays are the same for every scan of a sequence, so the
+// binned ray set is rebuilt only when the caller's rays (compared on the host) actually change
+static lt_rayset* g_rs = nullptr;
+static std::vector<float> g_rs_rays;
+static int g_rs_height = 0;
+static unsigned g_rs_norm = 0;
 
 extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
                             const int* colors, const float* rem, int n_rays, int n_verts, int n_faces,
@@ -278,6 +285,8 @@ extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float*
   if (g_scene && g_scene_dev != dev) {
     lt_scene_destroy(g_scene);
     g_scene = nullptr;
+    if (g_rs) (void)lt_rayset_destroy(g_rs);
+    g_rs = nullptr;
     if (g_io) (void)hipFree(g_io);
     g_io = nullptr;
     g_io_bytes = 0;
@@ -336,13 +345,19 @@ extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float*
                              tri ? d_tri : nullptr, (stats ? LT_TRACE_COUNT : 0u) | norm_flag, stream,
                              stats ? &st : nullptr));
   } else {
-    lt_rayset* rs = nullptr;
-    LT_CHECK(lt_rayset_create_dev(&rs, d_rays, (int)R, height, norm_flag, stream));
-    const int rc = lt_scene_render_dev(s, rs, origin, endpoints ? d_end : nullptr, endcolors ? d_col : nullptr,
-                                       range ? d_range : nullptr, endrem ? d_rem : nullptr, tri ? d_tri : nullptr,
-                                       (stats ? LT_TRACE_COUNT : 0u), stream, stats ? &st : nullptr);
-    (void)lt_rayset_destroy(rs);  // synchronises
-    LT_CHECK(rc);
+    const bool same = g_rs && g_rs_height == height && g_rs_norm == norm_flag && g_rs_rays.size() == R * 3 &&
+                      (R == 0 || memcmp(g_rs_rays.data(), rays, R * 12) == 0);
+    if (!same) {
+      if (g_rs) (void)lt_rayset_destroy(g_rs);
+      g_rs = nullptr;
+      LT_CHECK(lt_rayset_create_dev(&g_rs, d_rays, (int)R, height, norm_flag, stream));
+      g_rs_rays.assign(rays, rays + R * 3);
+      g_rs_height = height;
+      g_rs_norm = norm_flag;
+    }
+    LT_CHECK(lt_scene_render_dev(s, g_rs, origin, endpoints ? d_end : nullptr, endcolors ? d_col : nullptr,
+                                 range ? d_range : nullptr, endrem ? d_rem : nullptr, tri ? d_tri : nullptr,
+                                 (stats ? LT_TRACE_COUNT : 0u), stream, stats ? &st : nullptr));
   }
   if (R > 0) {
     if (endpoints) LT_HIP(hipMemcpyAsync(endpoints, d_end, R * 12, hipMemcpyDeviceToHost, stream));

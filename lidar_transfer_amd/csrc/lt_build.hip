@@ -435,46 +435,6 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint32_t* __restrict__ 
   N[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
 }
 
-// ---- 4-wide collapse: node i = children of its internal children (leaves stay) -----------------------------
-// Every live binary node gets a 128-B wide twin with the same index: 4 x { (mn.xyz, mx.x), (mx.yz, ref, -) }.
-// A quad of lanes reads it as one contiguous cache line, one child per lane (lt_trace.hip, k_trace4).
-__global__ __launch_bounds__(256) void k_collapse4(const float4* __restrict__ nodes, int n_nodes,
-                                                   float4* __restrict__ nodes4) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_nodes) return;
-  const float4* N = nodes + 4 * (size_t)i;
-  const float4 q3 = N[3];
-  const int c[2] = {__float_as_int(q3.x), __float_as_int(q3.y)};
-  if (c[0] == 0x7fffffff) return;  // dead slot
-  const float4 q0 = N[0], q1 = N[1], q2 = N[2];
-  const float inf = INFINITY;
-  const float4 e_lo = make_float4(inf, inf, inf, inf);                        // mn = mx = +inf: never hit
-  const float4 e_hi = make_float4(inf, inf, __int_as_float(0x7fffffff), 0.f);
-  const bool in0 = c[0] >= 0, in1 = c[1] >= 0;
-  // entries contributed by child 0 (A0, A1) and child 1 (B0, B1); the second one exists only for internal children
-  float4 a0l = make_float4(q0.x, q0.y, q0.z, q0.w), a0h = make_float4(q1.x, q1.y, __int_as_float(c[0]), 0.f);
-  float4 a1l = e_lo, a1h = e_hi;
-  float4 b0l = make_float4(q1.z, q1.w, q2.x, q2.y), b0h = make_float4(q2.z, q2.w, __int_as_float(c[1]), 0.f);
-  float4 b1l = e_lo, b1h = e_hi;
-  if (in0) {
-    const float4* M = nodes + 4 * (size_t)c[0];
-    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-    a0l = make_float4(m0.x, m0.y, m0.z, m0.w); a0h = make_float4(m1.x, m1.y, m3.x, 0.f);
-    a1l = make_float4(m1.z, m1.w, m2.x, m2.y); a1h = make_float4(m2.z, m2.w, m3.y, 0.f);
-  }
-  if (in1) {
-    const float4* M = nodes + 4 * (size_t)c[1];
-    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-    b0l = make_float4(m0.x, m0.y, m0.z, m0.w); b0h = make_float4(m1.x, m1.y, m3.x, 0.f);
-    b1l = make_float4(m1.z, m1.w, m2.x, m2.y); b1h = make_float4(m2.z, m2.w, m3.y, 0.f);
-  }
-  float4* O = nodes4 + 8 * (size_t)i;
-  O[0] = a0l; O[1] = a0h;
-  O[2] = in0 ? a1l : b0l; O[3] = in0 ? a1h : b0h;
-  O[4] = in0 ? b0l : b1l; O[5] = in0 ? b0h : b1h;   // (!in0): B1 is the empty entry unless child 1 is internal
-  O[6] = in0 ? b1l : e_lo; O[7] = in0 ? b1h : e_hi;
-}
-
 // ---- Karras topology straight into 4-wide nodes (default path) -------------------------------------------
 // Node i finds its own key range and split as k_hierarchy does; because the ranges of its two children
 // are then known, their splits need no range search -- one binary search each -- and the up to four

@@ -27,7 +27,6 @@
 
 #define LT_PI_F 3.14159265358979f
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
-#define LT_SC_SMALL 48   // candidate bins handled inline by the triangle's own thread
 
 __device__ __forceinline__ float sc_rsqrt_sse(float x) {  // see lt_trace.hip:rsqrt_sse
   const unsigned b = __float_as_uint(x);

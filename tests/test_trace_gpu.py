@@ -345,3 +345,37 @@ def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):
     assert np.allclose(np.linalg.norm(d, axis=1), a["range"][ok], rtol=2e-6)
     assert np.all(np.abs(a["endpoints"][ok]) <= np.abs(v).max() + 1e-3)
     assert np.all(a["range"][~ok] == 0) and np.all(a["endcolors"][~ok] == 0)
+
+
+def test_binary_one_ray_per_lane_path_in_subprocess(tmp_path):
+    """LIDARHIP_TRACE=binary (binary nodes, one ray per lane: the A/B twin of the quad traversal) is selected
+    once per process, so it is exercised in a child process: same images as the default path."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.raytracer import Scene
+from lidar_transfer_amd.synth import synth_scene
+dev = torch.device("cuda", 0)
+v, f, c, r = synth_scene(6, 40000)
+rays = create_rays(3, -25, 32, 256)
+sc = Scene(0)
+sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
+sc.build()
+o = sc.trace(torch.from_numpy(rays).to(dev), (0.0, 0.0, 0.0), 32, count=True)
+np.savez(sys.argv[1], tri=o["tri"].cpu().numpy(), range=o["range"].cpu().numpy(), nodes=o["stats"]["nodes_visited"])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("binary", "quad"):
+        env = dict(os.environ)
+        env.pop("LIDARHIP_TRACE", None)
+        if mode == "binary":
+            env["LIDARHIP_TRACE"] = "binary"
+        p = str(tmp_path / f"{mode}.npz")
+        subprocess.run([sys.executable, "-c", code, p], check=True, env=env, timeout=300)
+        outs[mode] = np.load(p)
+    assert np.array_equal(outs["binary"]["tri"], outs["quad"]["tri"])
+    _assert_bits(outs["binary"]["range"], outs["quad"]["range"], "range")
+    assert int(outs["binary"]["nodes"]) > int(outs["quad"]["nodes"]) > 0   # binary visits ~2x as many (thinner) nodes
