@@ -297,7 +297,8 @@ def main():
         ach = alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section); collected on workload C2 only
-        traffic = {"scatter": 53.8e6, "lbvh": None}[strategy] if args.workload == "C2" else None
+        # (profiles/r01/b_pmc_scatter.txt: k_sc_tris; profiles/r01/b_pmc_lbvh.txt: k_trace4)
+        traffic = {"scatter": 53.8e6, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
         d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
              "algorithmic_bytes_per_launch": int(alg)}
