@@ -12,11 +12,13 @@
 //
 //   rayset (built once per sensor model, reused across scans):
 //     k_rs_dirs    normalise (Vector3.h:73-89), azimuth/elevation, elevation range partials
+//     k_rs_fit     fit the azimuth grid (W or W - 1 columns) to the rays
 //     k_rs_keys    bin id per ray  ->  radix sort (k_hist/k_scan/k_scatter of lt_build.hip)
 //     k_rs_starts  first sorted slot of every bin
+//     k_rs_sortdirs / k_rs_grid  directions in bin order; one 16-B entry per bin (its ray, empty, or a slot range)
 //   per scan:
 //     k_sc_tris    one thread per triangle: bounds, candidate bins, MT, atomicMin; big triangles -> queue
-//     k_sc_large   one wave per queued triangle, lanes stride over its candidate rays
+//     k_sc_rest    queued slices of heavy workgroups; one wave per queued big triangle
 //     k_sc_resolve one thread per ray: unpack (t, face), write-back (RayTracer.cpp:73-90), reset the cell
 #include "lt_internal.h"
 #include <math.h>
@@ -26,6 +28,7 @@
 #include "lt_rsqrt_sse_table.h"
 
 #define LT_PI_F 3.14159265358979f
+#define LT_BIN_SLACK 4e-3f  // bins; float rounding of a grid coordinate is < 8192 * 2^-22
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
 __device__ __forceinline__ float sc_rsqrt_sse(float x) {  // see lt_trace.hip:rsqrt_sse
@@ -38,11 +41,31 @@ __device__ __forceinline__ float sc_rsqrt_sse(float x) {  // see lt_trace.hip:rs
   return __uint_as_float(LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((unsigned)k << 23));
 }
 
-struct rs_params {     // bin grid of a rayset
+// Bin grid of a rayset.  A ray with azimuth phi and elevation th has the continuous grid coordinates
+//   x = (phi + pi) * az_scale - az_off   (nb_az columns, periodic),   y = (th - el_lo) * el_scale   (nb_el rows)
+// and lives in the bin (round(x) mod nb_az, clamp(round(y))): the grid is laid out so that the rays of a
+// regular sensor model sit at the bin CENTRES (integer x, y).  dev_az / dev_el = the largest distance of any
+// ray from the centre of its bin, measured when the rayset is built.  A triangle whose padded angular bounds
+// are [x_lo, x_hi] can only be hit by rays of the columns ceil(x_lo - dev) .. floor(x_hi + dev): for a sensor
+// grid (dev ~ 1e-3) that is "the rays inside the bounds" -- none at all for most sub-pixel triangles --
+// instead of "every bin the bounds touch"; for an irregular ray set (dev ~ 0.5) it degrades to the latter.
+// The azimuth grid is fitted to the rays (k_rs_fit): W columns over [-pi, pi) or W - 1 columns when the model
+// spans [-pi, pi] inclusively (the reference's create_rays, laserscan.py, does: first and last column
+// coincide), with the phase of ray 0.
+struct rs_params {
   int nb_az, nb_el;
-  float az_scale;      // nb_az / 2pi
+  float az_scale;        // nb_az / 2pi
+  float az_off;          // phase: ray 0 sits at an integer x
   float el_lo, el_scale;
+  float dev_az, dev_el;  // written with atomicMax on the float bits (non-negative)
+  float dev_fit[2];      // k_rs_fit: dev_az the grid would have with W / W - 1 columns
 };
+
+__device__ __forceinline__ float rs_az_off(float phi0, float az_scale) {
+  if (!(phi0 == phi0)) return 0.f;
+  const float x0 = (phi0 + LT_PI_F) * az_scale;
+  return x0 - floorf(x0 + 0.5f);
+}
 
 // ---- rayset -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rs_dirs(const float* __restrict__ rays, int n, unsigned flags,
@@ -74,6 +97,34 @@ __global__ __launch_bounds__(256) void k_rs_dirs(const float* __restrict__ rays,
   }
 }
 
+// distance of the rays from the column centres for the two candidate azimuth grids
+__global__ __launch_bounds__(256) void k_rs_fit(const float2* __restrict__ ang, int n, int nb_az0,
+                                                rs_params* __restrict__ prm) {
+  const float phi0 = n > 0 ? ang[0].x : 0.f;
+  float dev[2] = {0.f, 0.f};
+  for (int k = 0; k < 2; ++k) {
+    const int K = nb_az0 - k;
+    if (K < 1) continue;
+    const float sc = (float)K / (2.0f * LT_PI_F), off = rs_az_off(phi0, sc);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+      const float phi = ang[i].x;
+      if (phi == phi) {
+        const float x = (phi + LT_PI_F) * sc - off;
+        dev[k] = fmaxf(dev[k], fabsf(x - floorf(x + 0.5f)));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dev[0] = fmaxf(dev[0], __shfl_xor(dev[0], o, 64));
+    dev[1] = fmaxf(dev[1], __shfl_xor(dev[1], o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax((int*)&prm->dev_fit[0], __float_as_int(dev[0]));
+    atomicMax((int*)&prm->dev_fit[1], __float_as_int(dev[1]));
+  }
+}
+
 // reduce the elevation partials (every workgroup redoes it: 2 KB), publish the grid, bin id per ray
 __global__ __launch_bounds__(256) void k_rs_keys(const float2* __restrict__ ang, int n, int nb_az, int nb_el,
                                                  const float* __restrict__ partial, rs_params* __restrict__ prm,
@@ -90,26 +141,48 @@ __global__ __launch_bounds__(256) void k_rs_keys(const float2* __restrict__ ang,
   lo = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
   hi = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
   if (!(lo <= hi)) { lo = 0.f; hi = 0.f; }
-  lo -= 1e-5f;
-  hi += 1e-5f;
+  // W - 1 columns when that grid clearly fits the rays better (inclusive [-pi, pi] models)
+  const int nb_max = nb_az;
+  if (nb_az >= 5 && prm->dev_fit[1] + 0.01f < prm->dev_fit[0]) nb_az -= 1;
   rs_params p;
   p.nb_az = nb_az; p.nb_el = nb_el;
   p.az_scale = (float)nb_az / (2.0f * LT_PI_F);
+  p.az_off = rs_az_off(n > 0 ? ang[0].x : 0.f, p.az_scale);
   p.el_lo = lo;
-  p.el_scale = (float)nb_el / (hi - lo);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *prm = p;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float2 a = ang[i];
-  uint32_t key = (uint32_t)nb_az * (uint32_t)nb_el;  // NaN directions: one extra bin that no triangle visits
-  if (a.x == a.x && a.y == a.y) {
-    int ia = (int)floorf((a.x + LT_PI_F) * p.az_scale), ie = (int)floorf((a.y - p.el_lo) * p.el_scale);
-    ia = min(max(ia, 0), nb_az - 1);
-    ie = min(max(ie, 0), nb_el - 1);
-    key = (uint32_t)ie * (uint32_t)nb_az + (uint32_t)ia;
+  p.el_scale = (nb_el > 1 && hi > lo) ? (float)(nb_el - 1) / (hi - lo) : 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // dev_az / dev_el were zeroed by the host before this launch
+    prm->nb_az = p.nb_az; prm->nb_el = p.nb_el;
+    prm->az_scale = p.az_scale; prm->az_off = p.az_off; prm->el_lo = p.el_lo; prm->el_scale = p.el_scale;
   }
-  keys[i] = key;
-  vals[i] = (uint32_t)i;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float dev_a = 0.f, dev_e = 0.f;
+  if (i < n) {
+    const float2 a = ang[i];
+    uint32_t key = (uint32_t)nb_max * (uint32_t)nb_el;  // NaN directions: one extra bin that no triangle visits
+    if (a.x == a.x && a.y == a.y) {
+      const float x = (a.x + LT_PI_F) * p.az_scale - p.az_off, y = (a.y - p.el_lo) * p.el_scale;
+      const float cx = floorf(x + 0.5f);
+      const float cy = fminf(fmaxf(floorf(y + 0.5f), 0.f), (float)(nb_el - 1));
+      dev_a = fabsf(x - cx);
+      dev_e = fabsf(y - cy);
+      int ia = (int)cx;  // x in [-1, nb_az + 1): the columns are periodic
+      if (ia < 0) ia += nb_az;
+      else if (ia >= nb_az) ia -= nb_az;
+      ia = min(max(ia, 0), nb_az - 1);
+      key = (uint32_t)cy * (uint32_t)nb_az + (uint32_t)ia;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dev_a = fmaxf(dev_a, __shfl_xor(dev_a, o, 64));
+    dev_e = fmaxf(dev_e, __shfl_xor(dev_e, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax((int*)&prm->dev_az, __float_as_int(dev_a));
+    atomicMax((int*)&prm->dev_el, __float_as_int(dev_e));
+  }
 }
 
 // bin_start[b] = first sorted slot whose key >= b, for b in [0, nbins]; keys are sorted
@@ -151,6 +224,7 @@ __device__ __forceinline__ float sc_mt(const tri_rec& T, float ox, float oy, flo
 __device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float f_atan2(float y, float x) {
+#pragma clang fp contract(fast)
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
   const float a = mx > 0.f ? mn * f_rcp(mx) : 0.f;
@@ -161,24 +235,29 @@ __device__ __forceinline__ float f_atan2(float y, float x) {
   return y < 0.f ? -r : r;
 }
 
-__device__ __forceinline__ float seg_dist2d(float ax, float ay, float bx, float by) {  // |(0,0) - segment ab|
+__device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, float by) {  // |(0,0) - segment ab|^2
+#pragma clang fp contract(fast)
   const float ex = bx - ax, ey = by - ay;
   const float l2 = ex * ex + ey * ey;
   float t = l2 > 0.f ? -(ax * ex + ay * ey) * f_rcp(l2) : 0.f;
   t = fminf(fmaxf(t, 0.f), 1.f);
   const float cx = ax + t * ex, cy = ay + t * ey;
-  return f_sqrt(cx * cx + cy * cy);
+  return cx * cx + cy * cy;
 }
 
 struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mod nb_az); elevation rows e0..e1
 
-// conservative angular bounds of a triangle seen from the origin -> bin rectangle (na == 0: nothing to do)
+// conservative angular bounds of a triangle seen from the origin -> bin rectangle (na == 0: nothing to do).
+// Everything in here is approximate-but-padded, so contraction to FMA is allowed (unlike the triangle test)
+// and minima / maxima are taken on squared lengths (4 square roots per triangle instead of 15).
 __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float y0, float z0, float x1, float y1,
                                              float z1, float x2, float y2, float z2) {
+#pragma clang fp contract(fast)
   bin_rect R;
   R.na = 0; R.a0 = 0; R.e0 = 0; R.e1 = -1;
-  const float r0 = f_sqrt(x0 * x0 + y0 * y0), r1 = f_sqrt(x1 * x1 + y1 * y1), r2 = f_sqrt(x2 * x2 + y2 * y2);
-  const float rho_max = fmaxf(r0, fmaxf(r1, r2));
+  const float q0 = x0 * x0 + y0 * y0, q1 = x1 * x1 + y1 * y1, q2 = x2 * x2 + y2 * y2;
+  const float rho_max2 = fmaxf(q0, fmaxf(q1, q2));
+  const float rho_max = f_sqrt(rho_max2);
   const float zmin = fminf(z0, fminf(z1, z2)), zmax = fmaxf(z0, fmaxf(z1, z2));
   // Where is the vertical axis through the origin relative to the triangle's xy-projection?
   //   mixed signs of the three sub-areas  -> strictly outside: the azimuth extent is an arc < pi
@@ -186,70 +265,98 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   //                                          itself reaches the axis (rho_min ~ 0)
   //   otherwise                           -> the axis pierces the triangle: every azimuth
   const float c0 = x0 * y1 - x1 * y0, c1 = x1 * y2 - x2 * y1, c2 = x2 * y0 - x0 * y2;
-  const float tol = 1e-6f * (rho_max * rho_max) + 1e-12f;
+  const float tol = 1e-6f * rho_max2 + 1e-12f;
   const float cmin = fminf(c0, fminf(c1, c2)), cmax = fmaxf(c0, fmaxf(c1, c2));
   const bool outside = cmin < -tol && cmax > tol;
   const bool edge_on = cmin >= -tol && cmax <= tol;
-  const float rho_edges =
-      fminf(seg_dist2d(x0, y0, x1, y1), fminf(seg_dist2d(x1, y1, x2, y2), seg_dist2d(x2, y2, x0, y0)));
-  const bool pierced = !(outside || (edge_on && rho_edges > 1e-4f * rho_max + 1e-6f));
+  const float rho_edges2 =
+      fminf(seg_dist2d_sq(x0, y0, x1, y1), fminf(seg_dist2d_sq(x1, y1, x2, y2), seg_dist2d_sq(x2, y2, x0, y0)));
+  const float rho_edges = f_sqrt(rho_edges2);
+  const float rho_tiny = 1e-4f * rho_max + 1e-6f;
+  const bool pierced = !(outside || (edge_on && rho_edges > rho_tiny));
   const float rho_min = pierced ? 0.f : rho_edges;
   // angular padding: float rounding of atan2 and of the ray bins, plus the positional slop (<= ~1e-4 m) with
-  // which the float Moller-Trumbore test may accept a ray that passes just outside the triangle
-  const float d0 = f_sqrt(r0 * r0 + z0 * z0), d1 = f_sqrt(r1 * r1 + z1 * z1), d2 = f_sqrt(r2 * r2 + z2 * z2);
-  const float e01 = f_sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
-  const float e12 = f_sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1));
-  const float e20 = f_sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2) + (z0 - z2) * (z0 - z2));
-  const float dlo = fmaxf(fminf(d0, fminf(d1, d2)) - fmaxf(e01, fmaxf(e12, e20)), 0.05f);
-  const float pad = 3e-4f + 2e-4f * f_rcp(dlo);
+  // which the float Moller-Trumbore test may accept a ray that passes just outside the triangle, seen from the
+  // closest the triangle can be: every point of it has rho >= rho_min and |z| >= z_near
+  const float z_near = zmin > 0.f ? zmin : (zmax < 0.f ? zmax : 0.f);
+  const float dlo2 = fmaxf((pierced ? 0.f : rho_edges2) + z_near * z_near, 0.0025f);
+  const float pad = 3e-4f + 2e-4f * __builtin_amdgcn_rsqf(dlo2);
   // elevation: z / rho over the triangle
-  const float th_hi = (zmax > 0.f ? f_atan2(zmax, rho_min) : f_atan2(zmax, rho_max)) + pad;
-  const float th_lo = (zmin < 0.f ? f_atan2(zmin, rho_min) : f_atan2(zmin, rho_max)) - pad;
-  const float fe0 = floorf((th_lo - P.el_lo) * P.el_scale), fe1 = floorf((th_hi - P.el_lo) * P.el_scale);
-  if (!(fe1 >= 0.f) || !(fe0 <= (float)(P.nb_el - 1))) return R;  // outside the sensor's elevation range (or NaN)
+  const float th_hi = f_atan2(zmax, zmax > 0.f ? rho_min : rho_max) + pad;
+  const float th_lo = f_atan2(zmin, zmin < 0.f ? rho_min : rho_max) - pad;
+  // rows whose rays can lie inside [th_lo, th_hi]; LT_BIN_SLACK covers the float rounding of the coordinates
+  const float de = P.dev_el + LT_BIN_SLACK, da = P.dev_az + LT_BIN_SLACK;
+  const float fe0 = ceilf((th_lo - P.el_lo) * P.el_scale - de), fe1 = floorf((th_hi - P.el_lo) * P.el_scale + de);
+  if (!(fe1 >= 0.f) || !(fe0 <= (float)(P.nb_el - 1)) || !(fe0 <= fe1)) return R;  // no row (or NaN)
   R.e0 = (int)fmaxf(fe0, 0.f);
   R.e1 = (int)fminf(fe1, (float)(P.nb_el - 1));
   // azimuth: full circle when pierced, else the shortest arc holding the three vertex azimuths
-  if (pierced || rho_min <= 1e-4f * rho_max + 1e-6f) {
+  if (pierced || rho_min <= rho_tiny || P.nb_az < 4) {
     R.a0 = 0;
     R.na = P.nb_az;
     return R;
   }
-  float p0 = f_atan2(y0, x0), p1 = f_atan2(y1, x1), p2 = f_atan2(y2, x2);
-  float lo = fminf(p0, fminf(p1, p2)), hi = fmaxf(p0, fmaxf(p1, p2));
-  const float mid = (p0 + p1 + p2) - lo - hi;
-  const float g0 = mid - lo, g1 = hi - mid, g2 = 2.0f * LT_PI_F - (hi - lo);
   float a_lo, a_hi;  // arc [a_lo, a_hi], a_hi may exceed pi (wraps)
-  if (g2 >= g0 && g2 >= g1) { a_lo = lo; a_hi = hi; }
-  else if (g0 >= g1) { a_lo = mid; a_hi = lo + 2.0f * LT_PI_F; }
-  else { a_lo = hi; a_hi = mid + 2.0f * LT_PI_F; }
+  if (!edge_on) {
+    // strictly outside: the sub-areas have mixed signs and name the extreme vertices without sorting angles
+    // -- lo is the vertex both others are counter-clockwise of, hi the one both are clockwise of (a sign that
+    // rounding could flip belongs to two vertices within ~1e-6 rad of each other: far below the padding)
+    const bool l0 = c0 >= 0.f && c2 <= 0.f, l1 = c1 >= 0.f && c0 <= 0.f;
+    const bool h0 = c0 <= 0.f && c2 >= 0.f, h1 = c1 <= 0.f && c0 >= 0.f;
+    a_lo = f_atan2(l0 ? y0 : (l1 ? y1 : y2), l0 ? x0 : (l1 ? x1 : x2));
+    a_hi = f_atan2(h0 ? y0 : (h1 ? y1 : y2), h0 ? x0 : (h1 ? x1 : x2));
+    if (a_hi < a_lo) a_hi += 2.0f * LT_PI_F;
+  } else {
+    // all three azimuths (nearly) coincide: the shortest arc holding them
+    const float p0 = f_atan2(y0, x0), p1 = f_atan2(y1, x1), p2 = f_atan2(y2, x2);
+    const float lo = fminf(p0, fminf(p1, p2)), hi = fmaxf(p0, fmaxf(p1, p2));
+    const float mid = (p0 + p1 + p2) - lo - hi;
+    const float g0 = mid - lo, g1 = hi - mid, g2 = 2.0f * LT_PI_F - (hi - lo);
+    if (g2 >= g0 && g2 >= g1) { a_lo = lo; a_hi = hi; }
+    else if (g0 >= g1) { a_lo = mid; a_hi = lo + 2.0f * LT_PI_F; }
+    else { a_lo = hi; a_hi = mid + 2.0f * LT_PI_F; }
+  }
   a_lo -= pad;
   a_hi += pad;
-  const float fa0 = floorf((a_lo + LT_PI_F) * P.az_scale), fa1 = floorf((a_hi + LT_PI_F) * P.az_scale);
-  int na = (int)(fa1 - fa0) + 1;
-  if (!(na >= 1)) return R;  // NaN
+  const float fa0 = ceilf((a_lo + LT_PI_F) * P.az_scale - P.az_off - da);
+  const float fa1 = floorf((a_hi + LT_PI_F) * P.az_scale - P.az_off + da);
+  const int na = (int)(fa1 - fa0) + 1;
+  if (!(na >= 1)) return R;  // no ray column inside the arc (or NaN)
   if (na >= P.nb_az) { R.a0 = 0; R.na = P.nb_az; return R; }
-  int a0 = (int)fa0 % P.nb_az;
+  int a0 = (int)fa0;  // a_lo is in [-pi - pad, pi], |az_off| <= 0.5: at most one wrap either way (nb_az >= 4 here)
   if (a0 < 0) a0 += P.nb_az;
+  else if (a0 >= P.nb_az) a0 -= P.nb_az;
   R.a0 = a0;
   R.na = na;
   return R;
 }
 
-// sdirs = normalised directions in bin order, ray index in .w (one dependent load less than dirs[bin_rays[k]])
-__device__ __forceinline__ void sc_test_bin(const tri_rec& T, int face, int bin, const int* __restrict__ bin_start,
-                                            const float4* __restrict__ sdirs, float ox, float oy, float oz,
-                                            unsigned long long* __restrict__ cell, unsigned& n_tests) {
-  const int s = bin_start[bin], e = bin_start[bin + 1];
-  for (int k = s; k < e; ++k) {
-    const float4 d = sdirs[k];
-    ++n_tests;
-    const float t = sc_mt(T, ox, oy, oz, d.x, d.y, d.z);
-    if (t == t)
-      atomicMin(&cell[__float_as_int(d.w)], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
+// grid[bin] = the bin's ray when it holds exactly one (direction, ray index in .w), a zero direction with
+// .w = -1 when it is empty (Moller-Trumbore rejects it at the determinant test), or (.x, .y) = the bin's slot
+// range in sdirs with .w = -2 when it holds several rays (irregular ray sets; a sensor grid has one per bin).
+// One 16-B load per candidate bin instead of the dependent bin_start -> direction chain.
+#define LT_GRID_EMPTY (-1)
+#define LT_GRID_MULTI (-2)
+__device__ __forceinline__ void sc_hit(float t, int ray, int face, unsigned long long* __restrict__ cell) {
+  if (t == t) atomicMin(&cell[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
+}
+__device__ __forceinline__ void sc_test_cell(const tri_rec& T, int face, const float4 g,
+                                             const float4* __restrict__ sdirs, float ox, float oy, float oz,
+                                             unsigned long long* __restrict__ cell, unsigned& n_tests) {
+  const int w = __float_as_int(g.w);
+  if (w != LT_GRID_MULTI) {
+    n_tests += w >= 0 ? 1u : 0u;
+    sc_hit(sc_mt(T, ox, oy, oz, g.x, g.y, g.z), w, face, cell);
+  } else {
+    for (int k = __float_as_int(g.x), e = __float_as_int(g.y); k < e; ++k) {
+      const float4 d = sdirs[k];
+      ++n_tests;
+      sc_hit(sc_mt(T, ox, oy, oz, d.x, d.y, d.z), __float_as_int(d.w), face, cell);
+    }
   }
 }
 
+// sdirs = normalised directions in bin order, ray index in .w
 __global__ __launch_bounds__(256) void k_rs_sortdirs(const float4* __restrict__ dirs,
                                                      const uint32_t* __restrict__ bin_rays, int n,
                                                      float4* __restrict__ sdirs) {
@@ -261,29 +368,42 @@ __global__ __launch_bounds__(256) void k_rs_sortdirs(const float4* __restrict__ 
   sdirs[k] = d;
 }
 
-#define LT_SC_BIG 4096  // candidate bins above which a triangle goes to the wave-per-triangle queue
+__global__ __launch_bounds__(256) void k_rs_grid(const int* __restrict__ bin_start,
+                                                 const float4* __restrict__ sdirs, int nbins,
+                                                 float4* __restrict__ grid) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nbins) return;
+  const int s = bin_start[b], e = bin_start[b + 1];
+  float4 g = make_float4(0.f, 0.f, 0.f, __int_as_float(LT_GRID_EMPTY));
+  if (e - s == 1) g = sdirs[s];
+  else if (e - s > 1) g = make_float4(__int_as_float(s), __int_as_float(e), 0.f, __int_as_float(LT_GRID_MULTI));
+  grid[b] = g;
+}
 
-// One workgroup = 256 consecutive triangles.  Phase A: every thread sets up one triangle (record + bin
-// rectangle) in LDS and the workgroup prefix-sums the candidate counts.  Phase B: the (triangle, bin)
-// candidates of the whole workgroup are dealt round-robin to the threads, so every lane runs the same
-// number of Moller-Trumbore tests no matter how unevenly the triangles cover the image (near geometry
-// covers hundreds of cells, far geometry one or none).
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                 int n_verts, int n_faces, float ox, float oy, float oz,
-                                                 const rs_params* __restrict__ prm, const int* __restrict__ bin_start,
-                                                 const float4* __restrict__ sdirs,
-                                                 unsigned long long* __restrict__ cell, int* __restrict__ large,
-                                                 int* __restrict__ large_count, unsigned* __restrict__ flags,
-                                                 unsigned long long* __restrict__ counters) {
-  __shared__ float tr[9][256];
-  __shared__ int ra0[256], rna[256], re0[256];
-  __shared__ float rinv[256];
-  __shared__ int pre[257];
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x * 256 + tid;
-  const rs_params P = *prm;
+#define LT_SC_BIG 512    // candidate bins above which a triangle goes to the wave-per-triangle queue
+#define LT_SC_CAP 1024   // candidates a k_sc_tris workgroup tests itself (4 rounds); the rest of a heavier workgroup
+                         // is queued in slices: a few near-field workgroups with 10-20 rounds would otherwise run
+                         // long after the rest of the grid has drained (measured: a 20 us tail on a 37 us kernel)
+#define LT_SC_SLICE 512  // candidates per queued slice (k_sc_rest)
+
+// LDS state of one workgroup = 256 consecutive triangles
+struct sc_shared {
+  float tr[9][256];       // v0, e1, e2
+  int ra0[256], rna[256], re0[256];
+  float rinv[256];
+  int pre[257];           // exclusive prefix sum of the candidate counts
+  int wsum[4];
+  int kept;
+};
+
+// Phase A: thread tid sets up triangle first_face + tid (record + bin rectangle) in LDS; returns its number
+// of candidate bins (0 for none / invalid / big; big triangles are queued when PUSH)
+template <bool PUSH>
+__device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
+                                        int n_verts, int n_faces, int f, float ox, float oy, float oz,
+                                        const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
+                                        unsigned* __restrict__ flags) {
+  const int tid = threadIdx.x;
   int cnt = 0;
   if (f < n_faces) {
     const int a = faces[3 * (size_t)f], b = faces[3 * (size_t)f + 1], c = faces[3 * (size_t)f + 2];
@@ -297,81 +417,175 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
                                   v2z - oz);
       const int ne = R.e1 - R.e0 + 1;
       if (R.na > 0 && ne > 0) {
-        const long long c64 = (long long)R.na * ne;
-        if (c64 > LT_SC_BIG) {
-          large[atomicAdd(large_count, 1)] = f;
+        const int c32 = R.na * ne;  // <= 8192 x 4096 bins (lt_rayset_create_dev)
+        if (c32 > LT_SC_BIG) {
+          if (PUSH) large[atomicAdd(large_count, 1)] = f;
         } else {
-          cnt = (int)c64;
-          tr[0][tid] = v0x; tr[1][tid] = v0y; tr[2][tid] = v0z;
-          tr[3][tid] = v1x - v0x; tr[4][tid] = v1y - v0y; tr[5][tid] = v1z - v0z;
-          tr[6][tid] = v2x - v0x; tr[7][tid] = v2y - v0y; tr[8][tid] = v2z - v0z;
-          ra0[tid] = R.a0; rna[tid] = R.na; re0[tid] = R.e0;
-          rinv[tid] = 1.0f / (float)R.na;
+          cnt = c32;
+          S.tr[0][tid] = v0x; S.tr[1][tid] = v0y; S.tr[2][tid] = v0z;
+          S.tr[3][tid] = v1x - v0x; S.tr[4][tid] = v1y - v0y; S.tr[5][tid] = v1z - v0z;
+          S.tr[6][tid] = v2x - v0x; S.tr[7][tid] = v2y - v0y; S.tr[8][tid] = v2z - v0z;
+          S.ra0[tid] = R.a0; S.rna[tid] = R.na; S.re0[tid] = R.e0;
+          S.rinv[tid] = f_rcp((float)R.na);  // 1-ulp reciprocal is enough, see sc_round_robin
         }
       }
-    } else {
+    } else if (PUSH) {
       atomicOr(flags, LT_FLAG_BAD_INDEX);
     }
   }
-  // exclusive prefix sum of cnt over the workgroup
+  return cnt;
+}
+
+// exclusive prefix sum of cnt over the workgroup -> S.pre[0..256]; returns this thread's prefix.  Contains one
+// barrier; the caller issues the second one (after any extra LDS it wants published with it).
+__device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int inc = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(inc, o, 64);
     if (lane >= o) inc += t;
   }
-  if (lane == 63) wsum[wave] = inc;
+  if (lane == 63) S.wsum[wave] = inc;
   __syncthreads();
   int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wsum[w];
-  pre[tid] = woff + inc - cnt;
-  if (tid == 255) pre[256] = woff + inc;
-  __syncthreads();
-  const int total = pre[256];
-  unsigned n_tests = 0, n_cand = 0;
-  // Candidates are dealt ROUND-ROBIN: in every iteration the 64 lanes of a wave hold 64 consecutive
-  // candidates = consecutive bins of a few neighbouring triangles, so the bin_start look-ups, the direction
-  // loads (directions are stored in bin order) and the atomics of a wave fall into a handful of cache lines.
-  // (A contiguous chunk per thread needs no search but made every lane touch its own lines: L2 bound.)
-  for (int c = tid; c < total; c += 256) {
-    int j = 0;  // triangle of this candidate: largest j with pre[j] <= c
+  for (int w = 0; w < wave; ++w) woff += S.wsum[w];
+  total = (S.wsum[0] + S.wsum[1]) + (S.wsum[2] + S.wsum[3]);
+  const int mypre = woff + inc - cnt;
+  S.pre[tid] = mypre;
+  if (tid == 255) S.pre[256] = total;
+  return mypre;
+}
+
+// Phase B over the candidates [c_begin, c_end) of the workgroup, dealt ROUND-ROBIN: in every iteration the 64
+// lanes of a wave hold 64 consecutive candidates = consecutive bins of a few neighbouring triangles, so the
+// grid loads and the atomics of a wave fall into a handful of cache lines, and every lane runs the same
+// number of Moller-Trumbore tests no matter how unevenly the triangles cover the image.  (A contiguous chunk
+// per thread needs no search but made every lane touch its own lines: L2 bound.)  The loop is
+// software-pipelined: the search and the grid load of the NEXT candidate are issued before the triangle test
+// of the current one.
+template <bool COUNT>
+__device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_params& P, const float4* __restrict__ grid,
+                                               const float4* __restrict__ sdirs, unsigned long long* __restrict__ cell,
+                                               int first_face, int c_begin, int c_end, float ox, float oy, float oz,
+                                               unsigned& n_tests, unsigned& n_cand) {
+  auto locate = [&](int c, int& j) -> int {  // triangle j = largest j with pre[j] <= c; returns the bin
+    j = 0;
 #pragma unroll
     for (int step = 128; step >= 1; step >>= 1)
-      if (pre[j + step] <= c) j += step;
-    const int local = c - pre[j];
-    const int na = rna[j];
-    const int row = (int)(((float)local + 0.5f) * rinv[j]);  // local / na, exact for local < 4096
-    int az = ra0[j] + (local - row * na);
+      if (S.pre[j + step] <= c) j += step;
+    const int local = c - S.pre[j];
+    const int na = S.rna[j];
+    // local / na: (local + 0.5) / na is >= 0.5 / na away from an integer and local / na <= LT_SC_BIG / na, so
+    // a relative error of 2^-22 in the product cannot cross one
+    const int row = (int)(((float)local + 0.5f) * S.rinv[j]);
+    int az = S.ra0[j] + (local - row * na);
     if (az >= P.nb_az) az -= P.nb_az;
-    tri_rec T;
-    T.v0x = tr[0][j]; T.v0y = tr[1][j]; T.v0z = tr[2][j];
-    T.e1x = tr[3][j]; T.e1y = tr[4][j]; T.e1z = tr[5][j];
-    T.e2x = tr[6][j]; T.e2y = tr[7][j]; T.e2z = tr[8][j];
-    if (COUNT) ++n_cand;
-    sc_test_bin(T, blockIdx.x * 256 + j, (re0[j] + row) * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+    return (S.re0[j] + row) * P.nb_az + az;
+  };
+  int c = c_begin + (int)threadIdx.x;
+  if (c < c_end) {
+    int j;
+    float4 g = grid[locate(c, j)];
+    for (;;) {
+      // branch-free prefetch (index clamped to the last candidate) so the load stays in flight across the test
+      const int cn = c + 256;
+      int jn;
+      const float4 gn = grid[locate(min(cn, c_end - 1), jn)];
+      tri_rec T;
+      T.v0x = S.tr[0][j]; T.v0y = S.tr[1][j]; T.v0z = S.tr[2][j];
+      T.e1x = S.tr[3][j]; T.e1y = S.tr[4][j]; T.e1z = S.tr[5][j];
+      T.e2x = S.tr[6][j]; T.e2y = S.tr[7][j]; T.e2z = S.tr[8][j];
+      if (COUNT) ++n_cand;
+      sc_test_cell(T, first_face + j, g, sdirs, ox, oy, oz, cell, n_tests);
+      if (cn >= c_end) break;
+      c = cn; j = jn; g = gn;
+    }
   }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsigned long long* __restrict__ counters) {
   if (COUNT) {
     unsigned long long vt = n_tests, vc = n_cand;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { vt += __shfl_xor(vt, o, 64); vc += __shfl_xor(vc, o, 64); }
-    if (lane == 0) { atomicAdd(&counters[1], vt); atomicAdd(&counters[0], vc); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[1], vt); atomicAdd(&counters[0], vc); }
   }
 }
 
-// one wave per queued (large) triangle; lanes stride over its candidate bins
+// One workgroup = 256 consecutive triangles: phase A, prefix sum, phase B over its first ~LT_SC_CAP
+// candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_sc_large(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                  float ox, float oy, float oz, const rs_params* __restrict__ prm,
-                                                  const int* __restrict__ bin_start,
-                                                  const float4* __restrict__ sdirs,
-                                                  unsigned long long* __restrict__ cell, const int* __restrict__ large,
-                                                  const int* __restrict__ large_count,
-                                                  unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                 int n_verts, int n_faces, float ox, float oy, float oz,
+                                                 const rs_params* __restrict__ prm, const float4* __restrict__ grid,
+                                                 const float4* __restrict__ sdirs,
+                                                 unsigned long long* __restrict__ cell, int* __restrict__ large,
+                                                 int* __restrict__ large_count, int2* __restrict__ slices,
+                                                 int cap_slices, unsigned* __restrict__ flags,
+                                                 unsigned long long* __restrict__ counters) {
+  __shared__ sc_shared S;
+  const int tid = threadIdx.x;
+  const int first = blockIdx.x * 256;
   const rs_params P = *prm;
-  const int n_large = *large_count;
+  const int cnt = sc_setup<true>(S, verts, faces, n_verts, n_faces, first + tid, ox, oy, oz, P, large, large_count, flags);
+  int total;
+  const int mypre = sc_prefix(S, cnt, total);
+  // The workgroup keeps the triangles that start below LT_SC_CAP; exactly one thread sees the crossing and
+  // queues the rest in slices (large_count[1] = number of slices; if the queue is full the workgroup keeps all).
+  if (total < LT_SC_CAP) {
+    if (tid == 255) S.kept = total;
+  } else if (mypre < LT_SC_CAP && mypre + cnt >= LT_SC_CAP) {
+    int kept = mypre + cnt;
+    const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
+    if (n_sl > 0) {
+      const int base = atomicAdd(&large_count[1], n_sl);
+      if (base + n_sl <= cap_slices) {
+        for (int k = 0; k < n_sl; ++k) slices[base + k] = make_int2((int)blockIdx.x, kept + k * LT_SC_SLICE);
+      } else {
+        atomicSub(&large_count[1], n_sl);
+        kept = total;
+      }
+    }
+    S.kept = kept;
+  }
+  __syncthreads();
+  unsigned n_tests = 0, n_cand = 0;
+  sc_round_robin<COUNT>(S, P, grid, sdirs, cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
+  sc_count<COUNT>(n_tests, n_cand, counters);
+}
+
+// The rest: (1) queued slices of heavy workgroups -- a workgroup redoes phase A of that triangle block (same
+// code, same prefix sums) and tests one slice of its candidates; (2) big triangles, one wave each, lanes
+// stride over the candidate bins.
+#define LT_SC_REST_BLOCKS 512
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                 int n_verts, int n_faces, float ox, float oy, float oz,
+                                                 const rs_params* __restrict__ prm, const float4* __restrict__ grid,
+                                                 const float4* __restrict__ sdirs,
+                                                 unsigned long long* __restrict__ cell, const int* __restrict__ large,
+                                                 const int* __restrict__ large_count, const int2* __restrict__ slices,
+                                                 int cap_slices, unsigned long long* __restrict__ counters) {
+  __shared__ sc_shared S;
+  const rs_params P = *prm;
+  const int n_large = large_count[0], n_slices = min(large_count[1], cap_slices);
+  unsigned n_tests = 0, n_cand = 0;
+  for (int q = blockIdx.x; q < n_slices; q += gridDim.x) {
+    const int2 sl = slices[q];
+    const int first = sl.x * 256;
+    const int cnt = sc_setup<false>(S, verts, faces, n_verts, n_faces, first + (int)threadIdx.x, ox, oy, oz, P, nullptr,
+                                    nullptr, nullptr);
+    int total;
+    (void)sc_prefix(S, cnt, total);
+    __syncthreads();
+    sc_round_robin<COUNT>(S, P, grid, sdirs, cell, first, sl.y, min(sl.y + LT_SC_SLICE, total), ox, oy, oz, n_tests,
+                          n_cand);
+    __syncthreads();  // LDS is reused by the next slice
+  }
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  unsigned n_tests = 0, n_cand = 0;
   for (int q = wave0; q < n_large; q += nwaves) {
     const int f = large[q];
     const float* pa = verts + 3 * (size_t)faces[3 * (size_t)f];
@@ -384,21 +598,17 @@ __global__ __launch_bounds__(256) void k_sc_large(const float* __restrict__ vert
     T.e2x = v2x - T.v0x; T.e2y = v2y - T.v0y; T.e2z = v2z - T.v0z;
     const bin_rect R = tri_bins(P, T.v0x - ox, T.v0y - oy, T.v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox,
                                 v2y - oy, v2z - oz);
-    const long long total = (long long)R.na * (R.e1 - R.e0 + 1);
-    for (long long w = lane; w < total; w += 64) {
-      const int e = R.e0 + (int)(w / R.na);
-      int az = R.a0 + (int)(w % R.na);
+    const int total = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
+    for (int w = lane; w < total; w += 64) {
+      const int row = w / R.na;
+      const int e = R.e0 + row;
+      int az = R.a0 + (w - row * R.na);
       if (az >= P.nb_az) az -= P.nb_az;
       if (COUNT) ++n_cand;
-      sc_test_bin(T, f, e * P.nb_az + az, bin_start, sdirs, ox, oy, oz, cell, n_tests);
+      sc_test_cell(T, f, grid[e * P.nb_az + az], sdirs, ox, oy, oz, cell, n_tests);
     }
   }
-  if (COUNT) {
-    unsigned long long vt = n_tests, vc = n_cand;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { vt += __shfl_xor(vt, o, 64); vc += __shfl_xor(vc, o, 64); }
-    if (lane == 0) { atomicAdd(&counters[1], vt); atomicAdd(&counters[0], vc); }
-  }
+  sc_count<COUNT>(n_tests, n_cand, counters);
 }
 
 // one thread per ray: unpack the winning (t, face), write back as RayTracer.cpp:73-90, re-arm the cell
@@ -413,7 +623,7 @@ __global__ __launch_bounds__(256) void k_sc_resolve(unsigned long long* __restri
                                                     int* __restrict__ large_count,
                                                     unsigned long long* __restrict__ counters) {
   const int ray = blockIdx.x * 256 + threadIdx.x;
-  if (ray == 0) *large_count = 0;
+  if (ray == 0) { large_count[0] = 0; large_count[1] = 0; }
   bool hit = false;
   if (ray < n_rays) {
     const unsigned long long key = cell[ray];
@@ -472,15 +682,17 @@ struct lt_rayset {
   int* bin_start;
   uint32_t* bin_rays;  // = vals[sorted buffer]
   float4* sdirs;       // directions in bin order, ray index in .w
+  float4* grid;        // one entry per bin, see sc_test_cell
   unsigned long long* cell;
   int* large;
-  int* large_count;
-  int cap_large;
+  int* large_count;  // [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
+  int2* slices;
+  int cap_large, cap_slices;
 };
 
 static void rs_free(lt_rayset* r) {
-  void* ps[] = {r->sdirs, r->dirs, r->ang, r->partial, r->prm, r->keys[0], r->keys[1], r->vals[0], r->vals[1], r->hist,
-                r->bin_start, r->cell, r->large, r->large_count};
+  void* ps[] = {r->grid, r->sdirs, r->dirs, r->ang, r->partial, r->prm, r->keys[0], r->keys[1], r->vals[0], r->vals[1], r->hist,
+                r->bin_start, r->cell, r->large, r->large_count, r->slices};
   for (void* p : ps)
     if (p) (void)hipFree(p);
 }
@@ -502,9 +714,11 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
   }
   *out = nullptr;
   hipStream_t stream = (hipStream_t)stream_;
+  int device = 0;
+  LT_HIP(hipGetDevice(&device));
   lt_rayset* r = (lt_rayset*)calloc(1, sizeof(lt_rayset));
   if (!r) return LT_ERR_NO_MEMORY;
-  LT_HIP(hipGetDevice(&r->device));
+  r->device = device;
   const int W = n_rays / height;
   const int n = W * height;  // RayTracer.cpp:56: rays beyond W * height are ignored
   r->n_rays = n;
@@ -532,6 +746,7 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
   }
   RS_ALLOC(r->hist, ((size_t)1024 * nb + 1024) * sizeof(uint32_t));
   RS_ALLOC(r->bin_start, (nbins + 1) * sizeof(int));
+  RS_ALLOC(r->grid, nbins * sizeof(float4));
   RS_ALLOC(r->cell, nn * sizeof(unsigned long long));
   RS_ALLOC(r->large_count, 4 * sizeof(int));
 #undef RS_ALLOC
@@ -540,9 +755,17 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
     free(r);
     return rc;
   }
-  LT_HIP(hipMemsetAsync(r->cell, 0xFF, nn * sizeof(unsigned long long), stream));
-  LT_HIP(hipMemsetAsync(r->large_count, 0, 4 * sizeof(int), stream));
+  if (hipMemsetAsync(r->cell, 0xFF, nn * sizeof(unsigned long long), stream) != hipSuccess ||
+      hipMemsetAsync(r->large_count, 0, 4 * sizeof(int), stream) != hipSuccess ||
+      hipMemsetAsync(r->prm, 0, sizeof(rs_params), stream) != hipSuccess) {
+    lt_set_error("lt_rayset_create_dev: hipMemsetAsync failed");
+    rs_free(r);
+    free(r);
+    return LT_ERR_HIP;
+  }
   hipLaunchKernelGGL(k_rs_dirs, dim3(256), dim3(256), 0, stream, rays, n, r->norm_flags, r->dirs, r->ang, r->partial);
+  // (prm->dev_az / dev_el start at 0: hipMemsetAsync below, before k_rs_keys accumulates them)
+  hipLaunchKernelGGL(k_rs_fit, dim3(64), dim3(256), 0, stream, r->ang, n, r->nb_az, r->prm);
   hipLaunchKernelGGL(k_rs_keys, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, stream, r->ang, n,
                      r->nb_az, r->nb_el, r->partial, r->prm, r->keys[0], r->vals[0]);
   int buf = 0;
@@ -552,21 +775,37 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
                      r->bin_start);
   if (n > 0)
     hipLaunchKernelGGL(k_rs_sortdirs, dim3((n + 255) / 256), dim3(256), 0, stream, r->dirs, r->bin_rays, n, r->sdirs);
-  LT_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_rs_grid, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, stream, r->bin_start, r->sdirs,
+                     (int)nbins, r->grid);
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    lt_set_error("lt_rayset_create_dev: kernel launch failed: %s", hipGetErrorString(le));
+    (void)hipStreamSynchronize(stream);
+    rs_free(r);
+    free(r);
+    return LT_ERR_HIP;
+  }
   *out = r;
   return LT_OK;
 }
 
+// queues of k_sc_tris: every triangle is queued at most once as "big", and a workgroup of 256 triangles with
+// <= LT_SC_BIG candidates each leaves at most 256 * LT_SC_BIG / LT_SC_SLICE = 256 slices
 static int rs_reserve_large(lt_rayset* r, int n_faces) {
   if (n_faces <= r->cap_large) return LT_OK;
-  if (r->large) {
+  if (r->large || r->slices) {
     LT_HIP(hipDeviceSynchronize());
     (void)hipFree(r->large);
+    (void)hipFree(r->slices);
     r->large = nullptr;
+    r->slices = nullptr;
+    r->cap_large = r->cap_slices = 0;
   }
   const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
   LT_HIP(hipMalloc((void**)&r->large, cap * sizeof(int)));
+  LT_HIP(hipMalloc((void**)&r->slices, cap * sizeof(int2)));
   r->cap_large = (int)cap;
+  r->cap_slices = (int)cap;
   return LT_OK;
 }
 
@@ -598,19 +837,21 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
       const dim3 g((n + 255) / 256), b(256);
       if (count) {
         hipLaunchKernelGGL(k_sc_tris<true>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
-                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->flags,
+                           r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->flags,
                            s->counters);
-        hipLaunchKernelGGL(k_sc_large<true>, dim3(64), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
-                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
+        hipLaunchKernelGGL(k_sc_rest<true>, dim3(LT_SC_REST_BLOCKS), b, 0, stream, s->verts, s->faces, s->n_verts, n,
+                           ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices,
+                           r->cap_slices, s->counters);
       } else {
         if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
         hipLaunchKernelGGL(k_sc_tris<false>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
-                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->flags,
+                           r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->flags,
                            s->counters);
         if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
         s->probe[0] = s->probe[1] = nullptr;
-        hipLaunchKernelGGL(k_sc_large<false>, dim3(64), b, 0, stream, s->verts, s->faces, ox, oy, oz, r->prm,
-                           r->bin_start, r->sdirs, r->cell, r->large, r->large_count, s->counters);
+        hipLaunchKernelGGL(k_sc_rest<false>, dim3(LT_SC_REST_BLOCKS), b, 0, stream, s->verts, s->faces, s->n_verts, n,
+                           ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices,
+                           r->cap_slices, s->counters);
       }
     }
     if (count)
