@@ -324,6 +324,46 @@ def test_scatter_equals_lbvh_equals_bruteforce_on_adversarial_soup(oracle):
         assert a["stats"]["n_hits"] == b["stats"]["n_hits"] == int((ref["tri"] >= 0).sum()) > 100
 
 
+def _adversarial_soup(rng, n):
+    cen = rng.normal(size=(n, 3)) * rng.choice([0.05, 0.5, 5.0, 40.0], size=(n, 1))
+    size = rng.choice([0.01, 0.1, 1.0, 20.0], size=(n, 1, 1))
+    tri = cen[:, None, :] + rng.normal(size=(n, 3, 3)) * size
+    k = n // 15
+    tri[:k, :, 1] = 0.0                          # edge-on: in the plane y = 0 through the sensor
+    tri[k:2 * k, :, 2] = tri[k:2 * k, :1, 2]     # horizontal triangles (many contain the vertical axis)
+    tri[2 * k:3 * k, 1, :2] = tri[2 * k:3 * k, 0, :2]   # vertical walls: two vertices above each other
+    tri[3 * k:4 * k, :, 0] = -np.abs(tri[3 * k:4 * k, :, 0])  # behind the sensor: straddle azimuth +-pi
+    tri[3 * k:4 * k, 0, 1] = -np.abs(tri[3 * k:4 * k, 0, 1]) - 1e-3
+    tri[3 * k:4 * k, 1, 1] = np.abs(tri[3 * k:4 * k, 1, 1]) + 1e-3
+    v = np.ascontiguousarray(tri.reshape(-1, 3).astype(np.float32))
+    f = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    c = rng.integers(0, 256, (3 * n, 3)).astype(np.int32)
+    r = rng.uniform(0, 1, 3 * n).astype(np.float32)
+    return v, f, c, r
+
+
+@pytest.mark.parametrize("H,W,fov_up,fov_down,seed", [(64, 2048, 3.0, -25.0, 1), (16, 301, 15.0, -15.0, 2),
+                                                      (1, 720, 0.0, -10.0, 3), (32, 1, 10.0, -30.0, 4),
+                                                      (128, 1024, 45.0, -45.0, 5), (5, 7, 2.0, -2.0, 6)])
+def test_scatter_on_sensor_grids_vs_adversarial_soup(oracle, H, W, fov_up, fov_down, seed):
+    """Regular sensor grids are where the scatter strategy selects candidates most tightly (rays sit at the bin
+    centres, a triangle only visits the columns / rows whose ray can lie inside its padded angular bounds):
+    check that selection against nasty geometry -- slivers, walls, triangles through the vertical axis, across
+    the +-pi seam, centimetres from the sensor -- for several grid shapes and origins, bit for bit against the
+    brute-force oracle and the LBVH strategy."""
+    rng = np.random.default_rng(seed)
+    v, f, c, r = _adversarial_soup(rng, 2500)
+    rays = create_rays(fov_up, fov_down, H, W)
+    for origin in ((0.0, 0.0, 0.0), (0.37, -0.21, 0.13)):
+        a, b = _both_strategies(v, f, c, r, rays, origin, H)
+        ref = oracle.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE,
+                                  norm=oracle.NORM_SSE_TABLE)
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(a[k], ref[k], f"scatter {k} {H}x{W} origin={origin}")
+            _assert_bits(b[k], ref[k], f"lbvh {k} {H}x{W} origin={origin}")
+        assert a["stats"]["n_hits"] == int((ref["tri"] >= 0).sum()) > 0
+
+
 @pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
                                             ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
 def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):

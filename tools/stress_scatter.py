@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Randomised GPU stress: scatter strategy vs LBVH strategy (both on the GPU, bit for bit) over many random
+sensor grids, origins and triangle soups.  Not part of the test suite; run it after touching lt_scatter.hip:
+    gpurun -- python tools/stress_scatter.py --cases 300"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.raytracer import RaySet, Scene
+from lidar_transfer_amd.synth import synth_scene
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from test_trace_gpu import _adversarial_soup
+
+ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(a.seed)
+bad = 0; tot_rays = tot_hits = tot_tris = 0
+for case in range(a.cases):
+    H = int(rng.choice([1, 2, 5, 16, 64, 128])); W = int(rng.choice([1, 3, 64, 301, 1024, 2048, 4000]))
+    up = float(rng.uniform(-5, 60)); down = float(up - rng.uniform(0.5, 80))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        v, f, c, r = _adversarial_soup(rng, int(rng.integers(10, 6000)))
+    elif kind == 1:
+        v, f, c, r = synth_scene(int(rng.integers(0, 1 << 30)), int(rng.integers(2000, 200000)))
+    else:  # low-poly: a handful of huge triangles (every one of them goes through the big-triangle queue)
+        v, f, c, r = _adversarial_soup(rng, int(rng.integers(1, 40)))
+        v = (v * 30).astype(np.float32)
+    origin = tuple(float(x) for x in rng.normal(size=3) * rng.choice([0.0, 0.1, 2.0]))
+    rays = create_rays(up, down, H, W)
+    if rng.random() < 0.2:   # jittered grid: an irregular ray set
+        rays = (rays + rng.normal(size=rays.shape).astype(np.float32) * 1e-3).astype(np.float32)
+    sc = Scene(0); t = [torch.from_numpy(x).to(dev) for x in (v, f, c, r)]
+    sc.set_mesh(*t); rt = torch.from_numpy(rays).to(dev); rs = RaySet(rt, H)
+    A = sc.render(rs, origin); sc.build(); B = sc.trace(rt, origin, H)
+    same = all(torch.equal(A[k].view(torch.int32), B[k].view(torch.int32)) for k in ("tri", "range", "endpoints", "endcolors", "endrem"))
+    tot_rays += H * W; tot_hits += int((A['tri'] >= 0).sum()); tot_tris += int(f.shape[0])
+    if not same:
+        bad += 1
+        nd = int((A["tri"] != B["tri"]).sum())
+        print(f"MISMATCH case {case}: H={H} W={W} fov=({up:.2f},{down:.2f}) kind={kind} tris={f.shape[0]} origin={origin} differing rays={nd}")
+    rs.close(); sc.close()
+print(f"{a.cases} cases, {bad} mismatches; {tot_tris} triangles, {tot_rays} rays, {tot_hits} hits")
+sys.exit(1 if bad else 0)
