@@ -245,6 +245,20 @@ __device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, flo
   return cx * cx + cy * cy;
 }
 
+// Addressing: with WIDE == false every array of a launch is smaller than 4 GB (the host checks), so element
+// addresses are base + 32-bit byte offset -- one VALU multiply instead of quarter-rate 64-bit multiply-adds on
+// the gather addresses of a VALU-bound kernel.
+template <bool WIDE, class T>
+__device__ __forceinline__ const T* at(const T* base, unsigned elem) {
+  return WIDE ? base + (size_t)elem : (const T*)((const char*)base + elem * (unsigned)sizeof(T));
+}
+template <bool WIDE, class T>
+__device__ __forceinline__ T* at(T* base, unsigned elem) {
+  return WIDE ? base + (size_t)elem : (T*)((char*)base + elem * (unsigned)sizeof(T));
+}
+struct f3 { float x, y, z; };  // 12-B vertex / index triple (alignment 4)
+struct i3 { int x, y, z; };
+
 struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mod nb_az); elevation rows e0..e1
 
 // conservative angular bounds of a triangle seen from the origin -> bin rectangle (na == 0: nothing to do).
@@ -337,21 +351,23 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
 // One 16-B load per candidate bin instead of the dependent bin_start -> direction chain.
 #define LT_GRID_EMPTY (-1)
 #define LT_GRID_MULTI (-2)
+template <bool WIDE>
 __device__ __forceinline__ void sc_hit(float t, int ray, int face, unsigned long long* __restrict__ cell) {
-  if (t == t) atomicMin(&cell[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
+  if (t == t) atomicMin(at<WIDE>(cell, (unsigned)ray), ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
 }
+template <bool WIDE>
 __device__ __forceinline__ void sc_test_cell(const tri_rec& T, int face, const float4 g,
                                              const float4* __restrict__ sdirs, float ox, float oy, float oz,
                                              unsigned long long* __restrict__ cell, unsigned& n_tests) {
   const int w = __float_as_int(g.w);
   if (w != LT_GRID_MULTI) {
     n_tests += w >= 0 ? 1u : 0u;
-    sc_hit(sc_mt(T, ox, oy, oz, g.x, g.y, g.z), w, face, cell);
+    sc_hit<WIDE>(sc_mt(T, ox, oy, oz, g.x, g.y, g.z), w, face, cell);
   } else {
     for (int k = __float_as_int(g.x), e = __float_as_int(g.y); k < e; ++k) {
-      const float4 d = sdirs[k];
+      const float4 d = *at<WIDE>(sdirs, (unsigned)k);
       ++n_tests;
-      sc_hit(sc_mt(T, ox, oy, oz, d.x, d.y, d.z), __float_as_int(d.w), face, cell);
+      sc_hit<WIDE>(sc_mt(T, ox, oy, oz, d.x, d.y, d.z), __float_as_int(d.w), face, cell);
     }
   }
 }
@@ -398,7 +414,7 @@ struct sc_shared {
 
 // Phase A: thread tid sets up triangle first_face + tid (record + bin rectangle) in LDS; returns its number
 // of candidate bins (0 for none / invalid / big; big triangles are queued when PUSH)
-template <bool PUSH>
+template <bool PUSH, bool WIDE>
 __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
                                         int n_verts, int n_faces, int f, float ox, float oy, float oz,
                                         const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
@@ -406,13 +422,14 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
   const int tid = threadIdx.x;
   int cnt = 0;
   if (f < n_faces) {
-    const int a = faces[3 * (size_t)f], b = faces[3 * (size_t)f + 1], c = faces[3 * (size_t)f + 2];
+    const i3 idx = *at<WIDE>((const i3*)faces, (unsigned)f);
+    const int a = idx.x, b = idx.y, c = idx.z;
     if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
-      const float* pa = verts + 3 * (size_t)a;
-      const float* pb = verts + 3 * (size_t)b;
-      const float* pc = verts + 3 * (size_t)c;
-      const float v0x = pa[0], v0y = pa[1], v0z = pa[2], v1x = pb[0], v1y = pb[1], v1z = pb[2];
-      const float v2x = pc[0], v2y = pc[1], v2z = pc[2];
+      const f3 A = *at<WIDE>((const f3*)verts, (unsigned)a);
+      const f3 B = *at<WIDE>((const f3*)verts, (unsigned)b);
+      const f3 C = *at<WIDE>((const f3*)verts, (unsigned)c);
+      const float v0x = A.x, v0y = A.y, v0z = A.z, v1x = B.x, v1y = B.y, v1z = B.z;
+      const float v2x = C.x, v2y = C.y, v2z = C.z;
       const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
                                   v2z - oz);
       const int ne = R.e1 - R.e0 + 1;
@@ -464,7 +481,7 @@ __device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
 // per thread needs no search but made every lane touch its own lines: L2 bound.)  The loop is
 // software-pipelined: the search and the grid load of the NEXT candidate are issued before the triangle test
 // of the current one.
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_params& P, const float4* __restrict__ grid,
                                                const float4* __restrict__ sdirs, unsigned long long* __restrict__ cell,
                                                int first_face, int c_begin, int c_end, float ox, float oy, float oz,
@@ -486,18 +503,18 @@ __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_para
   int c = c_begin + (int)threadIdx.x;
   if (c < c_end) {
     int j;
-    float4 g = grid[locate(c, j)];
+    float4 g = *at<false>(grid, (unsigned)locate(c, j));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
     for (;;) {
       // branch-free prefetch (index clamped to the last candidate) so the load stays in flight across the test
       const int cn = c + 256;
       int jn;
-      const float4 gn = grid[locate(min(cn, c_end - 1), jn)];
+      const float4 gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn));
       tri_rec T;
       T.v0x = S.tr[0][j]; T.v0y = S.tr[1][j]; T.v0z = S.tr[2][j];
       T.e1x = S.tr[3][j]; T.e1y = S.tr[4][j]; T.e1z = S.tr[5][j];
       T.e2x = S.tr[6][j]; T.e2y = S.tr[7][j]; T.e2z = S.tr[8][j];
       if (COUNT) ++n_cand;
-      sc_test_cell(T, first_face + j, g, sdirs, ox, oy, oz, cell, n_tests);
+      sc_test_cell<WIDE>(T, first_face + j, g, sdirs, ox, oy, oz, cell, n_tests);
       if (cn >= c_end) break;
       c = cn; j = jn; g = gn;
     }
@@ -516,7 +533,7 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
 
 // One workgroup = 256 consecutive triangles: phase A, prefix sum, phase B over its first ~LT_SC_CAP
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts, const int* __restrict__ faces,
                                                  int n_verts, int n_faces, float ox, float oy, float oz,
                                                  const rs_params* __restrict__ prm, const float4* __restrict__ grid,
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
   const int tid = threadIdx.x;
   const int first = blockIdx.x * 256;
   const rs_params P = *prm;
-  const int cnt = sc_setup<true>(S, verts, faces, n_verts, n_faces, first + tid, ox, oy, oz, P, large, large_count, flags);
+  const int cnt = sc_setup<true, WIDE>(S, verts, faces, n_verts, n_faces, first + tid, ox, oy, oz, P, large, large_count, flags);
   int total;
   const int mypre = sc_prefix(S, cnt, total);
   // The workgroup keeps the triangles that start below LT_SC_CAP; exactly one thread sees the crossing and
@@ -552,7 +569,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
   }
   __syncthreads();
   unsigned n_tests = 0, n_cand = 0;
-  sc_round_robin<COUNT>(S, P, grid, sdirs, cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
+  sc_round_robin<COUNT, WIDE>(S, P, grid, sdirs, cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
   sc_count<COUNT>(n_tests, n_cand, counters);
 }
 
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
 // code, same prefix sums) and tests one slice of its candidates; (2) big triangles, one wave each, lanes
 // stride over the candidate bins.
 #define LT_SC_REST_BLOCKS 512
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts, const int* __restrict__ faces,
                                                  int n_verts, int n_faces, float ox, float oy, float oz,
                                                  const rs_params* __restrict__ prm, const float4* __restrict__ grid,
@@ -575,12 +592,12 @@ __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts
   for (int q = blockIdx.x; q < n_slices; q += gridDim.x) {
     const int2 sl = slices[q];
     const int first = sl.x * 256;
-    const int cnt = sc_setup<false>(S, verts, faces, n_verts, n_faces, first + (int)threadIdx.x, ox, oy, oz, P, nullptr,
+    const int cnt = sc_setup<false, WIDE>(S, verts, faces, n_verts, n_faces, first + (int)threadIdx.x, ox, oy, oz, P, nullptr,
                                     nullptr, nullptr);
     int total;
     (void)sc_prefix(S, cnt, total);
     __syncthreads();
-    sc_round_robin<COUNT>(S, P, grid, sdirs, cell, first, sl.y, min(sl.y + LT_SC_SLICE, total), ox, oy, oz, n_tests,
+    sc_round_robin<COUNT, WIDE>(S, P, grid, sdirs, cell, first, sl.y, min(sl.y + LT_SC_SLICE, total), ox, oy, oz, n_tests,
                           n_cand);
     __syncthreads();  // LDS is reused by the next slice
   }
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts
       int az = R.a0 + (w - row * R.na);
       if (az >= P.nb_az) az -= P.nb_az;
       if (COUNT) ++n_cand;
-      sc_test_cell(T, f, grid[e * P.nb_az + az], sdirs, ox, oy, oz, cell, n_tests);
+      sc_test_cell<WIDE>(T, f, grid[e * P.nb_az + az], sdirs, ox, oy, oz, cell, n_tests);
     }
   }
   sc_count<COUNT>(n_tests, n_cand, counters);
@@ -835,24 +852,26 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
     const float ox = origin[0], oy = origin[1], oz = origin[2];
     if (n > 0) {
       const dim3 g((n + 255) / 256), b(256);
-      if (count) {
-        hipLaunchKernelGGL(k_sc_tris<true>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
-                           r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->flags,
-                           s->counters);
-        hipLaunchKernelGGL(k_sc_rest<true>, dim3(LT_SC_REST_BLOCKS), b, 0, stream, s->verts, s->faces, s->n_verts, n,
-                           ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices,
-                           r->cap_slices, s->counters);
-      } else {
-        if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
-        hipLaunchKernelGGL(k_sc_tris<false>, g, b, 0, stream, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm,
-                           r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->flags,
-                           s->counters);
+      // 32-bit byte offsets unless an array of this launch reaches 4 GB (> 357 M triangles / vertices, > 268 M rays)
+      const bool wide = (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 12 >= (1ull << 32) ||
+                        (size_t)R * 16 >= (1ull << 32);
+#define SC_LAUNCH(KERNEL, GRID, ...) \
+  do { \
+    if (count && wide) hipLaunchKernelGGL((KERNEL<true, true>), GRID, b, 0, stream, __VA_ARGS__); \
+    else if (count) hipLaunchKernelGGL((KERNEL<true, false>), GRID, b, 0, stream, __VA_ARGS__); \
+    else if (wide) hipLaunchKernelGGL((KERNEL<false, true>), GRID, b, 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, b, 0, stream, __VA_ARGS__); \
+  } while (0)
+      if (!count && s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
+      SC_LAUNCH(k_sc_tris, g, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell,
+                r->large, r->large_count, r->slices, r->cap_slices, s->flags, s->counters);
+      if (!count) {
         if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
         s->probe[0] = s->probe[1] = nullptr;
-        hipLaunchKernelGGL(k_sc_rest<false>, dim3(LT_SC_REST_BLOCKS), b, 0, stream, s->verts, s->faces, s->n_verts, n,
-                           ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell, r->large, r->large_count, r->slices,
-                           r->cap_slices, s->counters);
       }
+      SC_LAUNCH(k_sc_rest, dim3(LT_SC_REST_BLOCKS), s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm, r->grid,
+                r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->counters);
+#undef SC_LAUNCH
     }
     if (count)
       hipLaunchKernelGGL(k_sc_resolve<true>, dim3((R + 255) / 256), dim3(256), 0, stream, r->cell, r->dirs, R, ox, oy,
