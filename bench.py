@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 # ---- algorithmic bytes per unit ----------------------------------------------------
 # scatter, kernel k_sc_tris: per triangle 3 indices (12 B) + 3 vertices (36 B); per Moller-Trumbore test one
-# normalised direction (16 B) + the bin bookkeeping (8 B); per accepted hit one 8-B atomic
-SC_B_TRI, SC_B_TEST, SC_B_HIT = 48, 24, 8
+# 16-B grid entry (normalised direction + ray index); per accepted hit one 8-B atomic
+SC_B_TRI, SC_B_TEST, SC_B_HIT = 48, 16, 8
 # lbvh, kernel k_trace4: one 4-wide node 128 B, one triangle record 48 B; per ray 12 B direction in + 44 B out
 # (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
 LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
@@ -297,8 +297,8 @@ def main():
         ach = alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section); collected on workload C2 only
-        # (profiles/r01/b_pmc_scatter.txt: k_sc_tris; profiles/r01/b_pmc_lbvh.txt: k_trace4)
-        traffic = {"scatter": 53.8e6, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
+        # (profiles/r01/e_pmc_scatter.txt: k_sc_tris; profiles/r01/b_pmc_lbvh.txt: k_trace4)
+        traffic = {"scatter": 45.0e6, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
         d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
              "algorithmic_bytes_per_launch": int(alg)}
