@@ -248,13 +248,17 @@ __device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, flo
 // Addressing: with WIDE == false every array of a launch is smaller than 4 GB (the host checks), so element
 // addresses are base + 32-bit byte offset -- one VALU multiply instead of quarter-rate 64-bit multiply-adds on
 // the gather addresses of a VALU-bound kernel.
+template <class T>
+__device__ __forceinline__ unsigned byte_off(unsigned elem) {  // v_mul_lo_u32 is quarter rate: shift-add for 12 B
+  return sizeof(T) == 12 ? (elem << 3) + (elem << 2) : elem * (unsigned)sizeof(T);
+}
 template <bool WIDE, class T>
 __device__ __forceinline__ const T* at(const T* base, unsigned elem) {
-  return WIDE ? base + (size_t)elem : (const T*)((const char*)base + elem * (unsigned)sizeof(T));
+  return WIDE ? base + (size_t)elem : (const T*)((const char*)base + byte_off<T>(elem));
 }
 template <bool WIDE, class T>
 __device__ __forceinline__ T* at(T* base, unsigned elem) {
-  return WIDE ? base + (size_t)elem : (T*)((char*)base + elem * (unsigned)sizeof(T));
+  return WIDE ? base + (size_t)elem : (T*)((char*)base + byte_off<T>(elem));
 }
 struct f3 { float x, y, z; };  // 12-B vertex / index triple (alignment 4)
 struct i3 { int x, y, z; };
@@ -457,12 +461,15 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
 // barrier; the caller issues the second one (after any extra LDS it wants published with it).
 __device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // inclusive wave scan with DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31 across
+  // rows): 6 VALU instructions instead of 6 ds_bpermute round trips
   int inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);  // row_shr:1
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);  // row_shr:2
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);  // row_shr:4
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);  // row_shr:8
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
   if (lane == 63) S.wsum[wave] = inc;
   __syncthreads();
   int woff = 0;
@@ -486,37 +493,40 @@ __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_para
                                                const float4* __restrict__ sdirs, unsigned long long* __restrict__ cell,
                                                int first_face, int c_begin, int c_end, float ox, float oy, float oz,
                                                unsigned& n_tests, unsigned& n_cand) {
-  auto locate = [&](int c, int& j) -> int {  // triangle j = largest j with pre[j] <= c; returns the bin
-    j = 0;
+  // LDS slots are addressed by BYTE offset j4 = 4 * j throughout (one shift less per search step / array read)
+  auto ldi = [](const int* arr, unsigned j4) { return *(const int*)((const char*)arr + j4); };
+  auto ldf = [](const float* arr, unsigned j4) { return *(const float*)((const char*)arr + j4); };
+  auto locate = [&](int c, unsigned& j4) -> int {  // triangle j = largest j with pre[j] <= c; returns the bin
+    j4 = 0;
 #pragma unroll
-    for (int step = 128; step >= 1; step >>= 1)
-      if (S.pre[j + step] <= c) j += step;
-    const int local = c - S.pre[j];
-    const int na = S.rna[j];
+    for (unsigned step4 = 512; step4 >= 4; step4 >>= 1)
+      if (ldi(S.pre, j4 + step4) <= c) j4 += step4;
+    const int local = c - ldi(S.pre, j4);
+    const int na = ldi(S.rna, j4);
     // local / na: (local + 0.5) / na is >= 0.5 / na away from an integer and local / na <= LT_SC_BIG / na, so
     // a relative error of 2^-22 in the product cannot cross one
-    const int row = (int)(((float)local + 0.5f) * S.rinv[j]);
-    int az = S.ra0[j] + (local - row * na);
+    const int row = (int)(((float)local + 0.5f) * ldf(S.rinv, j4));
+    int az = ldi(S.ra0, j4) + (local - row * na);
     if (az >= P.nb_az) az -= P.nb_az;
-    return (S.re0[j] + row) * P.nb_az + az;
+    return (ldi(S.re0, j4) + row) * P.nb_az + az;
   };
   int c = c_begin + (int)threadIdx.x;
   if (c < c_end) {
-    int j;
-    float4 g = *at<false>(grid, (unsigned)locate(c, j));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
+    unsigned j4;
+    float4 g = *at<false>(grid, (unsigned)locate(c, j4));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
     for (;;) {
       // branch-free prefetch (index clamped to the last candidate) so the load stays in flight across the test
       const int cn = c + 256;
-      int jn;
-      const float4 gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn));
+      unsigned jn4;
+      const float4 gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn4));
       tri_rec T;
-      T.v0x = S.tr[0][j]; T.v0y = S.tr[1][j]; T.v0z = S.tr[2][j];
-      T.e1x = S.tr[3][j]; T.e1y = S.tr[4][j]; T.e1z = S.tr[5][j];
-      T.e2x = S.tr[6][j]; T.e2y = S.tr[7][j]; T.e2z = S.tr[8][j];
+      T.v0x = ldf(S.tr[0], j4); T.v0y = ldf(S.tr[1], j4); T.v0z = ldf(S.tr[2], j4);
+      T.e1x = ldf(S.tr[3], j4); T.e1y = ldf(S.tr[4], j4); T.e1z = ldf(S.tr[5], j4);
+      T.e2x = ldf(S.tr[6], j4); T.e2y = ldf(S.tr[7], j4); T.e2z = ldf(S.tr[8], j4);
       if (COUNT) ++n_cand;
-      sc_test_cell<WIDE>(T, first_face + j, g, sdirs, ox, oy, oz, cell, n_tests);
+      sc_test_cell<WIDE>(T, first_face + (int)(j4 >> 2), g, sdirs, ox, oy, oz, cell, n_tests);
       if (cn >= c_end) break;
-      c = cn; j = jn; g = gn;
+      c = cn; j4 = jn4; g = gn;
     }
   }
 }
