@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "8")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "16")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other strategy")
@@ -173,7 +173,8 @@ def main():
                      torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.int32, device=dev))
                     for c in range(n_chunks)]
         works = []
-        use_allgather = os.environ.get("LT_BENCH_COLLECTIVE", "gather") == "allgather"
+        coll = os.environ.get("LT_BENCH_COLLECTIVE", "p2p")  # p2p (grouped send/recv) | gather | allgather
+        use_allgather = coll == "allgather"
 
         # Host side of one step, kept as thin as a C++ driver would be: three calls into liblidarhip.so with
         # precomputed handles and pointers (mesh pointer swap, probe events, one render / build+trace).
@@ -222,6 +223,20 @@ def main():
                 cur.wait_event(ev)
             # deform's unpack for the whole chunk: label_image = ray_colors[:, :, 2] (laserscan.py:912)
             label_chunk = color_all[c0:c1, :, 2].contiguous()
+            if coll == "p2p":
+                # the gather as RCCL implements it -- one group of send/recv, 7 peers -> root over 7 separate
+                # xGMI links -- minus the root's send to itself (a plain device copy instead: RCCL moves the
+                # self-part through its channel kernels at ~15 GB/s, which at 48 k scans/s would dominate)
+                ops = []
+                for k, src in enumerate((range_all[c0:c1], label_chunk)):
+                    if rank == 0:
+                        recv[c][k][0].copy_(src, non_blocking=True)
+                        ops += [dist.P2POp(dist.irecv, recv[c][k][r], r) for r in range(1, world)]
+                    else:
+                        ops.append(dist.P2POp(dist.isend, src, 0))
+                if ops:
+                    works.extend(dist.batch_isend_irecv(ops))
+                return
             for k, src in enumerate((range_all[c0:c1], label_chunk)):
                 if use_allgather:  # LT_BENCH_COLLECTIVE=allgather: every rank receives everything (ring-bound)
                     ag = recv[c][k] if rank == 0 else torch.empty((world,) + tuple(src.shape), dtype=src.dtype,
@@ -235,11 +250,21 @@ def main():
             step(i)
         torch.cuda.synchronize()
         if do_gather:  # warm-up of the collective too: RCCL sets up its peer-to-peer channels lazily
+            # ... and of the exact torch ops gather_chunk uses (the first strided-gather / copy kernel of a process
+            # costs ~50 ms of module loading, which must not land in the timed region)
+            w_lab = color_all[0:2, :, 2].contiguous()
+            torch.empty_like(range_all[0:2]).copy_(range_all[0:2], non_blocking=True)
+            torch.empty_like(w_lab).copy_(w_lab, non_blocking=True)
             wbuf = torch.zeros((4, R), dtype=torch.float32, device=dev)
             wl_ = [torch.empty_like(wbuf) for _ in range(world)] if rank == 0 else None
             for _ in range(2):
                 if use_allgather:
                     dist.all_gather_into_tensor(torch.empty((world * 4, R), dtype=torch.float32, device=dev), wbuf)
+                elif coll == "p2p":
+                    wops = ([dist.P2POp(dist.irecv, wl_[r], r) for r in range(1, world)] if rank == 0
+                            else [dist.P2POp(dist.isend, wbuf, 0)])
+                    for wk in (dist.batch_isend_irecv(wops) if wops else []):
+                        wk.wait()
                 else:
                     dist.gather(wbuf, gather_list=wl_, dst=0)
             torch.cuda.synchronize()
@@ -305,6 +330,27 @@ def main():
         d.update(extra)
         return d
 
+    def isolated_kernel_ms(strategy, n=24):
+        """Outside the clock: the dominant kernel alone on an otherwise idle GPU (one scan at a time).  `frac`
+        above is measured inside the timed region, where `streams_per_gpu` scans share the chip and every
+        launch is stretched by its neighbours; this is the same kernel without them."""
+        w, ts = workers[0], []
+        for i in range(n + 4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w.set_mesh(*scenes[i % len(scenes)])
+            with torch.cuda.stream(streams[0]):
+                if strategy == "lbvh":
+                    w.build()
+                    w.set_probe(e0, e1)
+                    w.trace(rays, origin, H, out=scratch[0])
+                else:
+                    w.set_probe(e0, e1)
+                    w.render(raysets[0], origin, out=scratch[0])
+            torch.cuda.synchronize()
+            if i >= 4:
+                ts.append(e0.elapsed_time(e1))
+        return float(np.mean(ts))
+
     dt, kern_ms, hits = run(args.strategy, K, Wm, keep=True)
     other = None
     if not args.no_other:
@@ -314,8 +360,14 @@ def main():
         other = {"strategy": oname, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
                  "ms_per_step": round(odt / Ko * 1e3, 4), "steps": Ko, "roofline": roofline(oname, okern)}
 
+    iso_ms = isolated_kernel_ms(args.strategy)
     if rank == 0:
         value = world * K * R / dt / 1e6
+        rl = roofline(args.strategy, kern_ms)
+        rl["isolated"] = {"avg_kernel_ms": round(iso_ms, 5),
+                          "achieved": round(rl["algorithmic_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9, 1),
+                          "frac": round(rl["algorithmic_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "same kernel, one scan at a time on an idle GPU, measured after the timed region"}
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -329,7 +381,7 @@ def main():
                        "streams_per_gpu": S},
             "scans_per_s": round(world * K / dt, 2),
             "hit_fraction": round(hits / R, 4),
-            "roofline": roofline(args.strategy, kern_ms),
+            "roofline": rl,
         }
         if phase:
             out["lbvh_phase_ms"] = {k: round(v, 4) for k, v in phase.items() if k.startswith("ms_") and k != "ms_trace"}
