@@ -117,6 +117,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    from lidar_transfer_amd.dist import gather_to_root
     from lidar_transfer_amd.laserscan import create_rays
     from lidar_transfer_amd.raytracer import RaySet, Scene
     from lidar_transfer_amd.synth import WORKLOADS, synth_scene
@@ -227,15 +228,8 @@ def main():
                 # the gather as RCCL implements it -- one group of send/recv, 7 peers -> root over 7 separate
                 # xGMI links -- minus the root's send to itself (a plain device copy instead: RCCL moves the
                 # self-part through its channel kernels at ~15 GB/s, which at 48 k scans/s would dominate)
-                ops = []
                 for k, src in enumerate((range_all[c0:c1], label_chunk)):
-                    if rank == 0:
-                        recv[c][k][0].copy_(src, non_blocking=True)
-                        ops += [dist.P2POp(dist.irecv, recv[c][k][r], r) for r in range(1, world)]
-                    else:
-                        ops.append(dist.P2POp(dist.isend, src, 0))
-                if ops:
-                    works.extend(dist.batch_isend_irecv(ops))
+                    works.extend(gather_to_root(src, recv[c][k] if rank == 0 else None, dst=0))
                 return
             for k, src in enumerate((range_all[c0:c1], label_chunk)):
                 if use_allgather:  # LT_BENCH_COLLECTIVE=allgather: every rank receives everything (ring-bound)
@@ -261,9 +255,7 @@ def main():
                 if use_allgather:
                     dist.all_gather_into_tensor(torch.empty((world * 4, R), dtype=torch.float32, device=dev), wbuf)
                 elif coll == "p2p":
-                    wops = ([dist.P2POp(dist.irecv, wl_[r], r) for r in range(1, world)] if rank == 0
-                            else [dist.P2POp(dist.isend, wbuf, 0)])
-                    for wk in (dist.batch_isend_irecv(wops) if wops else []):
+                    for wk in gather_to_root(wbuf, wl_, dst=0):
                         wk.wait()
                 else:
                     dist.gather(wbuf, gather_list=wl_, dst=0)

@@ -64,3 +64,44 @@ def test_render_scans_two_ranks_equals_one(n):
         assert p.exitcode == 0
     assert np.array_equal(got["range"], single["range"].numpy())
     assert np.array_equal(got["label"], single["label"].numpy())
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lidar_transfer_amd.dist import gather_to_root
+    # the pattern bench.py uses: two images per chunk (range f32, label i32), several chunks in flight
+    works, recvs = [], []
+    for chunk in range(3):
+        rng = torch.full((2 + chunk, 16), float(10 * rank + chunk))
+        lab = torch.full((2 + chunk, 16), 100 * rank + chunk, dtype=torch.int32)
+        rr = [torch.empty((world, 2 + chunk, 16)), torch.empty((world, 2 + chunk, 16), dtype=torch.int32)] \
+            if rank == 0 else [None, None]
+        works += gather_to_root(rng, rr[0]) + gather_to_root(lab, rr[1])
+        recvs.append(rr)
+    for w in works:
+        w.wait()
+    if rank == 0:
+        q.put([[t.numpy() for t in rr] for rr in recvs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_to_root_grouped_send_recv(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for chunk, (rng, lab) in enumerate(got):
+        for r in range(world):
+            assert np.all(rng[r] == 10 * r + chunk) and np.all(lab[r] == 100 * r + chunk)
