@@ -52,11 +52,13 @@ LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000)   # a step is ~20 us: 1000 of them make a 20 ms timed region
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
-    ap.add_argument("--scenes", type=int, default=4, help="distinct scenes cycled through per rank")
+    ap.add_argument("--scenes", type=int, default=12,
+                    help="distinct scenes cycled through per rank (12 x 26 MB exceeds the 256 MB Infinity Cache, so a "
+                         "scan does not find its mesh cached from the last time round)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "16")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
