@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
 // code, same prefix sums) and tests one slice of its candidates; (2) big triangles, one wave each, lanes
 // stride over the candidate bins.
 #define LT_SC_REST_BLOCKS 512
+#define LT_SC_PARTS 8
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts, const int* __restrict__ faces,
                                                  int n_verts, int n_faces, float ox, float oy, float oz,
@@ -613,7 +614,11 @@ __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts
   }
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  for (int q = wave0; q < n_large; q += nwaves) {
+  // A big triangle is shared by up to LT_SC_PARTS waves (a ground triangle under the sensor of a low-poly
+  // scene covers tens of thousands of bins): work item v = (triangle q, part p); every wave of a triangle
+  // recomputes its bounds, part p takes the candidates p*64 + lane, stride 64 * (parts this triangle needs).
+  for (int v = wave0; v < n_large * LT_SC_PARTS; v += nwaves) {
+    const int q = v / LT_SC_PARTS, part = v - q * LT_SC_PARTS;
     const int f = large[q];
     const float* pa = verts + 3 * (size_t)faces[3 * (size_t)f];
     const float* pb = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
@@ -626,7 +631,9 @@ __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts
     const bin_rect R = tri_bins(P, T.v0x - ox, T.v0y - oy, T.v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox,
                                 v2y - oy, v2z - oz);
     const int total = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
-    for (int w = lane; w < total; w += 64) {
+    const int parts = min(max((total + 1023) / 1024, 1), LT_SC_PARTS);
+    if (part >= parts) continue;
+    for (int w = part * 64 + lane; w < total; w += 64 * parts) {
       const int row = w / R.na;
       const int e = R.e0 + row;
       int az = R.a0 + (w - row * R.na);
