@@ -3,7 +3,8 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                       # everything
+    LT_GOLDEN_ONLY='f5_c[34]' python tests/golden/make_golden.py   # only the fixtures whose name matches
 
 What runs is the reference itself, not our restatement:
   * the C++ raytracer compiled from /root/reference/auxiliary/raytracer by oracle/Makefile into
@@ -78,6 +79,19 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+ONLY = os.environ.get("LT_GOLDEN_ONLY")
+
+
+def wanted(tag):
+    import re
+    return ONLY is None or re.search(ONLY, tag) is not None
+
+
+def save(tag, **arrays):
+    if wanted(tag):
+        np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **arrays)
+
+
 def throw(fl, verts, faces, colors, rem, rays, origin, H, W):
     """The genuine throw_rays_at_mesh on a TSDFVolume whose get_mesh returns our mesh."""
     vol = object.__new__(fl.TSDFVolume)
@@ -103,7 +117,7 @@ def main():
             f1[f"{name}_head"] = r[:64]
             f1[f"{name}_tail"] = r[-64:]
             f1[f"{name}_stride997"] = r[::997]
-    np.savez_compressed(os.path.join(HERE, "f1_create_rays.npz"), **f1)
+    save("f1_create_rays", **f1)
 
     # ---- F2: three-triangle smoke scene ---------------------------------------
     verts = np.array([[5, -5, -5], [5, 5, -5], [5, 5, 5], [5, -5, 5], [2, -0.5, -0.5], [2, 0.5, -0.5], [2, 0, 0.5]],
@@ -116,7 +130,7 @@ def main():
                      [1, .9, .9]], np.float32)
     origin = np.zeros(3, np.float32)
     ep, rc, rg, rm = throw(fl, verts, faces, colors, rem, rays, origin, 2, 4)
-    np.savez_compressed(os.path.join(HERE, "f2_three_triangles.npz"), verts=verts, faces=faces,
+    save("f2_three_triangles", verts=verts, faces=faces,
                         colors=colors.astype(np.int32), rem=rem, rays=rays, origin=origin, H=2, W=4, endpoints=ep,
                         endcolors=rc, range=rg, endrem=rm)
 
@@ -128,12 +142,14 @@ def main():
     rem3 = np.linspace(0.1, 0.6, 6).astype(np.float32)
     rays3 = np.array([[-39.5, -25.5, -1.7], [-39.9, -25.9, -1.72], [-39.6, -25.7, -1.72], [1, 0, 0]], np.float32)
     ep, rc, rg, rm = throw(fl, verts3, faces3, colors3, rem3, rays3, origin, 1, 4)
-    np.savez_compressed(os.path.join(HERE, "f3_demo_geometry.npz"), verts=verts3, faces=faces3,
+    save("f3_demo_geometry", verts=verts3, faces=faces3,
                         colors=colors3.astype(np.int32), rem=rem3, rays=rays3, origin=origin, H=1, W=4,
                         endpoints=ep, endcolors=rc, range=rg, endrem=rm)
 
     # ---- F4 / F5: seeded synthetic scenes; hit-triangle ids through the soup trick ---------------------
     def scene_case(tag, seed, ntri, fov, H, W, org, full, overlap=False):
+        if not wanted(tag):
+            return
         v, f, c, r = synth_scene(seed, ntri, allow_overlap=overlap)
         sv, sf, sc, sr = soup(v, f, c, r)
         rays = create_rays(fov[0], fov[1], H, W)
@@ -154,7 +170,7 @@ def main():
                      range_sha256=np.frombuffer(bytes.fromhex(sha(rg)), np.uint8),
                      tri_sha256=np.frombuffer(bytes.fromhex(sha(tri)), np.uint8),
                      label_sha256=np.frombuffer(bytes.fromhex(sha(label)), np.uint8))
-        np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **d)
+        save(tag, **d)
         print(tag, "faces", f.shape[0], "hits", int(hit.sum()), "of", H * W)
 
     scene_case("f4_2k_16x64", 0, 2000, (3, -25), 16, 64, (0, 0, 0), True)
@@ -163,6 +179,8 @@ def main():
     scene_case("f4_20k_overlap_32x128", 3, 20000, (3, -25), 32, 128, (0, 0, 0), True, overlap=True)
     scene_case("f5_c1_200k_64x1024", 0, 200000, (3, -25), 64, 1024, (0, 0, 0), False)
     scene_case("f5_c2_1m_64x2048", 0, 1000000, (3, -25), 64, 2048, (0, 0, 0), False)
+    scene_case("f5_c3_1m_offset_32x1024", 1, 1000000, (10, -30), 32, 1024, (1.5, -2.25, 0.4), False)
+    scene_case("f5_c4_2m5_128x2048", 0, 2500000, (15, -25), 128, 2048, (0, 0, 0), False)
 
     # ---- F6: spherical projections (laserscan.py:202-292, :294-391) ------------------------------------
     color_dict = {0: [0, 0, 0], 10: [245, 150, 100], 40: [255, 0, 255], 48: [75, 0, 75], 50: [0, 200, 255],
@@ -201,7 +219,7 @@ def main():
         if beams:
             f6[f"{tag}_beam_angles"] = np.array(beam_angles)
     f6["H"], f6["W"], f6["fov_up"], f6["fov_down"] = 16, 128, 3.0, -25.0
-    np.savez_compressed(os.path.join(HERE, "f6_range_projection.npz"), **f6)
+    save("f6_range_projection", **f6)
     # ---- F7: what follows the render -- reverse projection, write(), compare() -----------------------------
     import tempfile
     f7 = {}
@@ -262,7 +280,7 @@ def main():
               cmp_target_rem=np.array(tgt.proj_remissions))
     label_diff, range_diff, rem_diff, m_iou, m_acc, mse = ls.compare(s_old, tgt)
     f7.update(cmp_range_diff=range_diff, cmp_rem_diff=rem_diff, cmp_m_iou=m_iou, cmp_m_acc=m_acc, cmp_mse=mse)
-    np.savez_compressed(os.path.join(HERE, "f7_post.npz"), **f7)
+    save("f7_post", **f7)
 
     # ---- F8: TSDF integrate, the reference's numpy CPU mode (fusion_lidar.py:289-392; = the `merge == false`
     # branch of the CUDA kernel without remissions).  The CUDA kernel itself cannot be run here. ---------------
@@ -282,7 +300,7 @@ def main():
     for _ in range(2):
         vol.integrate(label3, depth_im, rem_im, np.eye(4), obs_weight=1.)
     tsdf, col, _ = vol.get_volume()
-    np.savez_compressed(os.path.join(HERE, "f8_tsdf_cpu_mode.npz"), bnds=bnds, voxel=0.25, fov_up=fut, fov_down=fdt,
+    save("f8_tsdf_cpu_mode", bnds=bnds, voxel=0.25, fov_up=fut, fov_down=fdt,
                         label3=label3, depth_im=depth_im, rem_im=rem_im, tsdf=tsdf, weight=vol._weight_vol_cpu,
                         color=col)
     print("golden vectors written to", HERE)
