@@ -357,7 +357,8 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
 #define LT_GRID_MULTI (-2)
 template <bool WIDE>
 __device__ __forceinline__ void sc_hit(float t, int ray, int face, unsigned long long* __restrict__ cell) {
-  if (t == t) atomicMin(at<WIDE>(cell, (unsigned)ray), ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
+  // BVH.cpp:20, :59: a hit has to beat the initial t = 999999999.f (also false for sc_mt's NaN = "no hit")
+  if (t < 999999999.f) atomicMin(at<WIDE>(cell, (unsigned)ray), ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)face);
 }
 template <bool WIDE>
 __device__ __forceinline__ void sc_test_cell(const tri_rec& T, int face, const float4 g,

@@ -335,6 +335,10 @@ def _adversarial_soup(rng, n):
     tri[3 * k:4 * k, :, 0] = -np.abs(tri[3 * k:4 * k, :, 0])  # behind the sensor: straddle azimuth +-pi
     tri[3 * k:4 * k, 0, 1] = -np.abs(tri[3 * k:4 * k, 0, 1]) - 1e-3
     tri[3 * k:4 * k, 1, 1] = np.abs(tri[3 * k:4 * k, 1, 1]) + 1e-3
+    # beyond the reference's initial t = 999999999.f (BVH.cpp:20): must stay misses
+    nf = min(8, n - 4 * k)
+    far = rng.normal(size=(nf, 1, 3)); far /= np.linalg.norm(far, axis=2, keepdims=True)
+    tri[4 * k:4 * k + nf] = far * 3e9 + rng.normal(size=(nf, 3, 3)) * 1e9
     v = np.ascontiguousarray(tri.reshape(-1, 3).astype(np.float32))
     f = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
     c = rng.integers(0, 256, (3 * n, 3)).astype(np.int32)
