@@ -146,6 +146,15 @@ def main():
         v, f, c, r = synth_scene(1000 * rank + i, wl["tris"])
         scenes.append(tuple(torch.from_numpy(x).to(dev) for x in (v, f, c, r)))
     n_faces = int(scenes[0][1].shape[0])
+    # semantic labels travel as int16 when every label of this rank's scenes fits (decided before the clock;
+    # SemanticKITTI labels are < 260): 6 instead of 8 bytes per ray on the xGMI links into the root
+    lab_lo = min(int(sc_[2][:, 2].min()) for sc_ in scenes)
+    lab_hi = max(int(sc_[2][:, 2].max()) for sc_ in scenes)
+    if dist.is_initialized():  # every rank must pick the same width
+        lohi = torch.tensor([-lab_lo, lab_hi], dtype=torch.int64, device=dev)
+        dist.all_reduce(lohi, op=dist.ReduceOp.MAX)
+        lab_lo, lab_hi = -int(lohi[0].item()), int(lohi[1].item())
+    label_dtype = torch.int16 if (-32768 <= lab_lo and lab_hi <= 32767) else torch.int32
     rays = torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev)
     origin = (0.0, 0.0, 0.0)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
@@ -177,7 +186,7 @@ def main():
         recv = None
         if do_gather and rank == 0:
             recv = [(torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.float32, device=dev),
-                     torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=torch.int32, device=dev))
+                     torch.empty((world, bounds[c + 1] - bounds[c], R), dtype=label_dtype, device=dev))
                     for c in range(n_chunks)]
         works = []
         coll = os.environ.get("LT_BENCH_COLLECTIVE", "p2p")  # p2p (grouped send/recv) | gather | allgather
@@ -229,7 +238,7 @@ def main():
                 ev.record(st)
                 cur.wait_event(ev)
             # deform's unpack for the whole chunk: label_image = ray_colors[:, :, 2] (laserscan.py:912)
-            label_chunk = color_all[c0:c1, :, 2].contiguous()
+            label_chunk = color_all[c0:c1, :, 2].to(label_dtype, memory_format=torch.contiguous_format)
             if coll == "p2p":
                 # the gather as RCCL implements it -- one group of send/recv, 7 peers -> root over 7 separate
                 # xGMI links -- minus the root's send to itself (a plain device copy instead: RCCL moves the
@@ -252,7 +261,7 @@ def main():
         if do_gather:  # warm-up of the collective too: RCCL sets up its peer-to-peer channels lazily
             # ... and of the exact torch ops gather_chunk uses (the first strided-gather / copy kernel of a process
             # costs ~50 ms of module loading, which must not land in the timed region)
-            w_lab = color_all[0:2, :, 2].contiguous()
+            w_lab = color_all[0:2, :, 2].to(label_dtype, memory_format=torch.contiguous_format)
             torch.empty_like(range_all[0:2]).copy_(range_all[0:2], non_blocking=True)
             torch.empty_like(w_lab).copy_(w_lab, non_blocking=True)
             wbuf = torch.zeros((4, R), dtype=torch.float32, device=dev)
@@ -376,7 +385,7 @@ def main():
                                    f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan (new mesh) per step, "
                                    f"{len(scenes)} distinct scenes cycled",
                        "strategy": args.strategy,
-                       "parallelism": f"scan-parallel x{world}" + (", range+label images gathered to rank 0 over RCCL (8 chunks, overlapped)" if dist.is_initialized() else ""),
+                       "parallelism": f"scan-parallel x{world}" + (f", range f32 + label {str(label_dtype)[6:]} images gathered to rank 0 over RCCL (8 chunks, overlapped)" if dist.is_initialized() else ""),
                        "streams_per_gpu": S},
             "scans_per_s": round(world * K / dt, 2),
             "hit_fraction": round(hits / R, 4),
