@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void k_trace(
   float best_t = 999999999.f;  // BVH.cpp:20
   int best_face = 0x7fffffff;
   int sp = 0;
-  int cur = (active && n_faces > 0) ? 0 : LT_DONE;
+  // NaN in the direction or the origin: never a hit (see k_trace4), no traversal
+  const bool finite_ray = (dx == dx) && (dy == dy) && (dz == dz) && (ox == ox) && (oy == oy) && (oz == oz);
+  int cur = (active && n_faces > 0 && finite_ray) ? 0 : LT_DONE;
   unsigned n_nodes = 0, n_tris = 0, n_ovf = 0;
   const float eps = 0.000001f;  // Triangle.h:32
 
@@ -269,7 +271,10 @@ __global__ __launch_bounds__(256) void k_trace4(
   float best_t = 999999999.f;
   int best_face = 0x7fffffff;
   int sp = 0;
-  int cur = (active && n_faces > 0) ? 0 : LT_DONE;
+  // A direction or origin with a NaN can never be accepted by the triangle test (every product chain reaches
+  // t as NaN, and BVH.cpp:59 keeps a hit only if t < best): such rays are misses without a traversal.
+  const bool finite_ray = (dx == dx) && (dy == dy) && (dz == dz) && (ox == ox) && (oy == oy) && (oz == oz);
+  int cur = (active && n_faces > 0 && finite_ray) ? 0 : LT_DONE;
   unsigned n_nodes = 0, n_tris = 0, n_ovf = 0;
   const float eps = 0.000001f;
   int* spill = overflow + ray * (LT_STACK4_MAX - LT_STACK4_LDS);
@@ -285,8 +290,10 @@ __global__ __launch_bounds__(256) void k_trace4(
       const float l1z = (a.z - oz) * iz, l2z = (b.y - oz) * iz;
       const float tn = fmaxf(fmaxf(fminf(l1x, l2x), fminf(l1y, l2y)), fmaxf(fminf(l1z, l2z), 0.0f));
       const float tf = fminf(fminf(fmaxf(l1x, l2x), fmaxf(l1y, l2y)), fminf(fmaxf(l1z, l2z), best_t));
-      const int hit = tn <= tf ? 1 : 0;
       const int ref = __float_as_int(b.z);
+      // an unused child slot (box +inf, ref 0x7fffffff) fails the slab test of every finite ray, but fminf /
+      // fmaxf drop NaN operands, so a ray or origin with a NaN would "hit" it: exclude it explicitly
+      const int hit = (tn <= tf && ref != 0x7fffffff) ? 1 : 0;
       // rank of this child among the hit children of the quad (by tn, then lane)
       const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
       const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);

@@ -368,6 +368,31 @@ def test_scatter_on_sensor_grids_vs_adversarial_soup(oracle, H, W, fov_up, fov_d
         assert a["stats"]["n_hits"] == int((ref["tri"] >= 0).sum()) > 0
 
 
+@pytest.mark.parametrize("H,W", [(5, 8), (16, 64)])
+def test_non_finite_rays_and_origin_are_misses_on_a_deep_tree(oracle, H, W):
+    """Zero-length, NaN and unnormalised rays, and a NaN origin, on the adversarial soup (a deep, overlapping
+    tree).  fminf / fmaxf drop NaN operands, so a NaN ray used to pass the slab test of the UNUSED child slots of
+    the 4-wide nodes and follow their sentinel reference out of the node array (GPU memory fault).  Such rays
+    can never be accepted by the triangle test: both strategies must report a miss, the other rays must be
+    unaffected."""
+    rng = np.random.default_rng(1)
+    v, f, c, r = _adversarial_soup(rng, 3000)
+    rays = (create_rays(10, -20, H, W) * rng.uniform(0.1, 50.0, (H * W, 1))).astype(np.float32)
+    rays[0, 1] = np.nan
+    rays[3] = 0.0
+    rays[H * W - 1, 2] = np.inf
+    origin = (0.7, -1.0, 2.7)
+    a, b = _both_strategies(v, f, c, r, rays, origin, H)
+    ref = oracle.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE,
+                              norm=oracle.NORM_SSE_TABLE)
+    for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+        _assert_bits(a[k], ref[k], f"scatter {k}")
+        _assert_bits(b[k], ref[k], f"lbvh {k}")
+    assert a["tri"][0] == a["tri"][3] == a["tri"][H * W - 1] == -1 and int((ref["tri"] >= 0).sum()) > 0
+    a, b = _both_strategies(v, f, c, r, rays, (np.nan, 0.0, 0.0), H)
+    assert np.all(a["tri"] == -1) and np.all(b["tri"] == -1) and np.all(a["range"] == 0) and np.all(b["range"] == 0)
+
+
 @pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
                                             ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
 def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):

@@ -29,8 +29,29 @@ for case in range(a.cases):
         v = (v * 30).astype(np.float32)
     origin = tuple(float(x) for x in rng.normal(size=3) * rng.choice([0.0, 0.1, 2.0]))
     rays = create_rays(up, down, H, W)
-    if rng.random() < 0.2:   # jittered grid: an irregular ray set
+    rk = rng.random()
+    if rk < 0.15:    # jittered grid: an irregular ray set
         rays = (rays + rng.normal(size=rays.shape).astype(np.float32) * 1e-3).astype(np.float32)
+    elif rk < 0.25:  # azimuth grid WITHOUT the duplicated seam column (W columns over [-pi, pi))
+        az = (-np.pi + 2 * np.pi * (np.arange(W) + rng.random()) / W)
+        el = np.deg2rad(np.linspace(up, down, H))
+        rays = np.stack([np.cos(el)[:, None] * np.cos(az)[None], np.cos(el)[:, None] * np.sin(az)[None],
+                         np.sin(el)[:, None] * np.ones(W)[None]], -1).reshape(-1, 3).astype(np.float32)
+    elif rk < 0.35:  # two beam blocks with different spacing (HDL-64 style): rows are not equidistant
+        el = np.deg2rad(np.concatenate([np.linspace(up, (up + down) / 2, H - H // 2, endpoint=False),
+                                        np.linspace((up + down) / 2, down, H // 2) ** 1.0]))[:H]
+        az = np.linspace(np.pi, -np.pi, W)
+        rays = np.stack([np.cos(el)[:, None] * np.cos(az)[None], np.cos(el)[:, None] * np.sin(az)[None],
+                         np.sin(el)[:, None] * np.ones(W)[None]], -1).reshape(-1, 3).astype(np.float32)
+    elif rk < 0.42:  # many rays share a direction: bins holding several rays (the grid's slot-range entries)
+        idx = rng.integers(0, rays.shape[0], size=rays.shape[0] // 3)
+        rays[idx] = rays[rng.integers(0, rays.shape[0], size=idx.size)] * rng.uniform(0.5, 3.0, (idx.size, 1)).astype(np.float32)
+    elif rk < 0.46:  # unnormalised, zero and non-finite rays
+        rays = (rays * rng.uniform(0.1, 50.0, (rays.shape[0], 1))).astype(np.float32)
+        broken = rng.integers(0, rays.shape[0], size=max(1, rays.shape[0] // 50))
+        rays[broken[: broken.size // 2]] = 0.0
+        rays[broken[broken.size // 2:], rng.integers(0, 3)] = np.nan
+    if os.environ.get('LT_STRESS_VERBOSE'): print(f'case {case}: H={H} W={W} kind={kind} rk={rk:.3f} tris={f.shape[0]} origin={origin}', flush=True)
     sc = Scene(0); t = [torch.from_numpy(x).to(dev) for x in (v, f, c, r)]
     sc.set_mesh(*t); rt = torch.from_numpy(rays).to(dev); rs = RaySet(rt, H)
     A = sc.render(rs, origin); sc.build(); B = sc.trace(rt, origin, H)
