@@ -274,6 +274,18 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   bin_rect R;
   R.na = 0; R.a0 = 0; R.e0 = 0; R.e1 = -1;
   const float q0 = x0 * x0 + y0 * y0, q1 = x1 * x1 + y1 * y1, q2 = x2 * x2 + y2 * y2;
+  // The bounds below are only sound while no intermediate overflows or is NaN (fminf / fmaxf drop NaN
+  // operands).  Sums, unlike maxima, propagate both, so one test guards the fast path:
+  if (!(q0 + q1 + q2 < 1e36f && fabsf(z0) + fabsf(z1) + fabsf(z2) < 1e18f)) {
+    //   a NaN or infinite coordinate (vertex or origin): the triangle test can never accept -- every chain
+    //     of products reaches t as NaN, +-inf or 0, none of which is recorded (Triangle.h:47, BVH.cpp:59);
+    //   finite coordinates beyond ~1e18 (a vertex flung far away: the sliver towards it CAN be hit): every bin.
+    const float sum = ((x0 + y0) + (z0 + x1)) + ((y1 + z1) + (x2 + y2)) + z2;  // NaN or +-inf iff one of them is
+    const float asum = ((fabsf(x0) + fabsf(y0)) + (fabsf(z0) + fabsf(x1))) + ((fabsf(y1) + fabsf(z1)) + (fabsf(x2) + fabsf(y2))) + fabsf(z2);
+    if (sum != sum || asum == INFINITY) return R;
+    R.e0 = 0; R.e1 = P.nb_el - 1; R.a0 = 0; R.na = P.nb_az;
+    return R;
+  }
   const float rho_max2 = fmaxf(q0, fmaxf(q1, q2));
   const float rho_max = f_sqrt(rho_max2);
   const float zmin = fminf(z0, fminf(z1, z2)), zmax = fmaxf(z0, fmaxf(z1, z2));

@@ -393,6 +393,32 @@ def test_non_finite_rays_and_origin_are_misses_on_a_deep_tree(oracle, H, W):
     assert np.all(a["tri"] == -1) and np.all(b["tri"] == -1) and np.all(a["range"] == 0) and np.all(b["range"] == 0)
 
 
+def test_broken_meshes_non_finite_and_huge_vertices(oracle):
+    """A mesh with NaN / infinite vertices, vertices flung 1e19 ... 1e30 m away (the sliver towards such a vertex
+    CAN be hit: only one factor of every product is huge) and degenerate faces.  The scatter strategy's angular
+    bounds overflow on such triangles (x^2 > FLT_MAX) and used to drop them; now they are tested against every
+    ray, and triangles with a non-finite vertex -- which the triangle test can never accept -- are skipped."""
+    rng = np.random.default_rng(5)
+    v, f, c, r = synth_scene(4, 20000)
+    v = v.copy(); f = f.copy()
+    vals = [np.nan, np.inf, -np.inf, 1e30, -1e30, 1e19, -3e18, 1e-30, 5e17]
+    for k, val in enumerate(vals * 3):
+        v[rng.integers(0, v.shape[0]), k % 3] = val
+    fd = rng.integers(0, f.shape[0], 50)
+    f[fd, 1] = f[fd, 0]
+    rays = create_rays(3, -25, 16, 128)
+    for origin in ((0.0, 0.0, 0.0), (0.3, -0.2, 0.1)):
+        a, b = _both_strategies(v, f, c, r, rays, origin, 16)
+        ref = oracle.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, 16, mode=oracle.MODE_BRUTE,
+                                  norm=oracle.NORM_SSE_TABLE)
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(a[k], ref[k], f"scatter {k} origin={origin}")
+            _assert_bits(b[k], ref[k], f"lbvh {k} origin={origin}")
+    hit_faces = set(ref["tri"][ref["tri"] >= 0].tolist())
+    huge = np.nonzero(np.abs(np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)).max(axis=1) > 1e17)[0]
+    assert any(set(f[t].tolist()) & set(huge.tolist()) for t in hit_faces), "no sliver towards a far vertex was hit"
+
+
 @pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
                                             ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
 def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):

@@ -27,6 +27,12 @@ for case in range(a.cases):
     else:  # low-poly: a handful of huge triangles (every one of them goes through the big-triangle queue)
         v, f, c, r = _adversarial_soup(rng, int(rng.integers(1, 40)))
         v = (v * 30).astype(np.float32)
+    if rng.random() < 0.12:  # broken mesh: non-finite / huge vertices, degenerate faces
+        v = v.copy(); f = f.copy()
+        k = max(1, v.shape[0] // 200)
+        v[rng.integers(0, v.shape[0], k), rng.integers(0, 3, k)] = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30], k)
+        fd = rng.integers(0, f.shape[0], max(1, f.shape[0] // 100))
+        f[fd, 1] = f[fd, 0]
     origin = tuple(float(x) for x in rng.normal(size=3) * rng.choice([0.0, 0.1, 2.0]))
     rays = create_rays(up, down, H, W)
     rk = rng.random()
