@@ -18,6 +18,8 @@ rng = np.random.default_rng(a.seed)
 bad = 0; tot_rays = tot_hits = tot_tris = 0
 for case in range(a.cases):
     H = int(rng.choice([1, 2, 5, 16, 64, 128])); W = int(rng.choice([1, 3, 64, 301, 1024, 2048, 4000]))
+    if rng.random() < 0.03: H, W = 5000, int(rng.choice([1, 3]))     # more rows than the bin grid has (4096)
+    elif rng.random() < 0.03: H, W = int(rng.choice([1, 2])), 10000  # more columns than the bin grid has (8192)
     up = float(rng.uniform(-5, 60)); down = float(up - rng.uniform(0.5, 80))
     kind = rng.integers(0, 3)
     if kind == 0:
@@ -33,7 +35,7 @@ for case in range(a.cases):
         v[rng.integers(0, v.shape[0], k), rng.integers(0, 3, k)] = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30], k)
         fd = rng.integers(0, f.shape[0], max(1, f.shape[0] // 100))
         f[fd, 1] = f[fd, 0]
-    origin = tuple(float(x) for x in rng.normal(size=3) * rng.choice([0.0, 0.1, 2.0]))
+    origin = tuple(float(x) for x in rng.normal(size=3) * rng.choice([0.0, 0.1, 2.0, 2.0, 1e3, 1e5]))
     rays = create_rays(up, down, H, W)
     rk = rng.random()
     if rk < 0.15:    # jittered grid: an irregular ray set
