@@ -220,6 +220,46 @@ def main():
             f6[f"{tag}_beam_angles"] = np.array(beam_angles)
     f6["H"], f6["W"], f6["fov_up"], f6["fov_down"] = 16, 128, 3.0, -25.0
     save("f6_range_projection", **f6)
+    # ---- F9: the projections at BASELINE scale (120 k points -> 64 x 2048) --------------------------------
+    # float64 clouds: checksums of every output.  float32 clouds: numpy's float32 arcsin / arctan2 kernels are not
+    # correctly rounded and differ between numpy builds and from any other libm in the last bit, which moves
+    # about one point in 1e5 across a pixel border -- the images are stored so that the test can count cells.
+    # `do_range_projection` orders equal depths with an UNSTABLE argsort (laserscan.py:262), so its cloud has no
+    # exact duplicates; `do_range_projection_new` has a defined tie rule (strict <, laserscan.py:352) and keeps them.
+    if wanted("f9_range_projection_full"):
+        f9 = {}
+        H, W, fu, fd = 64, 2048, 3.0, -25.0
+        for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
+            for fn in ("do_range_projection", "do_range_projection_new"):
+                key = f"{tag}_{'old' if fn == 'do_range_projection' else 'new'}"
+                pts, rem_p, lab = synth_cloud(21, 120_000, dtype=dtype, fov_up=fu, fov_down=fd)
+                if fn == "do_range_projection_new":
+                    pts[1000:1100] = pts[5000:5100]   # equal depth in the same cell
+                pts[7] = 0
+                f9[f"{key}_points_sha256"] = np.frombuffer(bytes.fromhex(sha(pts)), np.uint8)
+                scan = ls.SemLaserScan(H, W, 300, color_dict, None, None)
+                scan.points, scan.remissions, scan.label = pts.copy(), rem_p.copy(), lab.copy()
+                scan.colorize()
+                getattr(scan, fn)(fu, fd, remove=True)
+                outs = {"proj_range": scan.proj_range, "proj_remissions": scan.proj_remissions,
+                        "unproj_range": scan.unproj_range, "points_kept": scan.points}
+                if fn == "do_range_projection":
+                    outs.update(proj_idx=scan.proj_idx, proj_xyz=scan.proj_xyz, proj_mask=scan.proj_mask)
+                else:
+                    scan.do_label_projection_new()
+                    outs.update(index=scan.index, label_image=scan.label_image, proj_x=scan.proj_x, proj_y=scan.proj_y,
+                                proj_label=scan.proj_label)
+                for name, arr in outs.items():
+                    arr = np.asarray(arr)
+                    f9[f"{key}_{name}_sha256"] = np.frombuffer(bytes.fromhex(sha(arr)), np.uint8)
+                    f9[f"{key}_{name}_dtype"] = np.array(str(arr.dtype))
+                    f9[f"{key}_{name}_shape"] = np.array(arr.shape, np.int64)
+                if tag == "f32":
+                    f9[f"{key}_image_index"] = np.asarray(outs["proj_idx" if fn == "do_range_projection" else "index"])
+                    f9[f"{key}_image_range"] = np.asarray(outs["proj_range"])
+                f9[f"{key}_filled"] = int((np.asarray(outs["proj_range"]) > 0).sum())
+        f9["H"], f9["W"], f9["fov_up"], f9["fov_down"], f9["n_points"], f9["seed"] = H, W, fu, fd, 120_000, 21
+        save("f9_range_projection_full", **f9)
     # ---- F7: what follows the render -- reverse projection, write(), compare() -----------------------------
     import tempfile
     f7 = {}
