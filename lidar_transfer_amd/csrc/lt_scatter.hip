@@ -2,13 +2,15 @@
 //
 // Every call of the reference's `ctrace` casts all rays from ONE origin (RayTracer.cpp:58, :68).  For
 // that case the closest hit per ray can be computed without any hierarchy over the mesh: bin the rays
-// once by direction (azimuth x elevation), then stream the triangles -- each triangle computes a
-// conservative angular bounding rectangle as seen from the origin, visits the ray bins it overlaps, runs
-// the reference's Moller-Trumbore test (Triangle.h:27-50, identical float operations to lt_trace.hip)
-// against those rays only, and merges accepted hits with a 64-bit atomicMin on (t bits << 32 | face).
+// once by direction (azimuth x elevation, rays at the bin centres), then stream the triangles -- each
+// triangle computes conservative angular bounds as seen from the origin, visits the bins whose ray can lie
+// inside them (for a sensor grid: the rays inside the bounds, none for most sub-pixel triangles), runs the
+// reference's Moller-Trumbore test (Triangle.h:27-50, identical float operations to lt_trace.hip) against
+// those rays only, and merges accepted hits with a 64-bit atomicMin on (t bits << 32 | face).
 // The result is, by construction, the minimum over (t, face index) of all accepted triangles -- the same
 // tree-independent definition the LBVH path implements, hence bit-identical images -- but the work is one
-// coalesced pass over the mesh (HBM-bound), with no sort, no tree and no dependent pointer chase.
+// coalesced pass over the mesh with no sort, no tree and no dependent pointer chase; it is bound by the VALU
+// work of the angular bounds.
 //
 //   rayset (built once per sensor model, reused across scans):
 //     k_rs_dirs    normalise (Vector3.h:73-89), azimuth/elevation, elevation range partials
@@ -17,8 +19,9 @@
 //     k_rs_starts  first sorted slot of every bin
 //     k_rs_sortdirs / k_rs_grid  directions in bin order; one 16-B entry per bin (its ray, empty, or a slot range)
 //   per scan:
-//     k_sc_tris    one thread per triangle: bounds, candidate bins, MT, atomicMin; big triangles -> queue
-//     k_sc_rest    queued slices of heavy workgroups; one wave per queued big triangle
+//     k_sc_tris    256 triangles per workgroup: bounds, candidate bins, balanced MT rounds, atomicMin;
+//                  the excess of heavy workgroups and big triangles -> queues
+//     k_sc_rest    queued slices of heavy workgroups; up to 8 waves per queued big triangle
 //     k_sc_resolve one thread per ray: unpack (t, face), write-back (RayTracer.cpp:73-90), reset the cell
 #include "lt_internal.h"
 #include <math.h>
