@@ -12,10 +12,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from test_trace_gpu import _adversarial_soup
 
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--oracle", action="store_true", help="also compare with the brute-force CPU oracle where tris x rays < 3e7")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(a.seed)
-bad = 0; tot_rays = tot_hits = tot_tris = 0
+bad = 0; tot_rays = tot_hits = tot_tris = 0; n_or = 0
 for case in range(a.cases):
     H = int(rng.choice([1, 2, 5, 16, 64, 128])); W = int(rng.choice([1, 3, 64, 301, 1024, 2048, 4000]))
     if rng.random() < 0.03: H, W = 5000, int(rng.choice([1, 3]))     # more rows than the bin grid has (4096)
@@ -65,10 +66,18 @@ for case in range(a.cases):
     A = sc.render(rs, origin); sc.build(); B = sc.trace(rt, origin, H)
     same = all(torch.equal(A[k].view(torch.int32), B[k].view(torch.int32)) for k in ("tri", "range", "endpoints", "endcolors", "endrem"))
     tot_rays += H * W; tot_hits += int((A['tri'] >= 0).sum()); tot_tris += int(f.shape[0])
+    if a.oracle and f.shape[0] * H * W < 3e7:
+        from oracle import binding as ob
+        ref = ob.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, H, mode=ob.MODE_BRUTE, norm=ob.NORM_SSE_TABLE)
+        n_or += 1
+        for k in ("tri", "range", "endpoints", "endcolors", "endrem"):
+            if not np.array_equal(A[k].cpu().numpy().reshape(-1).view(np.int32), np.ascontiguousarray(ref[k]).reshape(-1).view(np.int32)):
+                same = False
+                print(f"ORACLE MISMATCH case {case}: {k}")
     if not same:
         bad += 1
         nd = int((A["tri"] != B["tri"]).sum())
         print(f"MISMATCH case {case}: H={H} W={W} fov=({up:.2f},{down:.2f}) kind={kind} tris={f.shape[0]} origin={origin} differing rays={nd}")
     rs.close(); sc.close()
-print(f"{a.cases} cases, {bad} mismatches; {tot_tris} triangles, {tot_rays} rays, {tot_hits} hits")
+print(f"{a.cases} cases, {bad} mismatches; {tot_tris} triangles, {tot_rays} rays, {tot_hits} hits; {n_or} cases also against the brute-force oracle")
 sys.exit(1 if bad else 0)
