@@ -150,3 +150,57 @@ def test_projection_at_baseline_scale_vs_reference(tag, method):
         assert abs(int((rng_img > 0).sum()) - int(g[f"{key}_filled"])) <= 4
     else:
         assert int((np.asarray(outs["proj_range"]) > 0).sum()) == int(g[f"{key}_filled"])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_projection_fuzz_vs_cpu_restatement(seed):
+    """Random clouds, image shapes, fields of view, beam tables and removal modes: the HIP projections against
+    oracle/projection.py (itself pinned to the reference's arrays in tests/test_oracle_cpu.py).  float64 clouds must
+    match exactly; float32 clouds may differ in the few cells numpy's float32 arcsin / arctan2 rounding moves."""
+    from oracle import projection as op
+    from lidar_transfer_amd.laserscan import SemLaserScan
+    rng = np.random.default_rng(1000 + seed)
+    H = int(rng.choice([1, 4, 16, 64])); W = int(rng.choice([1, 16, 128, 2048]))
+    fu = float(rng.uniform(-5, 40)); fd = float(fu - rng.uniform(1, 70))
+    n = int(rng.choice([0, 1, 7, 500, 20000, 60000]))
+    dtype = np.float32 if seed % 3 == 0 else np.float64
+    remove = bool(seed % 2 == 0)
+    method = "new" if seed % 4 < 2 else "old"
+    beams = list(np.deg2rad(np.sort(rng.uniform(fd, fu, H))[::-1])) if seed % 5 == 0 and H > 1 else None
+    r = rng.uniform(0.5, 80.0, n); yaw = rng.uniform(-np.pi, np.pi, n)
+    pitch = np.deg2rad(rng.uniform(fd - 3, fu + 3, n) if remove else rng.uniform(fd, fu, n))
+    pts = np.stack([r * np.cos(pitch) * np.cos(yaw), r * np.cos(pitch) * np.sin(yaw), r * np.sin(pitch)], 1).astype(dtype)
+    if n >= 500:
+        pts[10:60] = pts[100:150]            # exact duplicates: depth ties in one cell
+        pts[200:230] *= dtype(2.0)           # same pixel, different depth
+        if remove or method == "new":
+            pts[5] = 0                       # depth 0 (the old method without `remove` divides by it: not a valid input)
+    rem = rng.uniform(0, 1, n).astype(np.float32)
+    lab = rng.choice(list(COLOR_DICT.keys()), n).astype(np.uint32)
+    scan = SemLaserScan(H, W, 300, COLOR_DICT, None, beams)
+    scan.points, scan.remissions, scan.label = pts.copy(), rem.copy(), lab.copy()
+    scan.colorize()
+    if method == "old":
+        scan.do_range_projection(fu, fd, remove=remove)
+        scan.do_label_projection()
+        got_index, got_range = scan.proj_idx, scan.proj_range
+    else:
+        scan.do_range_projection_new(fu, fd, remove=remove)
+        scan.do_label_projection_new()
+        got_index, got_range = scan.index, scan.range_image
+    o = op.range_projection(pts, rem, H, W, fu, fd, beam_angles=beams, remove=remove, method=method)
+    exp_label = op.label_projection(o["index"], lab[o["kept"]])
+    if dtype == np.float64:
+        assert np.array_equal(scan.points, pts[o["kept"]])
+        assert np.array_equal(scan.unproj_range, o["unproj_range"])
+        assert np.array_equal(got_index, o["index"]), f"{int((got_index != o['index']).sum())} cells differ"
+        assert np.array_equal(np.asarray(got_range).view(np.int32), o["range"].view(np.int32))
+        assert np.array_equal(scan.proj_remissions, o["remission"])
+        assert np.array_equal(scan.proj_label, exp_label)
+        if method == "old":
+            assert np.array_equal(scan.proj_xyz, o["xyz"]) and np.array_equal(scan.proj_mask, o["mask"])
+    else:
+        assert abs(scan.points.shape[0] - o["kept"].shape[0]) <= 2
+        if scan.points.shape[0] == o["kept"].shape[0]:
+            bad = (got_index != o["index"]) | (np.asarray(got_range).view(np.int32) != o["range"].view(np.int32))
+            assert int(bad.sum()) <= 6, f"{int(bad.sum())} cells differ"
