@@ -1,0 +1,16 @@
+"""CPU restatements of the reference's algorithms -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` leg may import this package; the product
+(`lidar_transfer_amd/`) never does and fails loudly when its HIP library is missing.
+
+  lt_oracle.c / binding.py   ray cast: the reference's BVH + traversal restated, brute force, LBVH model
+                             (pinned against oracle/_ref = the reference's own C++ compiled in place, and the
+                             golden vectors F2-F5)
+  projection.py              do_range_projection / do_range_projection_new / label projection in numpy
+                             (pinned against the reference's own arrays, golden vectors F6 and F9)
+  lt_tsdf_oracle.c           TSDF `integrate` CUDA source restated in C (parity unpinned for the class-aware branch:
+                             the reference kernel cannot be executed here; the plain-average branch is pinned
+                             against the reference's numpy CPU mode, golden F8)
+  gen_rsqrt_table.c          measures and exhaustively verifies the x86 RSQRTSS table the kernels replay
+  Makefile                   builds liblt_oracle.so and oracle/_ref/ (needs /root/reference for the latter)
+"""
