@@ -75,3 +75,28 @@ def test_compare_vs_reference_python(g):
     assert abs(r["m_acc"] - float(g["cmp_m_acc"])) < 1e-12
     # numpy sums the float32 image pairwise in float32; the kernel accumulates in float64
     assert abs(r["MSE"] - float(g["cmp_mse"])) < 1e-6 * max(float(g["cmp_mse"]), 1e-12) + 1e-9
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pack_scan_fuzz_vs_numpy_filter(seed):
+    """Stable compaction at image scale (up to 128 x 2048 cells) against the reference's filter chain restated
+    in numpy (laserscan.py:1138-1154): `index > 0` (cp adaption only), `label >= 0`, `sum(xyz) != 0` -- evaluated
+    in the dtype of the points, so a float32 and a float64 image can keep different points."""
+    from lidar_transfer_amd.post import pack_scan
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 63, 4096, 131072, 262144]))
+    dtype = np.float32 if seed % 2 else np.float64
+    pts = rng.normal(size=(n, 3)).astype(dtype) * 30
+    pts[rng.random(n) < 0.3] = 0                                   # misses
+    k = rng.random(n) < 0.05
+    pts[k, 2] = -(pts[k, 0] + pts[k, 1])                           # x + y + z == 0 without being (0, 0, 0) (sic)
+    lab = rng.integers(-1, 260, n).astype(np.int32)
+    rem = rng.uniform(0, 1, n).astype(np.float32)
+    index = rng.integers(-1, 50, n).astype(np.int32) if seed % 3 == 0 else None
+    b, l = pack_scan(pts, lab, rem, index=index)
+    keep = np.ones(n, bool) if index is None else index > 0
+    keep &= lab >= 0
+    keep &= np.sum(pts, axis=1) != 0
+    exp_b = np.concatenate([pts[keep].astype(np.float32), rem[keep][:, None]], axis=1)
+    assert b.shape == exp_b.shape and np.array_equal(b.view(np.int32), exp_b.view(np.int32))
+    assert np.array_equal(l, lab[keep].astype(np.uint32))
