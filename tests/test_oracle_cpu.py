@@ -290,3 +290,32 @@ def test_projection_restatement_at_baseline_scale_f64(method):
     assert sha(o["index"]) == bytes(g[f"{k}_{'proj_idx' if method == 'old' else 'index'}_sha256"])
     if method == "old":
         assert sha(o["xyz"]) == bytes(g[f"{k}_proj_xyz_sha256"]) and sha(o["mask"]) == bytes(g[f"{k}_proj_mask_sha256"])
+
+
+# ---- the product has no CPU path --------------------------------------------------------------------------------------
+def test_product_never_imports_the_oracle_and_fails_loudly_without_its_library(monkeypatch, tmp_path):
+    """`oracle/` is test infrastructure: nothing under lidar_transfer_amd/ may import it, and without liblidarhip.so
+    (and without a compiler to build it) every entry point must raise instead of computing something else."""
+    import re
+    pkg = os.path.join(ROOT, "lidar_transfer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{fn} imports the oracle"
+    from lidar_transfer_amd import _lib, build as _build
+    from lidar_transfer_amd.raytracer import C_Trace
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_build, "LIB_PATH", str(tmp_path / "liblidarhip.so"))
+    monkeypatch.setattr(_build, "needs_build", lambda: True)
+
+    def no_compiler(*a, **k):
+        raise RuntimeError("hipcc not found")
+    monkeypatch.setattr(_build, "build_lib", no_compiler)
+    with pytest.raises(RuntimeError, match="liblidarhip.so is missing"):
+        _lib.load()
+    z3, z = np.zeros(3, np.float32), np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError, match="liblidarhip.so is missing"):
+        C_Trace(np.array([1, 0, 0], np.float32), z3, np.zeros(9, np.float32), np.array([0, 1, 2], np.int32),
+                np.zeros(9, np.int32), np.zeros(3, np.float32), z3.copy(), np.zeros(3, np.int32), z.copy(), z.copy(),
+                1, 1)
