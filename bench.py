@@ -62,6 +62,9 @@ def parse():
                          "scan does not find its mesh cached from the last time round)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "16")),
                     help="scans in flight per GPU (HIP streams)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LT_BENCH_BATCH", "8")),
+                    help="scans per lt_scene_render_batch_dev call (scatter strategy, at most 8; 1 = one call per scan); "
+                         "--streams / --batch batches are in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other strategy")
     ap.add_argument("--cpu-reps", type=int, default=0, help="reference runs for the CPU baseline (0 = auto)")
@@ -230,6 +233,42 @@ def main():
             if rc:
                 _lib.check(rc, "bench step")
 
+        # Scatter strategy, batched: BATCH consecutive scans (each its own mesh, worker and images) go to the GPU with
+        # ONE call = three kernel launches for all of them (lt_scene_render_batch_dev); worker w always runs on
+        # stream (w // BATCH) % len(streams), so a worker is never in two batches at a time.
+        BATCH = args.batch if strategy == "scatter" else 1
+        if BATCH > 1:
+            assert S % BATCH == 0, "--streams must be a multiple of --batch"
+            n_groups = S // BATCH
+            arr = lambda vals: (vp * BATCH)(*vals)  # noqa: E731
+            grp_scenes = [arr([wh[g * BATCH + j] for j in range(BATCH)]) for g in range(n_groups)]
+            grp_rays = [arr([rh[g * BATCH + j] for j in range(BATCH)]) for g in range(n_groups)]
+            grp_out = [{k: arr([sp[g * BATCH + j][k] for j in range(BATCH)]) for k in ("endpoints", "endrem", "tri",
+                                                                                       "range", "endcolors")}
+                       for g in range(n_groups)]
+            org_b = (C.c_float * (3 * BATCH))(*(list(origin) * BATCH))
+            if keep:  # the range / colour images of the timed scans go to their slots
+                slot_rng = [arr([rng_p[min(b * BATCH + j, K - 1)] for j in range(BATCH)]) for b in range((K + BATCH - 1) // BATCH)]
+                slot_col = [arr([col_p[min(b * BATCH + j, K - 1)] for j in range(BATCH)]) for b in range((K + BATCH - 1) // BATCH)]
+
+        def step_batch(i0, nb, slot0=None, timed=False):
+            """Scans i0 .. i0 + nb - 1 (nb <= BATCH) as one batch."""
+            g = (i0 // BATCH) % n_groups
+            rc = 0
+            for j in range(nb):
+                rc |= lib.lt_scene_set_mesh_dev(wh[g * BATCH + j], *mesh_args[(i0 + j) % len(scenes)])
+            b = i0 // BATCH
+            if timed and b % PROBE_EVERY == 0:
+                rc |= lib.lt_scene_set_probe(wh[g * BATCH], *pr[b // PROBE_EVERY])
+            o = grp_out[g]
+            use_slots = keep and slot0 is not None
+            rc |= lib.lt_scene_render_batch_dev(nb, grp_scenes[g], grp_rays[g], org_b, o["endpoints"],
+                                                slot_col[b] if use_slots else o["endcolors"],
+                                                slot_rng[b] if use_slots else o["range"], o["endrem"], o["tri"], FL,
+                                                sh[g])
+            if rc:
+                _lib.check(rc, "bench step (batch)")
+
         def gather_chunk(c):
             c0, c1 = bounds[c], bounds[c + 1]
             cur = torch.cuda.current_stream(dev)
@@ -255,8 +294,12 @@ def main():
                     lst = [recv[c][k][r] for r in range(world)] if rank == 0 else None
                     works.append(dist.gather(src, gather_list=lst, dst=0, async_op=True))
 
-        for i in range(Wm):
-            step(i)
+        if BATCH > 1:
+            for i in range(0, Wm, BATCH):
+                step_batch(i, min(BATCH, Wm - i))
+        else:
+            for i in range(Wm):
+                step(i)
         torch.cuda.synchronize()
         if do_gather:  # warm-up of the collective too: RCCL sets up its peer-to-peer channels lazily
             # ... and of the exact torch ops gather_chunk uses (the first strided-gather / copy kernel of a process
@@ -280,11 +323,21 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         chunk = 0
-        for i in range(K):
-            step(i, slot=i, timed=True)
-            if do_gather and i + 1 == bounds[chunk + 1]:
-                gather_chunk(chunk)
-                chunk += 1
+        if BATCH > 1:
+            for i in range(0, K, BATCH):
+                nb = min(BATCH, K - i)
+                step_batch(i, nb, slot0=i, timed=True)
+                while do_gather and chunk < n_chunks and i + nb >= bounds[chunk + 1]:
+                    gather_chunk(chunk)
+                    chunk += 1
+            n_probed = ((K + BATCH - 1) // BATCH + PROBE_EVERY - 1) // PROBE_EVERY
+        else:
+            for i in range(K):
+                step(i, slot=i, timed=True)
+                if do_gather and i + 1 == bounds[chunk + 1]:
+                    gather_chunk(chunk)
+                    chunk += 1
+            n_probed = len(probes)
         for wk in works:
             wk.wait()
         for st in streams:
@@ -298,7 +351,7 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probes])) if probes else float("nan")
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probes[:n_probed]])) if probes else float("nan")
         hits = int((range_all[K - 1] > 0).sum().item()) if keep else -1
         if recv is not None:  # rank 0 really holds every rank's images
             assert torch.equal(recv[-1][0][0, -1], range_all[K - 1])
@@ -318,6 +371,7 @@ def main():
     torch.cuda.synchronize()
 
     def roofline(strategy, kern_ms):
+        spl = args.batch if strategy == "scatter" else 1  # scans per launch of the dominant kernel
         c = np.mean(np.array(cnt[strategy], dtype=np.float64), axis=0)
         if strategy == "scatter":
             alg = n_faces * SC_B_TRI + c[1] * SC_B_TEST + c[2] * SC_B_HIT
@@ -326,14 +380,17 @@ def main():
         else:
             alg = c[0] * LB_B_NODE + c[1] * LB_B_TRI + R * LB_B_RAY
             extra = {"kernel": "k_trace4", "nodes_per_ray": round(c[0] / R, 2), "tris_per_ray": round(c[1] / R, 2)}
+        alg_scan = alg
+        alg = alg * spl
         ach = alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section); collected on workload C2 only
         # (profiles/r01/e_pmc_scatter.txt: k_sc_tris; profiles/r01/b_pmc_lbvh.txt: k_trace4)
-        traffic = {"scatter": 45.0e6, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
+        traffic = {"scatter": 45.0e6 * spl, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
         d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
-             "algorithmic_bytes_per_launch": int(alg),
+             "algorithmic_bytes_per_launch": int(alg), "scans_per_launch": spl,
+             "algorithmic_bytes_per_scan": int(alg_scan),
              "probe": f"HIP events on the launch stream around every {PROBE_EVERY}th launch of the timed region"}
         d.update(extra)
         return d
@@ -373,8 +430,8 @@ def main():
         value = world * K * R / dt / 1e6
         rl = roofline(args.strategy, kern_ms)
         rl["isolated"] = {"avg_kernel_ms": round(iso_ms, 5),
-                          "achieved": round(rl["algorithmic_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9, 1),
-                          "frac": round(rl["algorithmic_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "achieved": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9, 1),
+                          "frac": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "same kernel, one scan at a time on an idle GPU, measured after the timed region"}
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
@@ -386,7 +443,7 @@ def main():
                                    f"{len(scenes)} distinct scenes cycled",
                        "strategy": args.strategy,
                        "parallelism": f"scan-parallel x{world}" + (f", range f32 + label {str(label_dtype)[6:]} images gathered to rank 0 over RCCL (8 chunks, overlapped)" if dist.is_initialized() else ""),
-                       "streams_per_gpu": S},
+                       "streams_per_gpu": S, "scans_per_call": args.batch if args.strategy == "scatter" else 1},
             "scans_per_s": round(world * K / dt, 2),
             "hit_fraction": round(hits / R, 4),
             "roofline": rl,

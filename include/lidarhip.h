@@ -139,6 +139,18 @@ int lt_scene_render_dev(lt_scene* scene, lt_rayset* rayset, const float* origin,
                         int* endcolors, float* range, float* endrem, int* tri, unsigned flags, void* stream,
                         lt_stats* stats);
 
+/* The same for up to 8 scans in ONE call -- n_scans (scene, rayset) pairs, each scene with its own current
+ * mesh, each rayset distinct; origins[3 * i ..] is scan i's origin (HOST), the output arguments are HOST arrays
+ * of n_scans DEVICE pointers (an array, or single entries of it, may be NULL).  The three kernels of the
+ * scatter strategy are launched once for the whole batch instead of once per scan: with tens of thousands of
+ * scans per second, the time a hardware queue spends between small kernels is what limits throughput
+ * (DESIGN.md section 9).  Results are those of n_scans separate lt_scene_render_dev calls.  Asynchronous;
+ * LT_TRACE_COUNT is not accepted. */
+int lt_scene_render_batch_dev(int n_scans, lt_scene* const* scenes, lt_rayset* const* raysets,
+                              const float* origins, float* const* endpoints, int* const* endcolors,
+                              float* const* range, float* const* endrem, int* const* tri, unsigned flags,
+                              void* stream);
+
 /* Measurement hook: record the caller's two hipEvent_t (passed as void*) on the launch stream immediately
  * before and after the dominant kernel (k_sc_tris / k_trace4) of the NEXT lt_scene_render_dev /
  * lt_scene_trace_dev call; one shot, no synchronisation.  bench.py uses it for the roofline figure. */

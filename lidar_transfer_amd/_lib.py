@@ -23,7 +23,7 @@ LT_TSDF_MERGE = 1
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
            "lt_scene_build", "lt_scene_trace_dev", "lt_scene_status", "lt_scene_destroy", "lt_last_error",
            "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection", "lt_rayset_create_dev",
-           "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
+           "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_render_batch_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
            "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
            "lt_tsdf_volumes", "lt_tsdf_destroy"]
 
@@ -93,6 +93,9 @@ def load():
     lib.lt_rayset_destroy.restype = C.c_int
     lib.lt_scene_render_dev.argtypes = [vp, vp, fp, vp, vp, vp, vp, vp, C.c_uint, vp, sp]
     lib.lt_scene_render_dev.restype = C.c_int
+    pvp = C.POINTER(vp)
+    lib.lt_scene_render_batch_dev.argtypes = [C.c_int, pvp, pvp, fp, pvp, pvp, pvp, pvp, pvp, C.c_uint, vp]
+    lib.lt_scene_render_batch_dev.restype = C.c_int
     lib.lt_reverse_projection_dev.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]
     lib.lt_reverse_projection_dev.restype = C.c_int
     lib.lt_pack_scan_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp]

@@ -557,22 +557,45 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
   }
 }
 
-// One workgroup = 256 consecutive triangles: phase A, prefix sum, phase B over its first ~LT_SC_CAP
+// ---- one launch, several scans ------------------------------------------------------------------------------------
+// A scan is three small kernels; with one launch per kernel and scan, the hardware queues spend more time
+// between kernels than the kernels need.  Every kernel below therefore takes a BATCH of
+// scans: the per-scan arguments live in a job table passed by value (kernel arguments: scalar registers), and a
+// workgroup looks up its scan from its block index.  A batch of one is the single-scan API.
+#define LT_SC_MAX_BATCH 8
+struct sc_job {
+  const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
+  const rs_params* prm; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set
+  unsigned long long* cell; int* large; int* large_count; int2* slices;
+  unsigned* flags; unsigned long long* counters;
+  float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
+  float ox, oy, oz;
+  int n_verts, n_faces, n_rays, cap_slices;
+  unsigned out_flags;
+  int tris_block0;     // first workgroup of this scan in k_sc_tris
+  int resolve_block0;  // ... in k_sc_resolve
+};
+struct sc_batch {
+  int n;
+  int tris_blocks, resolve_blocks;  // grid sizes
+  sc_job job[LT_SC_MAX_BATCH];
+};
+
+// One workgroup = 256 consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~LT_SC_CAP
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
 template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                 int n_verts, int n_faces, float ox, float oy, float oz,
-                                                 const rs_params* __restrict__ prm, const float4* __restrict__ grid,
-                                                 const float4* __restrict__ sdirs,
-                                                 unsigned long long* __restrict__ cell, int* __restrict__ large,
-                                                 int* __restrict__ large_count, int2* __restrict__ slices,
-                                                 int cap_slices, unsigned* __restrict__ flags,
-                                                 unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   __shared__ sc_shared S;
+  int j = 0;
+  while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].tris_block0) ++j;
+  const sc_job& J = B.job[j];
+  const int lb = (int)blockIdx.x - J.tris_block0;  // workgroup index inside the scan
   const int tid = threadIdx.x;
-  const int first = blockIdx.x * 256;
-  const rs_params P = *prm;
-  const int cnt = sc_setup<true, WIDE>(S, verts, faces, n_verts, n_faces, first + tid, ox, oy, oz, P, large, large_count, flags);
+  const int first = lb * 256;
+  const rs_params P = *J.prm;
+  const float ox = J.ox, oy = J.oy, oz = J.oz;
+  const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P, J.large,
+                                       J.large_count, J.flags);
   int total;
   const int mypre = sc_prefix(S, cnt, total);
   // The workgroup keeps the triangles that start below LT_SC_CAP; exactly one thread sees the crossing and
@@ -583,11 +606,11 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
     int kept = mypre + cnt;
     const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
     if (n_sl > 0) {
-      const int base = atomicAdd(&large_count[1], n_sl);
-      if (base + n_sl <= cap_slices) {
-        for (int k = 0; k < n_sl; ++k) slices[base + k] = make_int2((int)blockIdx.x, kept + k * LT_SC_SLICE);
+      const int base = atomicAdd(&J.large_count[1], n_sl);
+      if (base + n_sl <= J.cap_slices) {
+        for (int k = 0; k < n_sl; ++k) J.slices[base + k] = make_int2(lb, kept + k * LT_SC_SLICE);
       } else {
-        atomicSub(&large_count[1], n_sl);
+        atomicSub(&J.large_count[1], n_sl);
         kept = total;
       }
     }
@@ -595,47 +618,50 @@ __global__ __launch_bounds__(256) void k_sc_tris(const float* __restrict__ verts
   }
   __syncthreads();
   unsigned n_tests = 0, n_cand = 0;
-  sc_round_robin<COUNT, WIDE>(S, P, grid, sdirs, cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
-  sc_count<COUNT>(n_tests, n_cand, counters);
+  sc_round_robin<COUNT, WIDE>(S, P, J.grid, J.sdirs, J.cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
+  sc_count<COUNT>(n_tests, n_cand, J.counters);
 }
 
-// The rest: (1) queued slices of heavy workgroups -- a workgroup redoes phase A of that triangle block (same
-// code, same prefix sums) and tests one slice of its candidates; (2) big triangles, one wave each, lanes
-// stride over the candidate bins.
+// The rest, LT_SC_REST_BLOCKS workgroups per scan: (1) queued slices of heavy workgroups -- a workgroup redoes
+// phase A of that triangle block (same code, same prefix sums) and tests one slice of its candidates; (2) big
+// triangles, up to LT_SC_PARTS waves each, lanes stride over the candidate bins.
 #define LT_SC_REST_BLOCKS 512
 #define LT_SC_PARTS 8
 template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                 int n_verts, int n_faces, float ox, float oy, float oz,
-                                                 const rs_params* __restrict__ prm, const float4* __restrict__ grid,
-                                                 const float4* __restrict__ sdirs,
-                                                 unsigned long long* __restrict__ cell, const int* __restrict__ large,
-                                                 const int* __restrict__ large_count, const int2* __restrict__ slices,
-                                                 int cap_slices, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   __shared__ sc_shared S;
-  const rs_params P = *prm;
-  const int n_large = large_count[0], n_slices = min(large_count[1], cap_slices);
+  const sc_job& J = B.job[blockIdx.x / LT_SC_REST_BLOCKS];
+  const int rb = blockIdx.x % LT_SC_REST_BLOCKS;
+  if (J.n_faces <= 0) return;
+  const float* __restrict__ verts = J.verts;
+  const int* __restrict__ faces = J.faces;
+  const float4* __restrict__ grid = J.grid;
+  const float4* __restrict__ sdirs = J.sdirs;
+  unsigned long long* __restrict__ cell = J.cell;
+  const float ox = J.ox, oy = J.oy, oz = J.oz;
+  const rs_params P = *J.prm;
+  const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
   unsigned n_tests = 0, n_cand = 0;
-  for (int q = blockIdx.x; q < n_slices; q += gridDim.x) {
-    const int2 sl = slices[q];
+  for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
+    const int2 sl = J.slices[q];
     const int first = sl.x * 256;
-    const int cnt = sc_setup<false, WIDE>(S, verts, faces, n_verts, n_faces, first + (int)threadIdx.x, ox, oy, oz, P, nullptr,
-                                    nullptr, nullptr);
+    const int cnt = sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first + (int)threadIdx.x, ox, oy, oz, P,
+                                          nullptr, nullptr, nullptr);
     int total;
     (void)sc_prefix(S, cnt, total);
     __syncthreads();
     sc_round_robin<COUNT, WIDE>(S, P, grid, sdirs, cell, first, sl.y, min(sl.y + LT_SC_SLICE, total), ox, oy, oz, n_tests,
-                          n_cand);
+                                n_cand);
     __syncthreads();  // LDS is reused by the next slice
   }
   const int lane = threadIdx.x & 63;
-  const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave0 = rb * 4 + (threadIdx.x >> 6), nwaves = LT_SC_REST_BLOCKS * 4;
   // A big triangle is shared by up to LT_SC_PARTS waves (a ground triangle under the sensor of a low-poly
   // scene covers tens of thousands of bins): work item v = (triangle q, part p); every wave of a triangle
   // recomputes its bounds, part p takes the candidates p*64 + lane, stride 64 * (parts this triangle needs).
   for (int v = wave0; v < n_large * LT_SC_PARTS; v += nwaves) {
     const int q = v / LT_SC_PARTS, part = v - q * LT_SC_PARTS;
-    const int f = large[q];
+    const int f = J.large[q];
     const float* pa = verts + 3 * (size_t)faces[3 * (size_t)f];
     const float* pb = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
     const float* pc = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
@@ -658,43 +684,46 @@ __global__ __launch_bounds__(256) void k_sc_rest(const float* __restrict__ verts
       sc_test_cell<WIDE>(T, f, grid[e * P.nb_az + az], sdirs, ox, oy, oz, cell, n_tests);
     }
   }
-  sc_count<COUNT>(n_tests, n_cand, counters);
+  sc_count<COUNT>(n_tests, n_cand, J.counters);
 }
 
 // one thread per ray: unpack the winning (t, face), write back as RayTracer.cpp:73-90, re-arm the cell
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_sc_resolve(unsigned long long* __restrict__ cell,
-                                                    const float4* __restrict__ dirs, int n_rays, float ox, float oy,
-                                                    float oz, const int* __restrict__ faces,
-                                                    const int* __restrict__ colors, const float* __restrict__ rem,
-                                                    float* __restrict__ endpoints, int* __restrict__ endcolors,
-                                                    float* __restrict__ range, float* __restrict__ endrem,
-                                                    int* __restrict__ tri_out, unsigned flags,
-                                                    int* __restrict__ large_count,
-                                                    unsigned long long* __restrict__ counters) {
-  const int ray = blockIdx.x * 256 + threadIdx.x;
-  if (ray == 0) { large_count[0] = 0; large_count[1] = 0; }
+__global__ __launch_bounds__(256) void k_sc_resolve(const sc_batch B) {
+  int j = 0;
+  while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].resolve_block0) ++j;
+  const sc_job& J = B.job[j];
+  const int ray = ((int)blockIdx.x - J.resolve_block0) * 256 + threadIdx.x;
+  unsigned long long* __restrict__ cell = J.cell;
+  const int* __restrict__ faces = J.faces;
+  float* __restrict__ endpoints = J.endpoints;
+  int* __restrict__ endcolors = J.endcolors;
+  float* __restrict__ range = J.range;
+  float* __restrict__ endrem = J.endrem;
+  int* __restrict__ tri_out = J.tri;
+  const unsigned flags = J.out_flags;
+  if (ray == 0) { J.large_count[0] = 0; J.large_count[1] = 0; }
   bool hit = false;
-  if (ray < n_rays) {
+  if (ray < J.n_rays) {
     const unsigned long long key = cell[ray];
     cell[ray] = LT_EMPTY_KEY;
     hit = key != LT_EMPTY_KEY;
     if (hit) {
       const float t = __uint_as_float((unsigned)(key >> 32));
       const int face = (int)(unsigned)(key & 0xFFFFFFFFull);
-      const float4 d = dirs[ray];
+      const float4 d = J.dirs[ray];
       const int i0 = faces[3 * (size_t)face], i1 = faces[3 * (size_t)face + 1], i2 = faces[3 * (size_t)face + 2];
       if (endpoints) {
-        endpoints[3 * (size_t)ray] = ox + d.x * t;
-        endpoints[3 * (size_t)ray + 1] = oy + d.y * t;
-        endpoints[3 * (size_t)ray + 2] = oz + d.z * t;
+        endpoints[3 * (size_t)ray] = J.ox + d.x * t;
+        endpoints[3 * (size_t)ray + 1] = J.oy + d.y * t;
+        endpoints[3 * (size_t)ray + 2] = J.oz + d.z * t;
       }
       if (endcolors) {
-        endcolors[3 * (size_t)ray] = (int)(float)colors[3 * (size_t)i0];
-        endcolors[3 * (size_t)ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
-        endcolors[3 * (size_t)ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+        endcolors[3 * (size_t)ray] = (int)(float)J.colors[3 * (size_t)i0];
+        endcolors[3 * (size_t)ray + 1] = (int)(float)J.colors[3 * (size_t)i0 + 1];
+        endcolors[3 * (size_t)ray + 2] = (int)(float)J.colors[3 * (size_t)i0 + 2];
       }
-      if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
+      if (endrem) endrem[ray] = ((J.rem[i0] + J.rem[i1]) + J.rem[i2]) / 3.0f;
       if (range) range[ray] = t;
       if (tri_out) tri_out[ray] = face;
     } else if (flags & LT_TRACE_WRITE_MISSES) {
@@ -709,7 +738,7 @@ __global__ __launch_bounds__(256) void k_sc_resolve(unsigned long long* __restri
     unsigned long long vh = hit ? 1u : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vh += __shfl_xor(vh, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&counters[2], vh);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&J.counters[2], vh);
   }
 }
 
@@ -859,6 +888,73 @@ static int rs_reserve_large(lt_rayset* r, int n_faces) {
   return LT_OK;
 }
 
+// ---- launching a batch -----------------------------------------------------------------------------------------------
+struct sc_item {  // host view of one scan of a batch
+  lt_scene* s;
+  lt_rayset* r;
+  const float* origin;
+  float* endpoints; int* endcolors; float* range; float* endrem; int* tri;
+};
+
+// Three launches for the whole batch (k_sc_tris, k_sc_rest, k_sc_resolve) on `stream`.  `probe` = the scene
+// whose probe events (lt_scene_set_probe) are recorded around k_sc_tris, or nullptr.
+static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipStream_t stream, bool count,
+                           lt_scene* probe) {
+  sc_batch B;
+  memset(&B, 0, sizeof(B));
+  bool wide = false;
+  int tb = 0, rb = 0;
+  for (int i = 0; i < n_items; ++i) {
+    lt_scene* s = it[i].s;
+    lt_rayset* r = it[i].r;
+    const int n = s->n_faces, R = r->n_rays;
+    if (R <= 0) continue;  // nothing to write for this scan
+    LT_CHECK(rs_reserve_large(r, n));
+    sc_job& J = B.job[B.n++];
+    J.verts = s->verts; J.faces = s->faces; J.colors = s->colors; J.rem = s->rem;
+    J.prm = r->prm; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
+    J.cell = r->cell; J.large = r->large; J.large_count = r->large_count; J.slices = r->slices;
+    J.flags = s->flags; J.counters = s->counters;
+    J.endpoints = it[i].endpoints; J.endcolors = it[i].endcolors; J.range = it[i].range; J.endrem = it[i].endrem;
+    J.tri = it[i].tri;
+    J.ox = it[i].origin[0]; J.oy = it[i].origin[1]; J.oz = it[i].origin[2];
+    J.n_verts = s->n_verts; J.n_faces = n; J.n_rays = R; J.cap_slices = r->cap_slices;
+    J.out_flags = flags;
+    J.tris_block0 = tb;
+    J.resolve_block0 = rb;
+    tb += (n + 255) / 256;
+    rb += (R + 255) / 256;
+    // 32-bit byte offsets unless an array of the launch reaches 4 GB (> 357 M triangles / vertices, > 268 M rays)
+    wide = wide || (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 12 >= (1ull << 32) ||
+           (size_t)R * 16 >= (1ull << 32);
+  }
+  if (B.n == 0) return LT_OK;
+  B.tris_blocks = tb;
+  B.resolve_blocks = rb;
+  const dim3 b(256);
+#define SC_LAUNCH(KERNEL, GRID) \
+  do { \
+    if (count && wide) hipLaunchKernelGGL((KERNEL<true, true>), GRID, b, 0, stream, B); \
+    else if (count) hipLaunchKernelGGL((KERNEL<true, false>), GRID, b, 0, stream, B); \
+    else if (wide) hipLaunchKernelGGL((KERNEL<false, true>), GRID, b, 0, stream, B); \
+    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, b, 0, stream, B); \
+  } while (0)
+  if (tb > 0) {
+    if (probe && probe->probe[0]) LT_HIP(hipEventRecord(probe->probe[0], stream));
+    SC_LAUNCH(k_sc_tris, dim3(tb));
+    if (probe) {
+      if (probe->probe[1]) LT_HIP(hipEventRecord(probe->probe[1], stream));
+      probe->probe[0] = probe->probe[1] = nullptr;
+    }
+    SC_LAUNCH(k_sc_rest, dim3(B.n * LT_SC_REST_BLOCKS));
+  }
+#undef SC_LAUNCH
+  if (count) hipLaunchKernelGGL(k_sc_resolve<true>, dim3(rb), b, 0, stream, B);
+  else hipLaunchKernelGGL(k_sc_resolve<false>, dim3(rb), b, 0, stream, B);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
 // Render the scene's CURRENT mesh with the scatter strategy (no BVH needed).
 extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origin, float* endpoints, int* endcolors,
                                    float* range, float* endrem, int* tri, unsigned flags, void* stream_,
@@ -879,43 +975,11 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
   s->stats.n_rays = R;
   s->stats.n_faces = n;
   if (R > 0) {
-    LT_CHECK(rs_reserve_large(r, n));
     if (count) LT_HIP(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
     if (timed) LT_HIP(hipEventRecord(s->ev[7], stream));
-    const float ox = origin[0], oy = origin[1], oz = origin[2];
-    if (n > 0) {
-      const dim3 g((n + 255) / 256), b(256);
-      // 32-bit byte offsets unless an array of this launch reaches 4 GB (> 357 M triangles / vertices, > 268 M rays)
-      const bool wide = (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 12 >= (1ull << 32) ||
-                        (size_t)R * 16 >= (1ull << 32);
-#define SC_LAUNCH(KERNEL, GRID, ...) \
-  do { \
-    if (count && wide) hipLaunchKernelGGL((KERNEL<true, true>), GRID, b, 0, stream, __VA_ARGS__); \
-    else if (count) hipLaunchKernelGGL((KERNEL<true, false>), GRID, b, 0, stream, __VA_ARGS__); \
-    else if (wide) hipLaunchKernelGGL((KERNEL<false, true>), GRID, b, 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, b, 0, stream, __VA_ARGS__); \
-  } while (0)
-      if (!count && s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
-      SC_LAUNCH(k_sc_tris, g, s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm, r->grid, r->sdirs, r->cell,
-                r->large, r->large_count, r->slices, r->cap_slices, s->flags, s->counters);
-      if (!count) {
-        if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
-        s->probe[0] = s->probe[1] = nullptr;
-      }
-      SC_LAUNCH(k_sc_rest, dim3(LT_SC_REST_BLOCKS), s->verts, s->faces, s->n_verts, n, ox, oy, oz, r->prm, r->grid,
-                r->sdirs, r->cell, r->large, r->large_count, r->slices, r->cap_slices, s->counters);
-#undef SC_LAUNCH
-    }
-    if (count)
-      hipLaunchKernelGGL(k_sc_resolve<true>, dim3((R + 255) / 256), dim3(256), 0, stream, r->cell, r->dirs, R, ox, oy,
-                         oz, s->faces, s->colors, s->rem, endpoints, endcolors, range, endrem, tri, flags,
-                         r->large_count, s->counters);
-    else
-      hipLaunchKernelGGL(k_sc_resolve<false>, dim3((R + 255) / 256), dim3(256), 0, stream, r->cell, r->dirs, R, ox,
-                         oy, oz, s->faces, s->colors, s->rem, endpoints, endcolors, range, endrem, tri, flags,
-                         r->large_count, s->counters);
+    const sc_item it = {s, r, origin, endpoints, endcolors, range, endrem, tri};
+    LT_CHECK(sc_launch_batch(&it, 1, flags, stream, count, count ? nullptr : s));
     if (timed) LT_HIP(hipEventRecord(s->ev[8], stream));
-    LT_HIP(hipGetLastError());
   }
   if (timed || count) {
     LT_HIP(hipStreamSynchronize(stream));
@@ -931,4 +995,45 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
     if (stats) *stats = s->stats;
   }
   return LT_OK;
+}
+
+// The same for up to LT_SC_MAX_BATCH scans at once: three launches for all of them instead of three each.
+extern "C" int lt_scene_render_batch_dev(int n_scans, lt_scene* const* scenes, lt_rayset* const* raysets,
+                                         const float* origins, float* const* endpoints, int* const* endcolors,
+                                         float* const* range, float* const* endrem, int* const* tri, unsigned flags,
+                                         void* stream_) {
+  if (n_scans < 0 || n_scans > LT_SC_MAX_BATCH || (n_scans > 0 && (!scenes || !raysets || !origins))) {
+    lt_set_error("lt_scene_render_batch_dev: invalid argument (n_scans=%d, at most %d per call)", n_scans,
+                 LT_SC_MAX_BATCH);
+    return LT_ERR_INVALID_ARG;
+  }
+  if (flags & LT_TRACE_COUNT) {
+    lt_set_error("lt_scene_render_batch_dev: LT_TRACE_COUNT is a single-scan diagnostic (lt_scene_render_dev)");
+    return LT_ERR_INVALID_ARG;
+  }
+  if (n_scans == 0) return LT_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  sc_item it[LT_SC_MAX_BATCH];
+  lt_scene* probe = nullptr;
+  for (int i = 0; i < n_scans; ++i) {
+    if (!scenes[i] || !raysets[i] || scenes[i]->device != raysets[i]->device ||
+        scenes[i]->device != scenes[0]->device) {
+      lt_set_error("lt_scene_render_batch_dev: scan %d: NULL scene / rayset, or not all on one device", i);
+      return LT_ERR_INVALID_ARG;
+    }
+    for (int k = 0; k < i; ++k)
+      if (raysets[k] == raysets[i]) {
+        lt_set_error("lt_scene_render_batch_dev: scans %d and %d share a rayset (one render per rayset at a time)", k, i);
+        return LT_ERR_INVALID_ARG;
+      }
+    it[i] = {scenes[i], raysets[i], origins + 3 * i, endpoints ? endpoints[i] : nullptr,
+             endcolors ? endcolors[i] : nullptr, range ? range[i] : nullptr, endrem ? endrem[i] : nullptr,
+             tri ? tri[i] : nullptr};
+    scenes[i]->last_stream = stream;
+    scenes[i]->stats.n_rays = raysets[i]->n_rays;
+    scenes[i]->stats.n_faces = scenes[i]->n_faces;
+    if (!probe && scenes[i]->probe[0]) probe = scenes[i];
+  }
+  LT_HIP(hipSetDevice(scenes[0]->device));
+  return sc_launch_batch(it, n_scans, flags, stream, false, probe ? probe : scenes[0]);
 }

@@ -192,6 +192,32 @@ class Scene:
             out["stats"] = st.asdict()
         return out
 
+    @staticmethod
+    def render_batch(scenes, raysets, origins, outs=None, stream=None, write_misses=True):
+        """``lt_scene_render_batch_dev``: the scans ``(scenes[i], raysets[i], origins[i])`` -- at most 8, every
+        scene with its own current mesh, every rayset distinct -- rendered with three kernel launches for all of
+        them.  Returns the list of output dicts (``outs[i]`` or freshly allocated)."""
+        n = len(scenes)
+        if not (n == len(raysets) == len(origins)) or (outs is not None and len(outs) != n):
+            raise ValueError("render_batch: scenes, raysets, origins (and outs) must have one entry per scan")
+        if n == 0:
+            return []
+        if outs is None:
+            outs = [scenes[i].alloc_outputs(raysets[i].n_rays) for i in range(n)]
+        vp = C.c_void_p
+        arr = lambda vals: (vp * n)(*vals)  # noqa: E731
+        org = (C.c_float * (3 * n))(*[float(v) for o in origins for v in o])
+
+        def col(k):
+            return arr([(o[k].data_ptr() if o.get(k) is not None else None) for o in outs])
+
+        flags = _lib.LT_TRACE_WRITE_MISSES if write_misses else 0
+        _lib.check(scenes[0]._lib.lt_scene_render_batch_dev(n, arr([s._h for s in scenes]), arr([r._h for r in raysets]),
+                                                            org, col("endpoints"), col("endcolors"), col("range"),
+                                                            col("endrem"), col("tri"), flags, scenes[0]._stream(stream)),
+                   "lt_scene_render_batch_dev")
+        return outs
+
     def set_probe(self, ev_start, ev_stop):
         """Record two ``torch.cuda.Event(enable_timing=True)`` around the dominant kernel of the next cast."""
         for ev in (ev_start, ev_stop):  # materialise the underlying hipEvent_t

@@ -419,6 +419,49 @@ def test_broken_meshes_non_finite_and_huge_vertices(oracle):
     assert any(set(f[t].tolist()) & set(huge.tolist()) for t in hit_faces), "no sliver towards a far vertex was hit"
 
 
+def test_render_batch_equals_separate_renders():
+    """lt_scene_render_batch_dev: several scans -- different meshes (one of them empty, one low-poly whose triangles
+    all go through the big-triangle queue), different ray models and origins -- with three launches for all of
+    them; every image must be what a separate lt_scene_render_dev call produces, bit for bit."""
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    meshes = [synth_scene(11, 60000), synth_scene(12, 3000), _adversarial_soup(rng, 2500),
+              (np.zeros((3, 3), np.float32), np.zeros((0, 3), np.int32), np.zeros((3, 3), np.int32),
+               np.zeros(3, np.float32)),
+              synth_scene(13, 250000)]
+    models = [(3.0, -25.0, 64, 512), (10.0, -30.0, 32, 301), (15.0, -15.0, 16, 1024), (3.0, -25.0, 8, 64),
+              (3.0, -25.0, 64, 2048)]
+    origins = [(0.0, 0.0, 0.0), (1.5, -2.25, 0.4), (0.3, -0.2, 0.1), (0.0, 0.0, 0.0), (-4.0, 3.0, 0.2)]
+    scenes, raysets, single = [], [], []
+    for (v, f, c, r), (fu, fd, H, W), org in zip(meshes, models, origins):
+        sc = Scene(0)
+        sc.set_mesh(*[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (v, f, c, r)])
+        rs = RaySet(torch.from_numpy(create_rays(fu, fd, H, W)).to(dev), H)
+        single.append({k: t.clone() for k, t in sc.render(rs, org).items()})
+        scenes.append(sc)
+        raysets.append(rs)
+    outs = Scene.render_batch(scenes, raysets, origins)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, outs)):
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), f"scan {i}: {k} differs"
+    assert int((outs[0]["tri"] >= 0).sum()) > 1000 and int((outs[3]["tri"] >= 0).sum()) == 0
+    # a second batch on the same objects (queues and cells were re-armed), in another order and size
+    outs2 = Scene.render_batch(scenes[::-1][:3], raysets[::-1][:3], origins[::-1][:3])
+    for a, b in zip(single[::-1][:3], outs2):
+        assert torch.equal(a["range"].view(torch.int32), b["range"].view(torch.int32))
+    with pytest.raises(RuntimeError):
+        Scene.render_batch([scenes[0], scenes[1]], [raysets[0], raysets[0]], origins[:2])   # shared rayset
+    for sc in scenes:
+        sc.status()
+    for rs in raysets:
+        rs.close()
+    for sc in scenes:
+        sc.close()
+
+
 @pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
                                             ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
 def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):
