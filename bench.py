@@ -420,7 +420,7 @@ def main():
     other = None
     if not args.no_other:
         oname = "lbvh" if args.strategy == "scatter" else "scatter"
-        Ko = max(20, K // 4)
+        Ko = max(20, K // 4) if oname == "lbvh" else max(K, 400)  # a scatter step is ~15x shorter than an LBVH step
         odt, okern, _ = run(oname, Ko, max(4, Wm // 4), keep=False)
         other = {"strategy": oname, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
                  "ms_per_step": round(odt / Ko * 1e3, 4), "steps": Ko, "roofline": roofline(oname, okern)}
