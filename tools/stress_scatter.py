@@ -12,11 +12,25 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from test_trace_gpu import _adversarial_soup
 
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--batch", type=int, default=0, help="also render groups of up to this many cases with one lt_scene_render_batch_dev call")
 ap.add_argument("--oracle", action="store_true", help="also compare with the brute-force CPU oracle where tris x rays < 3e7")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(a.seed)
-bad = 0; tot_rays = tot_hits = tot_tris = 0; n_or = 0
+bad = 0; tot_rays = tot_hits = tot_tris = 0; n_or = 0; pending = []; n_batched = 0
+
+
+def flush(pending):
+    """the scans rendered one by one above, once more as ONE batch call"""
+    global bad
+    outs = Scene.render_batch([p[0] for p in pending], [p[1] for p in pending], [p[2] for p in pending])
+    torch.cuda.synchronize()
+    for (sc_, rs_, org_, A_, case_), o in zip(pending, outs):
+        if not all(torch.equal(A_[k].view(torch.int32), o[k].view(torch.int32)) for k in ("tri", "range", "endpoints", "endcolors", "endrem")):
+            bad += 1
+            print(f"BATCH MISMATCH case {case_}")
+        rs_.close(); sc_.close()
+
 for case in range(a.cases):
     H = int(rng.choice([1, 2, 5, 16, 64, 128])); W = int(rng.choice([1, 3, 64, 301, 1024, 2048, 4000]))
     if rng.random() < 0.03: H, W = 5000, int(rng.choice([1, 3]))     # more rows than the bin grid has (4096)
@@ -78,6 +92,13 @@ for case in range(a.cases):
         bad += 1
         nd = int((A["tri"] != B["tri"]).sum())
         print(f"MISMATCH case {case}: H={H} W={W} fov=({up:.2f},{down:.2f}) kind={kind} tris={f.shape[0]} origin={origin} differing rays={nd}")
-    rs.close(); sc.close()
-print(f"{a.cases} cases, {bad} mismatches; {tot_tris} triangles, {tot_rays} rays, {tot_hits} hits; {n_or} cases also against the brute-force oracle")
+    if a.batch > 1:
+        pending.append((sc, rs, origin, {k: t_.clone() for k, t_ in A.items() if hasattr(t_, 'clone')}, case)); n_batched += 1
+        if len(pending) == a.batch or case % 5 == 0:  # groups of 1 .. batch scans
+            flush(pending); pending = []
+    else:
+        rs.close(); sc.close()
+if pending:
+    flush(pending)
+print(f"{a.cases} cases, {bad} mismatches; {tot_tris} triangles, {tot_rays} rays, {tot_hits} hits; {n_or} cases also against the brute-force oracle, {n_batched} also in batch calls")
 sys.exit(1 if bad else 0)
