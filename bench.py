@@ -142,6 +142,8 @@ def main():
     H, W = wl["H"], wl["W"]
     R = H * W
     K, Wm, S = args.steps, args.warmup, max(1, args.streams)
+    args.batch = min(max(1, args.batch), 8)  # lt_scene_render_batch_dev takes at most 8 scans
+    S = (S + args.batch - 1) // args.batch * args.batch  # whole batches of workers
 
     # ---- synthetic inputs, resident in HBM before the clock starts -----------------------------------
     scenes = []
