@@ -417,9 +417,14 @@ __global__ __launch_bounds__(256) void k_rs_grid(const int* __restrict__ bin_sta
 }
 
 #define LT_SC_BIG 512    // candidate bins above which a triangle goes to the wave-per-triangle queue
-#define LT_SC_CAP 1024   // candidates a k_sc_tris workgroup tests itself (4 rounds); the rest of a heavier workgroup
-                         // is queued in slices: a few near-field workgroups with 10-20 rounds would otherwise run
-                         // long after the rest of the grid has drained (measured: a 20 us tail on a 37 us kernel)
+// Candidates a k_sc_tris workgroup tests itself; the rest of a heavier workgroup is queued in slices for k_sc_rest.
+//   single-scan call: 1024 (4 rounds) -- a few near-field workgroups with 10-20 rounds would otherwise run long
+//     after the rest of the grid has drained (measured: a 20 us tail on a 37 us kernel);
+//   batch call: 8192 -- with the triangles of 8 scans in one grid there is no tail to speak of, and what is
+//     deferred costs a second pass over its triangle block in k_sc_rest (7.6 -> 8.3 Grays/s on C2, where no
+//     workgroup reaches 8192; the bound is there for a near field full of medium-sized triangles).
+#define LT_SC_CAP_SINGLE 1024
+#define LT_SC_CAP_BATCH 8192
 #define LT_SC_SLICE 512  // candidates per queued slice (k_sc_rest)
 
 // LDS state of one workgroup = 256 consecutive triangles
@@ -578,10 +583,11 @@ struct sc_job {
 struct sc_batch {
   int n;
   int tris_blocks, resolve_blocks;  // grid sizes
+  int cap;                          // LT_SC_CAP_SINGLE / LT_SC_CAP_BATCH
   sc_job job[LT_SC_MAX_BATCH];
 };
 
-// One workgroup = 256 consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~LT_SC_CAP
+// One workgroup = 256 consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~B.cap
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
@@ -598,11 +604,11 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
                                        J.large_count, J.flags);
   int total;
   const int mypre = sc_prefix(S, cnt, total);
-  // The workgroup keeps the triangles that start below LT_SC_CAP; exactly one thread sees the crossing and
+  // The workgroup keeps the triangles that start below the cap; exactly one thread sees the crossing and
   // queues the rest in slices (large_count[1] = number of slices; if the queue is full the workgroup keeps all).
-  if (total < LT_SC_CAP) {
+  if (total < B.cap) {
     if (tid == 255) S.kept = total;
-  } else if (mypre < LT_SC_CAP && mypre + cnt >= LT_SC_CAP) {
+  } else if (mypre < B.cap && mypre + cnt >= B.cap) {
     int kept = mypre + cnt;
     const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
     if (n_sl > 0) {
@@ -931,6 +937,7 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
   if (B.n == 0) return LT_OK;
   B.tris_blocks = tb;
   B.resolve_blocks = rb;
+  B.cap = n_items > 1 ? LT_SC_CAP_BATCH : LT_SC_CAP_SINGLE;
   const dim3 b(256);
 #define SC_LAUNCH(KERNEL, GRID) \
   do { \
