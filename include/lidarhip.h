@@ -42,6 +42,9 @@ extern "C" {
 #define LT_TRACE_NORM_EXACT 4u   /* seed the direction normalisation (Vector3.h:73-89) with a correctly */
                                  /* rounded 1/sqrt instead of the replayed x86 RSQRTSS seed (default);  */
                                  /* vendor independent, differs from the reference in the last ulp      */
+#define LT_TRACE_LABEL_IMAGE 8u  /* `endcolors` receives [n_rays] ints: colour channel 2 only = the      */
+                                 /* semantic label image `deform` unpacks (label_image = ray_colors[:, :, */
+                                 /* 2], laserscan.py:912) instead of [n_rays, 3]; device-pointer calls    */
 
 /* Per-phase timings (hipEvent, milliseconds) and work counters of the last build / trace of a scene. */
 typedef struct lt_stats {

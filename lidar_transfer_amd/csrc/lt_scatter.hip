@@ -725,16 +725,23 @@ __global__ __launch_bounds__(256) void k_sc_resolve(const sc_batch B) {
         endpoints[3 * (size_t)ray + 2] = J.oz + d.z * t;
       }
       if (endcolors) {
-        endcolors[3 * (size_t)ray] = (int)(float)J.colors[3 * (size_t)i0];
-        endcolors[3 * (size_t)ray + 1] = (int)(float)J.colors[3 * (size_t)i0 + 1];
-        endcolors[3 * (size_t)ray + 2] = (int)(float)J.colors[3 * (size_t)i0 + 2];
+        if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
+          endcolors[ray] = (int)(float)J.colors[3 * (size_t)i0 + 2];
+        } else {
+          endcolors[3 * (size_t)ray] = (int)(float)J.colors[3 * (size_t)i0];
+          endcolors[3 * (size_t)ray + 1] = (int)(float)J.colors[3 * (size_t)i0 + 1];
+          endcolors[3 * (size_t)ray + 2] = (int)(float)J.colors[3 * (size_t)i0 + 2];
+        }
       }
       if (endrem) endrem[ray] = ((J.rem[i0] + J.rem[i1]) + J.rem[i2]) / 3.0f;
       if (range) range[ray] = t;
       if (tri_out) tri_out[ray] = face;
     } else if (flags & LT_TRACE_WRITE_MISSES) {
       if (endpoints) { endpoints[3 * (size_t)ray] = 0.f; endpoints[3 * (size_t)ray + 1] = 0.f; endpoints[3 * (size_t)ray + 2] = 0.f; }
-      if (endcolors) { endcolors[3 * (size_t)ray] = 0; endcolors[3 * (size_t)ray + 1] = 0; endcolors[3 * (size_t)ray + 2] = 0; }
+      if (endcolors) {
+        if (flags & LT_TRACE_LABEL_IMAGE) endcolors[ray] = 0;
+        else { endcolors[3 * (size_t)ray] = 0; endcolors[3 * (size_t)ray + 1] = 0; endcolors[3 * (size_t)ray + 2] = 0; }
+      }
       if (endrem) endrem[ray] = 0.f;
       if (range) range[ray] = 0.f;
       if (tri_out) tri_out[ray] = -1;

@@ -169,16 +169,23 @@ __global__ __launch_bounds__(256) void k_trace(
         endpoints[3 * ray + 2] = oz + dz * best_t;
       }
       if (endcolors) {  // colour of vertex 0, int -> float -> int (RayTracer.cpp:36, :80-82)
-        endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
-        endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
-        endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+        if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
+          endcolors[ray] = (int)(float)colors[3 * (size_t)i0 + 2];
+        } else {
+          endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
+          endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
+          endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+        }
       }
       if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;  // Triangle.h:69
       if (range) range[ray] = best_t;
       if (tri_out) tri_out[ray] = best_face;
     } else if (flags & LT_TRACE_WRITE_MISSES) {
       if (endpoints) { endpoints[3 * ray] = 0.f; endpoints[3 * ray + 1] = 0.f; endpoints[3 * ray + 2] = 0.f; }
-      if (endcolors) { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+      if (endcolors) {
+        if (flags & LT_TRACE_LABEL_IMAGE) endcolors[ray] = 0;
+        else { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+      }
       if (endrem) endrem[ray] = 0.f;
       if (range) range[ray] = 0.f;
       if (tri_out) tri_out[ray] = -1;
@@ -394,16 +401,23 @@ __global__ __launch_bounds__(256) void k_trace4(
         endpoints[3 * ray + 2] = oz + dz * best_t;
       }
       if (endcolors) {
-        endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
-        endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
-        endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+        if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
+          endcolors[ray] = (int)(float)colors[3 * (size_t)i0 + 2];
+        } else {
+          endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
+          endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
+          endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+        }
       }
       if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
       if (range) range[ray] = best_t;
       if (tri_out) tri_out[ray] = best_face;
     } else if (flags & LT_TRACE_WRITE_MISSES) {
       if (endpoints) { endpoints[3 * ray] = 0.f; endpoints[3 * ray + 1] = 0.f; endpoints[3 * ray + 2] = 0.f; }
-      if (endcolors) { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+      if (endcolors) {
+        if (flags & LT_TRACE_LABEL_IMAGE) endcolors[ray] = 0;
+        else { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+      }
       if (endrem) endrem[ray] = 0.f;
       if (range) range[ray] = 0.f;
       if (tri_out) tri_out[ray] = -1;

@@ -29,15 +29,16 @@ def partition(items: Sequence, world_size: int, rank: int) -> List:
     return list(items[start:start + base + (1 if rank < extra else 0)])
 
 
-def gather_to_root(src, recv=None, dst: int = 0, group=None):
+def gather_to_root(src, recv=None, dst: int = 0, group=None, copy_self: bool = True):
     """ONE gather, issued the way RCCL implements it: a group of point-to-point transfers.
 
     Every rank other than ``dst`` sends ``src``; ``dst`` receives rank r's tensor into ``recv[r]`` (``recv``:
     a list of tensors, or one tensor whose first dimension is the world size; the parts may differ in size)
     and copies its own part with a plain device copy -- RCCL would move the root's send-to-itself through its
     channel kernels at a fraction of the copy rate.  With 8 GPUs the root receives from 7 peers over 7
-    separate xGMI links concurrently.  Returns the list of outstanding works (``w.wait()``); an empty ``src``
-    (0 elements) is skipped on both sides.
+    separate xGMI links concurrently.  ``copy_self=False`` leaves the root's own part where it is (``recv[dst]``
+    is not touched): a driver that already holds its images does not need a second copy of them.  Returns the
+    list of outstanding works (``w.wait()``); an empty ``src`` (0 elements) is skipped on both sides.
     """
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -46,7 +47,7 @@ def gather_to_root(src, recv=None, dst: int = 0, group=None):
     if rank == dst:
         if recv is None:
             raise ValueError("gather_to_root: the destination rank needs receive buffers")
-        if src is not None and src.numel() > 0:
+        if copy_self and src is not None and src.numel() > 0:
             recv[rank].copy_(src, non_blocking=True)
         ops = [dist.P2POp(dist.irecv, recv[r], r, group) for r in range(world) if r != dst and recv[r].numel() > 0]
     elif src is not None and src.numel() > 0:

@@ -142,7 +142,7 @@ class Scene:
         return st.asdict() if stats else None
 
     def trace(self, rays, origin, H, out=None, stream=None, write_misses=True, count=False, stats=False,
-              exact_normalize=False):
+              exact_normalize=False, label_image=False):
         """Cast ``rays [R,3] f32`` (device) from ``origin`` (3 floats, host); returns dict of device tensors.
 
         ``out`` may carry preallocated ``endpoints [R,3] f32, endcolors [R,3] i32, range [R] f32,
@@ -152,10 +152,11 @@ class Scene:
         rays = self._t(rays, torch.float32, "rays")
         n_rays = rays.numel() // 3
         if out is None:
-            out = self.alloc_outputs(n_rays)
+            out = self.alloc_outputs(n_rays, label_image=label_image)
         org = (C.c_float * 3)(*[float(v) for v in origin])
         flags = ((_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
-                 | (_lib.LT_TRACE_NORM_EXACT if exact_normalize else 0))
+                 | (_lib.LT_TRACE_NORM_EXACT if exact_normalize else 0)
+                 | (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0))
         st = _lib.Stats()
 
         def p(k):
@@ -171,13 +172,15 @@ class Scene:
             out["stats"] = st.asdict()
         return out
 
-    def render(self, rayset, origin, out=None, stream=None, write_misses=True, count=False, stats=False):
+    def render(self, rayset, origin, out=None, stream=None, write_misses=True, count=False, stats=False,
+               label_image=False):
         """Closest hits of a :class:`RaySet` against the CURRENT mesh with the single-origin scatter
         strategy (``lt_scene_render_dev``): no BVH build; bit-identical to :meth:`build` + :meth:`trace`."""
         if out is None:
-            out = self.alloc_outputs(rayset.n_rays)
+            out = self.alloc_outputs(rayset.n_rays, label_image=label_image)
         org = (C.c_float * 3)(*[float(v) for v in origin])
-        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
+        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0) | \
+            (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0)
         st = _lib.Stats()
 
         def p(k):
@@ -193,7 +196,7 @@ class Scene:
         return out
 
     @staticmethod
-    def render_batch(scenes, raysets, origins, outs=None, stream=None, write_misses=True):
+    def render_batch(scenes, raysets, origins, outs=None, stream=None, write_misses=True, label_image=False):
         """``lt_scene_render_batch_dev``: the scans ``(scenes[i], raysets[i], origins[i])`` -- at most 8, every
         scene with its own current mesh, every rayset distinct -- rendered with three kernel launches for all of
         them.  Returns the list of output dicts (``outs[i]`` or freshly allocated)."""
@@ -203,7 +206,7 @@ class Scene:
         if n == 0:
             return []
         if outs is None:
-            outs = [scenes[i].alloc_outputs(raysets[i].n_rays) for i in range(n)]
+            outs = [scenes[i].alloc_outputs(raysets[i].n_rays, label_image=label_image) for i in range(n)]
         vp = C.c_void_p
         arr = lambda vals: (vp * n)(*vals)  # noqa: E731
         org = (C.c_float * (3 * n))(*[float(v) for o in origins for v in o])
@@ -211,7 +214,7 @@ class Scene:
         def col(k):
             return arr([(o[k].data_ptr() if o.get(k) is not None else None) for o in outs])
 
-        flags = _lib.LT_TRACE_WRITE_MISSES if write_misses else 0
+        flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0)
         _lib.check(scenes[0]._lib.lt_scene_render_batch_dev(n, arr([s._h for s in scenes]), arr([r._h for r in raysets]),
                                                             org, col("endpoints"), col("endcolors"), col("range"),
                                                             col("endrem"), col("tri"), flags, scenes[0]._stream(stream)),
@@ -226,11 +229,13 @@ class Scene:
         _lib.check(self._lib.lt_scene_set_probe(self._h, C.c_void_p(ev_start.cuda_event),
                                                 C.c_void_p(ev_stop.cuda_event)), "lt_scene_set_probe")
 
-    def alloc_outputs(self, n_rays):
+    def alloc_outputs(self, n_rays, label_image=False):
+        """Output images; with ``label_image`` the colour output is the [n_rays] semantic-label image
+        (``LT_TRACE_LABEL_IMAGE``: channel 2 only, ``deform``'s ``label_image = ray_colors[:, :, 2]``)."""
         torch = self._torch
         d = self.device
         return dict(endpoints=torch.empty((n_rays, 3), dtype=torch.float32, device=d),
-                    endcolors=torch.empty((n_rays, 3), dtype=torch.int32, device=d),
+                    endcolors=torch.empty((n_rays,) if label_image else (n_rays, 3), dtype=torch.int32, device=d),
                     range=torch.empty((n_rays,), dtype=torch.float32, device=d),
                     endrem=torch.empty((n_rays,), dtype=torch.float32, device=d),
                     tri=torch.empty((n_rays,), dtype=torch.int32, device=d))

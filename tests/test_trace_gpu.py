@@ -419,6 +419,32 @@ def test_broken_meshes_non_finite_and_huge_vertices(oracle):
     assert any(set(f[t].tolist()) & set(huge.tolist()) for t in hit_faces), "no sliver towards a far vertex was hit"
 
 
+def test_label_image_output_is_colour_channel_two():
+    """LT_TRACE_LABEL_IMAGE: the colour output shrinks to the [n_rays] semantic-label image that `deform` unpacks
+    (`label_image = ray_colors[:, :, 2]`, laserscan.py:912) -- in both strategies and in the batch call; everything
+    else is unchanged."""
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    v, f, c, r = synth_scene(21, 30000)
+    rays = torch.from_numpy(create_rays(3.0, -25.0, 32, 256)).to(dev)
+    sc = Scene(0)
+    sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
+    rs, rs2 = RaySet(rays, 32), RaySet(rays, 32)
+    full = sc.render(rs, (0.2, 0.1, 0.0))
+    lab = sc.render(rs, (0.2, 0.1, 0.0), label_image=True)
+    sc.build()
+    lab_b = sc.trace(rays, (0.2, 0.1, 0.0), 32, label_image=True)
+    lab_c = Scene.render_batch([sc], [rs2], [(0.2, 0.1, 0.0)], label_image=True)[0]
+    for o in (lab, lab_b, lab_c):
+        assert o["endcolors"].shape == (32 * 256,)
+        assert torch.equal(o["endcolors"], full["endcolors"][:, 2])
+        for k in ("tri", "range", "endrem", "endpoints"):
+            assert torch.equal(o[k].view(torch.int32), full[k].view(torch.int32))
+    assert int((lab["endcolors"] != 0).sum()) > 1000
+    rs.close(); rs2.close(); sc.close()
+
+
 def test_render_batch_equals_separate_renders():
     """lt_scene_render_batch_dev: several scans -- different meshes (one of them empty, one low-poly whose triangles
     all go through the big-triangle queue), different ray models and origins -- with three launches for all of
