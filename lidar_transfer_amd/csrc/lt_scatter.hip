@@ -482,15 +482,20 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
 // barrier; the caller issues the second one (after any extra LDS it wants published with it).
 __device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // inclusive wave scan with DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31 across
-  // rows): 6 VALU instructions instead of 6 ds_bpermute round trips
+  // inclusive wave scan with six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31 across
+  // rows).  Written as v_add_u32_dpp so that a step is ONE instruction: lanes whose DPP source does not exist add
+  // 0 (bound_ctrl:0), rows deselected by row_mask keep their value.  The s_nop is the VALU-write -> DPP-read
+  // hazard of gfx9 (2 wait states), which the assembler does not insert inside inline asm.
   int inc = cnt;
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);  // row_shr:1
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);  // row_shr:2
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);  // row_shr:4
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);  // row_shr:8
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
-  inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+  asm volatile(
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(inc));
   if (lane == 63) S.wsum[wave] = inc;
   __syncthreads();
   int woff = 0;
