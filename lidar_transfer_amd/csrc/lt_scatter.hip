@@ -274,8 +274,8 @@ struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mo
 __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float y0, float z0, float x1, float y1,
                                              float z1, float x2, float y2, float z2) {
 #pragma clang fp contract(fast)
-  bin_rect R;
-  R.na = 0; R.a0 = 0; R.e0 = 0; R.e1 = -1;
+  bin_rect R;  // only R.na is defined when the rectangle is empty (callers test R.na > 0 first)
+  R.na = 0;
   const float q0 = x0 * x0 + y0 * y0, q1 = x1 * x1 + y1 * y1, q2 = x2 * x2 + y2 * y2;
   // The bounds below are only sound while no intermediate overflows or is NaN (fminf / fmaxf drop NaN
   // operands).  Sums, unlike maxima, propagate both, so one test guards the fast path:
@@ -457,9 +457,8 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
       const float v2x = C.x, v2y = C.y, v2z = C.z;
       const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
                                   v2z - oz);
-      const int ne = R.e1 - R.e0 + 1;
-      if (R.na > 0 && ne > 0) {
-        const int c32 = R.na * ne;  // <= 8192 x 4096 bins (lt_rayset_create_dev)
+      if (R.na > 0) {  // (rows e0..e1 are non-empty whenever na > 0)
+        const int c32 = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
         if (c32 > LT_SC_BIG) {
           if (PUSH) large[atomicAdd(large_count, 1)] = f;
         } else {
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
     T.e2x = v2x - T.v0x; T.e2y = v2y - T.v0y; T.e2z = v2z - T.v0z;
     const bin_rect R = tri_bins(P, T.v0x - ox, T.v0y - oy, T.v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox,
                                 v2y - oy, v2z - oz);
-    const int total = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
+    const int total = R.na > 0 ? R.na * (R.e1 - R.e0 + 1) : 0;  // <= 8192 x 4096 bins (lt_rayset_create_dev)
     const int parts = min(max((total + 1023) / 1024, 1), LT_SC_PARTS);
     if (part >= parts) continue;
     for (int w = part * 64 + lane; w < total; w += 64 * parts) {
