@@ -252,8 +252,13 @@ __device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, flo
 // addresses are base + 32-bit byte offset -- one VALU multiply instead of quarter-rate 64-bit multiply-adds on
 // the gather addresses of a VALU-bound kernel.
 template <class T>
-__device__ __forceinline__ unsigned byte_off(unsigned elem) {  // v_mul_lo_u32 is quarter rate: shift-add for 12 B
-  return sizeof(T) == 12 ? (elem << 3) + (elem << 2) : elem * (unsigned)sizeof(T);
+__device__ __forceinline__ unsigned byte_off(unsigned elem) {
+  if (sizeof(T) == 12) {  // v_mul_lo_u32 is quarter rate and the optimiser folds (e << 3) + (e << 2) back into it
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(elem), "v"(elem << 2));
+    return r;
+  }
+  return elem * (unsigned)sizeof(T);
 }
 template <bool WIDE, class T>
 __device__ __forceinline__ const T* at(const T* base, unsigned elem) {
