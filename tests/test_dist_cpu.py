@@ -105,3 +105,15 @@ def test_gather_to_root_grouped_send_recv(world):
     for chunk, (rng, lab) in enumerate(got):
         for r in range(world):
             assert np.all(rng[r] == 10 * r + chunk) and np.all(lab[r] == 100 * r + chunk)
+
+
+def test_bench_cli_parses_without_a_gpu():
+    """`bench.py --help` must work on a box without a GPU (the driver's contract flags are all there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=120)
+    assert res.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in res.stdout
