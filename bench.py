@@ -53,8 +53,10 @@ LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)   # a step is ~20 us: 1000 of them make a 20 ms timed region
-    ap.add_argument("--warmup", type=int, default=100)
+    # a step is ~14 us: 4000 of them make a 55 ms timed region (filling and draining the pipeline of 16 scans in
+    # flight costs ~1 ms of it; at 1000 steps that would be 8 % of the region)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=12,
