@@ -25,29 +25,69 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def _deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def source_hash() -> str:
+    """Content hash of everything the library is compiled from (and of the flags)."""
+    import hashlib
+    h = hashlib.sha256(" ".join([ARCH, *FLAGS]).encode())
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    """Stale = built from other sources.  Decided by content, not by file times: a repository snapshot copied to
+    another machine keeps its bytes but not necessarily the order of its mtimes, and a spurious rebuild there
+    would have every rank of a multi-GPU job compile the same file at once."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(HASH_PATH) as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        # no record (library built by hand): fall back to file times
+        t = os.path.getmtime(LIB_PATH)
+        return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """Build the shared library if it is missing or stale; return its path."""
+    """Build the shared library if it is missing or stale; return its path.  Safe against concurrent callers
+    (ranks of one job): one compiles under a file lock into a temporary name and renames, the others wait."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build liblidarhip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", LIB_PATH, *sources()]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # somebody else built it while we waited
+                return LIB_PATH
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                   "-o", tmp, *sources()]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIB_PATH)
+            with open(HASH_PATH, "w") as f:
+                f.write(source_hash() + "\n")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
