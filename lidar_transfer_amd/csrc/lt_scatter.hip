@@ -924,7 +924,10 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
                            lt_scene* probe) {
   sc_batch B;
   memset(&B, 0, sizeof(B));
-  bool wide = false;
+  // LIDARHIP_FORCE_WIDE=1 selects the 64-bit addressing variants on any input (they are otherwise only reached
+  // with > 357 M triangles): a test hook
+  static const bool force_wide = getenv("LIDARHIP_FORCE_WIDE") != nullptr;
+  bool wide = force_wide;
   int tb = 0, rb = 0;
   for (int i = 0; i < n_items; ++i) {
     lt_scene* s = it[i].s;

@@ -543,3 +543,44 @@ np.savez(sys.argv[1], tri=o["tri"].cpu().numpy(), range=o["range"].cpu().numpy()
     assert np.array_equal(outs["binary"]["tri"], outs["quad"]["tri"])
     _assert_bits(outs["binary"]["range"], outs["quad"]["range"], "range")
     assert int(outs["binary"]["nodes"]) > int(outs["quad"]["nodes"]) > 0   # binary visits ~2x as many (thinner) nodes
+
+
+def test_wide_addressing_variants_in_subprocess(tmp_path):
+    """The scatter kernels have a 64-bit addressing variant for arrays of 4 GB and more (> 357 M triangles); force
+    it on an ordinary scene (LIDARHIP_FORCE_WIDE=1, read once per process, hence the subprocess) and compare with
+    the 32-bit variant of this process."""
+    import subprocess
+    import sys
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    v, f, c, r = synth_scene(31, 40000)
+    rays = create_rays(3.0, -25.0, 32, 512)
+    dev = torch.device("cuda", 0)
+    sc = Scene(0)
+    sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
+    rs = RaySet(torch.from_numpy(rays).to(dev), 32)
+    a = sc.render(rs, (0.1, 0.2, 0.0))
+    np.savez(tmp_path / "narrow.npz", **{k: t.cpu().numpy() for k, t in a.items()})
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from lidar_transfer_amd.raytracer import RaySet, Scene
+from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.synth import synth_scene
+v, f, c, r = synth_scene(31, 40000)
+dev = torch.device("cuda", 0)
+sc = Scene(0); sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
+rs = RaySet(torch.from_numpy(create_rays(3.0, -25.0, 32, 512)).to(dev), 32)
+a = sc.render(rs, (0.1, 0.2, 0.0), count=True)
+b = Scene.render_batch([sc], [rs], [(0.1, 0.2, 0.0)])[0]
+g = np.load({str(tmp_path / "narrow.npz")!r})
+for o in (a, b):
+    for k in ("tri", "range", "endpoints", "endcolors", "endrem"):
+        assert np.array_equal(o[k].cpu().numpy().view(np.int32), g[k].view(np.int32)), k
+print("WIDE_OK", int((a["tri"] >= 0).sum()))
+"""
+    env = dict(os.environ, LIDARHIP_FORCE_WIDE="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and "WIDE_OK" in res.stdout, res.stdout + res.stderr
+    rs.close()
+    sc.close()
