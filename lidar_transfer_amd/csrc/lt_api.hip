@@ -227,6 +227,37 @@ extern "C" int lt_debug_wave_times(lt_scene* s, unsigned long long* out, int n_w
   return LT_OK;
 }
 
+// debug helper (not part of the documented ABI): compare lt_rcp_ieee with the IEEE division for every one of the
+// 2^32 float bit patterns; returns the number of patterns where the bits differ in *mismatches, and how many
+// patterns took the 5-instruction path in *fast
+__global__ __launch_bounds__(256) void k_verify_rcp(unsigned long long* __restrict__ out) {
+  unsigned long long bad = 0, fast = 0;
+  const unsigned long long n = 1ull << 32;
+  for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b < n;
+       b += (unsigned long long)gridDim.x * 256) {
+    const float a = __uint_as_float((unsigned)b);
+    const float x = lt_rcp_ieee(a), y = 1.0f / a;
+    if (__float_as_uint(x) != __float_as_uint(y) && !(x != x && y != y)) ++bad;
+    if (fabsf(a) >= 5.421010862e-20f && fabsf(a) <= 1.8446744e19f) ++fast;
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  atomicAdd(&out[1], fast);
+}
+
+extern "C" int lt_debug_verify_rcp(unsigned long long* mismatches, unsigned long long* fast) {
+  unsigned long long* d = nullptr;
+  LT_HIP(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+  LT_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_verify_rcp, dim3(8192), dim3(256), 0, 0, d);
+  unsigned long long h[2] = {0, 0};
+  const hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  LT_HIP(e);
+  if (mismatches) *mismatches = h[0];
+  if (fast) *fast = h[1];
+  return LT_OK;
+}
+
 extern "C" int lt_scene_set_probe(lt_scene* s, void* ev_start, void* ev_stop) {
   if (!s) {
     lt_set_error("lt_scene_set_probe: NULL scene");

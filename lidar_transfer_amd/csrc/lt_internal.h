@@ -92,3 +92,22 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
 bool lt_binary_path();  // LIDARHIP_TRACE=binary: one ray per lane over binary nodes (A/B cross-check)
 int lt_scene_reserve(lt_scene* s, int n_faces);
 int lt_scene_reserve_rays(lt_scene* s, int n_rays);
+
+// ---- correctly rounded reciprocal in 5 instructions ------------------------------------------------------------
+// The reference multiplies by inv_a = 1.0f / a (Triangle.h:35, an IEEE division).  hipcc's IEEE f32 division is a
+// 10-instruction sequence (div_scale x2, rcp, 4 fma, div_fmas, div_fixup) whose scaling steps only matter for
+// denormal or huge operands.  For 2^-64 <= |a| <= 2^64 two Newton steps on v_rcp_f32 (1 ulp) with exact fma
+// residuals give the correctly rounded quotient: after the first step the relative error is ~2^-46, after the
+// second the value fed to the final rounding is within 2^-90 of 1/a, and 1/a cannot be that close to a rounding
+// boundary (|a x midpoint - 1| >= 2^-48).  Not taken on trust: lt_debug_verify_rcp compares it with the
+// division for EVERY float in that range (tests/test_trace_gpu.py); outside the range the division is used.
+#ifdef __HIPCC__
+__device__ __forceinline__ float lt_rcp_ieee(float a) {
+  if (!(fabsf(a) >= 5.421010862e-20f && fabsf(a) <= 1.8446744e19f)) return 1.0f / a;  // incl. NaN
+  float r = __builtin_amdgcn_rcpf(a);
+  float e = __builtin_fmaf(-a, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  e = __builtin_fmaf(-a, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+#endif

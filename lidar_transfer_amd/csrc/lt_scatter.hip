@@ -209,7 +209,7 @@ __device__ __forceinline__ float sc_mt(const tri_rec& T, float ox, float oy, flo
   const float hx = dy * T.e2z - dz * T.e2y, hy = dz * T.e2x - dx * T.e2z, hz = dx * T.e2y - dy * T.e2x;
   const float a = (T.e1x * hx + T.e1y * hy) + T.e1z * hz;
   if (a < eps && a > -eps) return NAN;
-  const float inv_a = 1.0f / a;
+  const float inv_a = lt_rcp_ieee(a);  // = 1.0f / a, bit for bit (lt_internal.h)
   const float sx = ox - T.v0x, sy = oy - T.v0y, sz = oz - T.v0z;
   const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
   if (u < 0 || u > 1) return NAN;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_trace(
         const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
         const float a = (e1x * hx + e1y * hy) + e1z * hz;
         if (a < eps && a > -eps) continue;
-        const float inv_a = 1.0f / a;
+        const float inv_a = lt_rcp_ieee(a);  // = 1.0f / a, bit for bit (lt_internal.h)
         const float sx = ox - t0.x, sy = oy - t0.y, sz = oz - t0.z;
         const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
         if (u < 0 || u > 1) continue;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_trace4(
         const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
         const float aa = (e1x * hx + e1y * hy) + e1z * hz;
         if (!(aa < eps && aa > -eps)) {
-          const float inv_a = 1.0f / aa;
+          const float inv_a = lt_rcp_ieee(aa);  // = 1.0f / aa, bit for bit (lt_internal.h)
           const float sx = ox - t0.x, sy = oy - t0.y, sz = oz - t0.z;
           const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
           if (!(u < 0 || u > 1)) {

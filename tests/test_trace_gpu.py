@@ -584,3 +584,18 @@ print("WIDE_OK", int((a["tri"] >= 0).sum()))
     assert res.returncode == 0 and "WIDE_OK" in res.stdout, res.stdout + res.stderr
     rs.close()
     sc.close()
+
+
+def test_five_instruction_reciprocal_is_the_ieee_division_for_every_float():
+    """The triangle test multiplies by inv_a = 1.0f / a (Triangle.h:35).  The kernels compute it with two Newton
+    steps on v_rcp_f32 for 2^-64 <= |a| <= 2^64 (lt_internal.h: lt_rcp_ieee) instead of the 10-instruction IEEE
+    division sequence; this compares the two for all 2^32 bit patterns."""
+    import ctypes as C
+    from lidar_transfer_amd import _lib
+    lib = _lib.load()
+    bad, fast = C.c_ulonglong(1), C.c_ulonglong(0)
+    lib.lt_debug_verify_rcp.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.lt_debug_verify_rcp.restype = C.c_int
+    assert lib.lt_debug_verify_rcp(C.byref(bad), C.byref(fast)) == 0
+    assert bad.value == 0, f"{bad.value} of 2^32 floats differ"
+    assert fast.value == 2 * 128 * (1 << 23) + 2   # 128 binades of each sign, plus +-2^64
