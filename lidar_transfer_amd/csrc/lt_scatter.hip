@@ -238,6 +238,23 @@ __device__ __forceinline__ float f_atan2(float y, float x) {
   return y < 0.f ? -r : r;
 }
 
+// elevation pair atan2(za, ra), atan2(zb, rb) for ra, rb >= 0: when both |z / r| <= 1 in every lane of the wave
+// (elevations within +-45 degrees -- everything a LiDAR sees except the ground right under it) the octant
+// reduction of f_atan2 is not needed: the same polynomial on t = z / r directly, 9 instructions instead of 17.
+__device__ __forceinline__ void f_atan_pair(float za, float ra, float zb, float rb, float& tha, float& thb) {
+#pragma clang fp contract(fast)
+  const float ta = za * f_rcp(ra), tb = zb * f_rcp(rb);
+  const bool easy = fabsf(ta) <= 1.0f && fabsf(tb) <= 1.0f;  // false for NaN / inf (r == 0)
+  if (__ballot(!easy) == 0ull) {  // wave-uniform: the common case has no general-path lane at all
+    const float qa = ta * ta, qb = tb * tb;
+    tha = ta * (0.99997726f + qa * (-0.33262347f + qa * (0.19354346f + qa * (-0.11643287f + qa * (0.05265332f + qa * -0.01172120f)))));
+    thb = tb * (0.99997726f + qb * (-0.33262347f + qb * (0.19354346f + qb * (-0.11643287f + qb * (0.05265332f + qb * -0.01172120f)))));
+  } else {
+    tha = f_atan2(za, ra);
+    thb = f_atan2(zb, rb);
+  }
+}
+
 __device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, float by) {  // |(0,0) - segment ab|^2
 #pragma clang fp contract(fast)
   const float ex = bx - ax, ey = by - ay;
@@ -320,8 +337,10 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   const float dlo2 = fmaxf((pierced ? 0.f : rho_edges2) + z_near * z_near, 0.0025f);
   const float pad = 3e-4f + 2e-4f * __builtin_amdgcn_rsqf(dlo2);
   // elevation: z / rho over the triangle
-  const float th_hi = f_atan2(zmax, zmax > 0.f ? rho_min : rho_max) + pad;
-  const float th_lo = f_atan2(zmin, zmin < 0.f ? rho_min : rho_max) - pad;
+  float th_hi, th_lo;
+  f_atan_pair(zmax, zmax > 0.f ? rho_min : rho_max, zmin, zmin < 0.f ? rho_min : rho_max, th_hi, th_lo);
+  th_hi += pad;
+  th_lo -= pad;
   // rows whose rays can lie inside [th_lo, th_hi]; LT_BIN_SLACK covers the float rounding of the coordinates
   const float de = P.dev_el + LT_BIN_SLACK, da = P.dev_az + LT_BIN_SLACK;
   const float fe0 = ceilf((th_lo - P.el_lo) * P.el_scale - de), fe1 = floorf((th_hi - P.el_lo) * P.el_scale + de);
