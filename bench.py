@@ -406,11 +406,13 @@ def main():
         """Outside the clock: the dominant kernel alone on an otherwise idle GPU (one scan at a time).  `frac`
         above is measured inside the timed region, where `streams_per_gpu` scans share the chip and every
         launch is stretched by its neighbours; this is the same kernel without them."""
-        w, ts = workers[0], []
-        for i in range(n + 4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            w.set_mesh(*scenes[i % len(scenes)])
-            with torch.cuda.stream(streams[0]):
+        # back to back on ONE stream (launches of one stream do not overlap), one synchronisation at the end: a
+        # host round trip between launches lets the GPU drop its clocks and measures that instead
+        w, evs = workers[0], []
+        with torch.cuda.stream(streams[0]):
+            for i in range(n + 8):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w.set_mesh(*scenes[i % len(scenes)])
                 if strategy == "lbvh":
                     w.build()
                     w.set_probe(e0, e1)
@@ -418,10 +420,9 @@ def main():
                 else:
                     w.set_probe(e0, e1)
                     w.render(raysets[0], origin, out=scratch[0])
-            torch.cuda.synchronize()
-            if i >= 4:
-                ts.append(e0.elapsed_time(e1))
-        return float(np.mean(ts))
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs[8:]]))
 
     dt, kern_ms, hits = run(args.strategy, K, Wm, keep=True)
     other = None
@@ -439,7 +440,8 @@ def main():
         rl["isolated"] = {"avg_kernel_ms": round(iso_ms, 5),
                           "achieved": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9, 1),
                           "frac": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "note": "same kernel, one scan at a time on an idle GPU, measured after the timed region"}
+                          "note": "same kernel, launches of ONE scan each, back to back on one stream (nothing beside "
+                                  "them), after the timed region"}
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
