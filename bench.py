@@ -146,6 +146,10 @@ def main():
     K, Wm, S = args.steps, args.warmup, max(1, args.streams)
     args.batch = min(max(1, args.batch), 8)  # lt_scene_render_batch_dev takes at most 8 scans
     S = (S + args.batch - 1) // args.batch * args.batch  # whole batches of workers
+    # every timed scan keeps its range + label image (8 B per ray) and rank 0 also holds the peers' (6 B per ray)
+    need = K * R * 8 + (K * R * 6 * (world - 1) if rank == 0 else 0)
+    if need > 0.7 * torch.cuda.get_device_properties(dev).total_memory:
+        raise SystemExit(f"bench.py: --steps {K} keeps {need / 2**30:.0f} GiB of images on this rank; use fewer steps")
 
     # ---- synthetic inputs, resident in HBM before the clock starts -----------------------------------
     scenes = []
