@@ -123,6 +123,11 @@ sys.stderr.write("LTBASE " + json.dumps({"times": ts, "threads": ob.num_threads(
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: RCCL prints a version banner to stdout when its communicator is created
+    # (and libraries may print what they like) -- everything else that is written to fd 1 goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from lidar_transfer_amd.dist import gather_to_root
@@ -470,7 +475,8 @@ def main():
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_baseline"] = round(value / world / cb["value"], 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())  # the ONE line on stdout
     for rs in raysets:
         rs.close()
     for wk in workers:
