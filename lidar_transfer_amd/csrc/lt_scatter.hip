@@ -555,9 +555,10 @@ __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_para
     // local / na: (local + 0.5) / na is >= 0.5 / na away from an integer and local / na <= LT_SC_BIG / na, so
     // a relative error of 2^-22 in the product cannot cross one
     const int row = (int)(((float)local + 0.5f) * ldf(S.rinv, j4));
-    int az = ldi(S.ra0, j4) + (local - row * na);
+    // rows < 4096 and columns <= 8192 (lt_rayset_create_dev): 24-bit multiplies, full rate (v_mul_lo_u32 is 1/4)
+    int az = ldi(S.ra0, j4) + (local - __mul24(row, na));
     if (az >= P.nb_az) az -= P.nb_az;
-    return (ldi(S.re0, j4) + row) * P.nb_az + az;
+    return __mul24(ldi(S.re0, j4) + row, P.nb_az) + az;
   };
   int c = c_begin + (int)threadIdx.x;
   if (c < c_end) {
