@@ -301,16 +301,9 @@ static std::vector<float> g_rs_rays;
 static int g_rs_height = 0;
 static unsigned g_rs_norm = 0;
 
-extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
-                            const int* colors, const float* rem, int n_rays, int n_verts, int n_faces,
-                            int height, float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
-                            lt_stats* stats) {
-  if (height <= 0 || n_rays < 0 || !origin || (n_rays > 0 && !rays)) {
-    lt_set_error("lt_ctrace: invalid argument (n_rays=%d height=%d)", n_rays, height);
-    return LT_ERR_INVALID_ARG;
-  }
-  LT_CHECK(check_mesh_args("lt_ctrace", verts, faces, colors, rem, n_verts, n_faces));
-  std::lock_guard<std::mutex> lock(g_mu);
+static int ctrace_locked(const float* rays, const float* origin, const float* verts, const int* faces,
+                         const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
+                         float* endpoints, int* endcolors, float* range, float* endrem, int* tri, lt_stats* stats) {
   int dev = 0;
   LT_HIP(hipGetDevice(&dev));
   if (g_scene && g_scene_dev != dev) {
@@ -400,6 +393,23 @@ extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float*
   LT_HIP(hipStreamSynchronize(stream));
   if (stats) *stats = st;
   return lt_scene_status(s);
+}
+
+extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
+                            const int* colors, const float* rem, int n_rays, int n_verts, int n_faces,
+                            int height, float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
+                            lt_stats* stats) {
+  if (height <= 0 || n_rays < 0 || !origin || (n_rays > 0 && !rays)) {
+    lt_set_error("lt_ctrace: invalid argument (n_rays=%d height=%d)", n_rays, height);
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_CHECK(check_mesh_args("lt_ctrace", verts, faces, colors, rem, n_verts, n_faces));
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int rc = ctrace_locked(rays, origin, verts, faces, colors, rem, n_rays, n_verts, n_faces, height, endpoints,
+                               endcolors, range, endrem, tri, stats);
+  // a failure half way may leave copies from / to the caller's arrays queued: they must not outlive the call
+  if (rc != LT_OK) (void)hipStreamSynchronize(nullptr);
+  return rc;
 }
 
 extern "C" int lt_ctrace(const float* rays, const float* origin, const float* verts, const int* faces,

@@ -62,7 +62,7 @@ struct lt_scene {
   int np;               // segment-tree leaf count (power of two >= n_faces)
   uint32_t* keys[2];
   uint32_t* vals[2];
-  uint32_t* hist;       // [256 * n_sort_blocks + 256 digit totals]
+  uint32_t* hist;       // [1024 digits * n_sort_tiles + 1024 digit totals] (lt_build.hip, LT_RD)
   float4* tris;         // [3 * n_faces]
   float4* seg;          // [2 * 2 * np]
   float4* nodes;        // [4 * max(n_faces - 1, 1)]   binary nodes (64 B)
@@ -70,8 +70,8 @@ struct lt_scene {
   float* partial;       // per-workgroup bounds partials [6 * LT_BOUNDS_BLOCKS]
   float* params;        // device: lo.xyz, scale, pad
   unsigned* flags;      // device: [0] error bits
-  unsigned long long* counters;  // device: nodes, tris, hits, overflows
-  int* overflow;        // [n_rays_cap * (LT_STACK_MAX - LT_STACK_LDS)] spill area
+  unsigned long long* counters;  // device: nodes, tris, hits, overflows (LT_TRACE_COUNT), then LT_DBG_WAVES clock pairs
+  int* overflow;        // [cap_rays * (LT_STACK4_MAX - LT_STACK4_LDS)] stack spill area
   int cap_rays;
   int built;
   hipStream_t last_stream;

@@ -108,55 +108,36 @@ __global__ __launch_bounds__(256) void k_project(const T* __restrict__ pts, int 
   if (threadIdx.x == 0) blockcount[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
-// exclusive scan of the workgroup counts (single workgroup), total -> blockcount[nblocks]
-__global__ __launch_bounds__(1024) void k_scan_counts(int* __restrict__ blockcount, int nblocks) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int carry = 0;
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < nblocks ? blockcount[i] : 0;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    if (i < nblocks) blockcount[i] = carry + woff + inc - v;
-    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-    __syncthreads();
-    carry = carry_s;
-  }
-  if (threadIdx.x == 0) blockcount[nblocks] = carry;
-}
-
-// pass 2: compacted index of every kept point (stable), compacted per-point outputs, index z-min
+// pass 2: compacted index of every kept point (stable), compacted per-point outputs, index z-min.
+// Every workgroup sums the kept-counts of the workgroups before it itself (n / 256 integers from L2: cheaper
+// than a scan kernel between the two passes); the last one also leaves the total in blockcount[gridDim.x].
 template <typename T>
 __global__ __launch_bounds__(256) void k_assign(const T* __restrict__ pts, const float* __restrict__ rem,
                                                 const unsigned* __restrict__ label, int n, int W,
                                                 const int* __restrict__ cell, const double* __restrict__ depth_d,
                                                 const T* __restrict__ xf, const T* __restrict__ yf,
                                                 const unsigned long long* __restrict__ cellmin,
-                                                const int* __restrict__ blockoff, int round_key,
+                                                int* __restrict__ blockcount, int round_key,
                                                 int* __restrict__ idxmin, int* __restrict__ idxlast,
                                                 int* __restrict__ orig_of, T* __restrict__ pts_k,
                                                 float* __restrict__ rem_k, unsigned* __restrict__ label_k,
                                                 T* __restrict__ depth_k, int* __restrict__ px_k,
                                                 int* __restrict__ py_k, T* __restrict__ xf_k, T* __restrict__ yf_k) {
-  __shared__ int wcnt[4];
+  __shared__ int wcnt[4], wbefore[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = i < n ? cell[i] : -1;
   const bool keep = c >= 0;
   const unsigned long long m = __ballot(keep);
-  if (lane == 0) wcnt[wave] = __popcll(m);
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += blockcount[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) { wcnt[wave] = __popcll(m); wbefore[wave] = before; }
   __syncthreads();
-  int off = blockoff[blockIdx.x];
+  int off = (wbefore[0] + wbefore[1]) + (wbefore[2] + wbefore[3]);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    blockcount[gridDim.x] = off + (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);  // number of kept points
   for (int w = 0; w < wave; ++w) off += wcnt[w];
   if (!keep) return;
   const int k = off + __popcll(m & ((1ull << lane) - 1ull));
@@ -184,11 +165,13 @@ __global__ __launch_bounds__(256) void k_assign(const T* __restrict__ pts, const
   }
 }
 
-// pass 3: one thread per cell gathers the winner (laserscan.py:283-292, :376-382, :645-649)
+// pass 3: one thread per cell gathers the winner (laserscan.py:283-292, :376-382, :645-649) and re-arms the
+// cell's three z-min words for the next projection (no memsets between calls)
 template <typename T>
 __global__ __launch_bounds__(256) void k_resolve(const T* __restrict__ pts, const float* __restrict__ rem,
                                                  const unsigned* __restrict__ label, const double* __restrict__ depth_d,
-                                                 const int* __restrict__ idxmin, const int* __restrict__ idxlast,
+                                                 unsigned long long* __restrict__ cellmin,
+                                                 int* __restrict__ idxmin, int* __restrict__ idxlast,
                                                  const int* __restrict__ orig_of, int ncells, const float* __restrict__ lut, int lut_len,
                                                  float range_init, float rem_init, float xyz_init,
                                                  int* __restrict__ idx_img, float* __restrict__ range_img,
@@ -201,6 +184,9 @@ __global__ __launch_bounds__(256) void k_resolve(const T* __restrict__ pts, cons
   // of that bucket lie below the float32 minimum -- then the last of those (idxlast is -1 otherwise and
   // always for float32 input, where rounding is the identity)
   const int first = idxmin[c], last = idxlast[c];
+  cellmin[c] = ~0ull;
+  idxmin[c] = LT_EMPTY_IDX;
+  idxlast[c] = -1;
   const int k = (last >= 0 && last != first) ? last : first;
   const bool has = first != LT_EMPTY_IDX;
   const int i = has ? orig_of[k] : 0;
@@ -268,6 +254,7 @@ struct proj_ws {
   int* idxmin = nullptr;
   int* idxlast = nullptr;
   double* beams = nullptr;
+  bool armed = false;  // cellmin / idxmin / idxlast hold their empty patterns (k_resolve leaves them so)
 };
 std::mutex g_pmu;
 proj_ws g_pws;
@@ -313,24 +300,26 @@ int run_projection(proj_ws& w, const T* pts, const float* rem, const unsigned* l
   const double fov = fabs(fd) + fabs(fu);
   const int cells = H * W;
   const int nb = (n + 255) / 256;
-  LT_HIP(hipMemsetAsync(w.cellmin, 0xFF, (size_t)cells * sizeof(unsigned long long), st));
-  LT_HIP(hipMemsetAsync(w.idxmin, 0x7F, (size_t)cells * sizeof(int), st));
-  LT_HIP(hipMemsetAsync(w.idxlast, 0xFF, (size_t)cells * sizeof(int), st));
+  if (!w.armed) {  // first use of the workspace, or the previous call failed half way
+    LT_HIP(hipMemsetAsync(w.cellmin, 0xFF, w.cap_cells * sizeof(unsigned long long), st));
+    LT_HIP(hipMemsetAsync(w.idxmin, 0x7F, w.cap_cells * sizeof(int), st));
+    LT_HIP(hipMemsetAsync(w.idxlast, 0xFF, w.cap_cells * sizeof(int), st));
+  }
+  w.armed = false;
   const int round_key = (flags & LT_PROJ_NEW) ? 1 : 0;
   if (n > 0) {
     hipLaunchKernelGGL(k_project<T>, dim3(nb), dim3(256), 0, st, pts, n, (T)M_PI, (T)fabs(fd), (T)fov, H, W,
                        (const double*)w.beams, n_beams, (flags & (LT_PROJ_REMOVE | LT_PROJ_NEW)) ? 1 : 0,
                        (flags & LT_PROJ_REMOVE) ? 1 : 0, round_key, w.cell, w.depth_d, (T*)w.xf, (T*)w.yf, w.cellmin,
                        w.blockcount);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.blockcount, nb);
     hipLaunchKernelGGL(k_assign<T>, dim3(nb), dim3(256), 0, st, pts, rem, label, n, W, (const int*)w.cell,
                        (const double*)w.depth_d, (const T*)w.xf, (const T*)w.yf,
-                       (const unsigned long long*)w.cellmin, (const int*)w.blockcount, round_key, w.idxmin,
+                       (const unsigned long long*)w.cellmin, w.blockcount, round_key, w.idxmin,
                        w.idxlast, w.orig_of, pts_k,
                        rem_k, label_k, depth_k, px_k, py_k, xf_k, yf_k);
   }
   hipLaunchKernelGGL(k_resolve<T>, dim3((cells + 255) / 256), dim3(256), 0, st, pts, rem, label,
-                     (const double*)w.depth_d, (const int*)w.idxmin, (const int*)w.idxlast, (const int*)w.orig_of,
+                     (const double*)w.depth_d, w.cellmin, w.idxmin, w.idxlast, (const int*)w.orig_of,
                      cells, lut, lut_len,
                      range_init, rem_init, xyz_init, idx_img, range_img, xyz_img, rem_img, label_img, color_img,
                      mask_img);
@@ -338,6 +327,7 @@ int run_projection(proj_ws& w, const T* pts, const float* rem, const unsigned* l
   int kept = 0;
   if (n > 0) LT_HIP(hipMemcpyAsync(&kept, w.blockcount + nb, sizeof(int), hipMemcpyDeviceToHost, st));
   LT_HIP(hipStreamSynchronize(st));
+  w.armed = true;
   if (n_kept) *n_kept = kept;
   return LT_OK;
 }
