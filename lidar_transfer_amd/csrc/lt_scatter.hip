@@ -324,8 +324,21 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   const float cmin = fminf(c0, fminf(c1, c2)), cmax = fmaxf(c0, fmaxf(c1, c2));
   const bool outside = cmin < -tol && cmax > tol;
   const bool edge_on = cmin >= -tol && cmax <= tol;
-  const float rho_edges2 =
-      fminf(seg_dist2d_sq(x0, y0, x1, y1), fminf(seg_dist2d_sq(x1, y1, x2, y2), seg_dist2d_sq(x2, y2, x0, y0)));
+  // rho_edges2 = a lower bound of the squared distance from the axis to the triangle's edges.  The closest point
+  // of an edge is at most half the edge away from one of its end points, at a right angle when it is interior:
+  // d^2 >= min(q) - L^2 / 4 with L the longest edge.  For a triangle small against its distance from the axis
+  // (every triangle of a 5 cm mesh beyond half a metre) that is within 0.13 % of the exact distance at a third
+  // of its cost; waves holding a triangle for which it is loose take the three exact point-segment distances.
+  const float e01x = x1 - x0, e01y = y1 - y0, e12x = x2 - x1, e12y = y2 - y1, e20x = x0 - x2, e20y = y0 - y2;
+  const float lmax2 = fmaxf(e01x * e01x + e01y * e01y, fmaxf(e12x * e12x + e12y * e12y, e20x * e20x + e20y * e20y));
+  const float qmin = fminf(q0, fminf(q1, q2));
+  float rho_edges2;
+  if (__ballot(!(lmax2 <= 0.01f * qmin)) == 0ull) {  // wave-uniform
+    rho_edges2 = qmin - 0.25f * lmax2;
+  } else {
+    rho_edges2 =
+        fminf(seg_dist2d_sq(x0, y0, x1, y1), fminf(seg_dist2d_sq(x1, y1, x2, y2), seg_dist2d_sq(x2, y2, x0, y0)));
+  }
   const float rho_edges = f_sqrt(rho_edges2);
   const float rho_tiny = 1e-4f * rho_max + 1e-6f;
   const bool pierced = !(outside || (edge_on && rho_edges > rho_tiny));
