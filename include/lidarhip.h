@@ -127,7 +127,9 @@ typedef struct lt_rayset lt_rayset; /* opaque: normalised directions of one ray 
  * directions exactly as the trace kernel does (Vector3.h:73-89; flags & LT_TRACE_NORM_EXACT selects
  * the seed) and bin them by azimuth x elevation.  A sensor model's rays do not change from scan to
  * scan (create_rays, laserscan.py:1092-1119, depends only on the YAML), so one rayset serves a whole
- * sequence.  `rays` is not referenced after the call has completed on `stream`. */
+ * sequence -- it is read-only once created (the state of a render lives in the scene), so ONE rayset can be used by
+ * any number of scenes and streams at the same time.  `rays` is not referenced after the call has completed on
+ * `stream`; the rayset must not be used on another stream before that either. */
 int lt_rayset_create_dev(lt_rayset** rayset, const float* rays, int n_rays, int height, unsigned flags,
                          void* stream);
 int lt_rayset_destroy(lt_rayset* rayset);
@@ -137,13 +139,15 @@ int lt_rayset_destroy(lt_rayset* rayset);
  * bins inside its angular bounds and merges hits by atomic min over (t, face).  Same outputs, flags and
  * bit-identical results as lt_scene_build + lt_scene_trace_dev; replaces BVH::build + the ray loop
  * (BVH.cpp:143-243, RayTracer.cpp:62-92) for the reference's only call pattern, one origin per call
- * (RayTracer.cpp:58).  One render per rayset may be in flight at a time. */
+ * (RayTracer.cpp:58).  A scene renders one scan at a time (its mesh and its z-min image are per scene); the
+ * rayset may be shared. */
 int lt_scene_render_dev(lt_scene* scene, lt_rayset* rayset, const float* origin, float* endpoints,
                         int* endcolors, float* range, float* endrem, int* tri, unsigned flags, void* stream,
                         lt_stats* stats);
 
-/* The same for up to 8 scans in ONE call -- n_scans (scene, rayset) pairs, each scene with its own current
- * mesh, each rayset distinct; origins[3 * i ..] is scan i's origin (HOST), the output arguments are HOST arrays
+/* The same for up to 8 scans in ONE call -- n_scans (scene, rayset) pairs, the scenes distinct and each with
+ * its own current mesh, the raysets normally all the same one (one sensor model: its bin grid then stays in
+ * every L2); origins[3 * i ..] is scan i's origin (HOST), the output arguments are HOST arrays
  * of n_scans DEVICE pointers (an array, or single entries of it, may be NULL).  The three kernels of the
  * scatter strategy are launched once for the whole batch instead of once per scan: with tens of thousands of
  * scans per second, the time a hardware queue spends between small kernels is what limits throughput

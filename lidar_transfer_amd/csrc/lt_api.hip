@@ -124,6 +124,10 @@ extern "C" int lt_scene_destroy(lt_scene* s) {
   if (s->flags) (void)hipFree(s->flags);
   if (s->counters) (void)hipFree(s->counters);
   if (s->overflow) (void)hipFree(s->overflow);
+  if (s->sc_cell) (void)hipFree(s->sc_cell);
+  if (s->sc_large) (void)hipFree(s->sc_large);
+  if (s->sc_slices) (void)hipFree(s->sc_slices);
+  if (s->sc_large_count) (void)hipFree(s->sc_large_count);
   for (int k = 0; k < s->have_events; ++k) (void)hipEventDestroy(s->ev[k]);
   free(s);
   return LT_OK;

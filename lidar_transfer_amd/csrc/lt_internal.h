@@ -73,6 +73,13 @@ struct lt_scene {
   unsigned long long* counters;  // device: nodes, tris, hits, overflows (LT_TRACE_COUNT), then LT_DBG_WAVES clock pairs
   int* overflow;        // [cap_rays * (LT_STACK4_MAX - LT_STACK4_LDS)] stack spill area
   int cap_rays;
+  // scatter strategy (lt_scatter.hip): state of the render in flight -- per SCENE, so that a ray set is read-only
+  // during a render and one ray set (one sensor model) serves any number of scenes and streams at once
+  unsigned long long* sc_cell;  // [sc_cap_cells] packed (t, face) z-min per ray; all-ones = empty, re-armed by k_sc_resolve
+  int* sc_large;                // [sc_cap_queue] queue of big triangles
+  int2* sc_slices;              // [sc_cap_queue] queue of (block, first candidate) slices
+  int* sc_large_count;          // [4]: [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
+  int sc_cap_cells, sc_cap_queue;
   int built;
   hipStream_t last_stream;
   hipEvent_t probe[2];   // caller's events to record around the dominant kernel of the next cast (one shot)

@@ -817,16 +817,11 @@ struct lt_rayset {
   uint32_t* bin_rays;  // = vals[sorted buffer]
   float4* sdirs;       // directions in bin order, ray index in .w
   float4* grid;        // one entry per bin, see sc_test_cell
-  unsigned long long* cell;
-  int* large;
-  int* large_count;  // [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
-  int2* slices;
-  int cap_large, cap_slices;
-};
+};  // read-only once created: the state of a render lives in the scene (lt_internal.h)
 
 static void rs_free(lt_rayset* r) {
   void* ps[] = {r->grid, r->sdirs, r->dirs, r->ang, r->partial, r->prm, r->keys[0], r->keys[1], r->vals[0], r->vals[1], r->hist,
-                r->bin_start, r->cell, r->large, r->large_count, r->slices};
+                r->bin_start};
   for (void* p : ps)
     if (p) (void)hipFree(p);
 }
@@ -881,17 +876,13 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
   RS_ALLOC(r->hist, ((size_t)1024 * nb + 1024) * sizeof(uint32_t));
   RS_ALLOC(r->bin_start, (nbins + 1) * sizeof(int));
   RS_ALLOC(r->grid, nbins * sizeof(float4));
-  RS_ALLOC(r->cell, nn * sizeof(unsigned long long));
-  RS_ALLOC(r->large_count, 4 * sizeof(int));
 #undef RS_ALLOC
   if (rc != LT_OK) {
     rs_free(r);
     free(r);
     return rc;
   }
-  if (hipMemsetAsync(r->cell, 0xFF, nn * sizeof(unsigned long long), stream) != hipSuccess ||
-      hipMemsetAsync(r->large_count, 0, 4 * sizeof(int), stream) != hipSuccess ||
-      hipMemsetAsync(r->prm, 0, sizeof(rs_params), stream) != hipSuccess) {
+  if (hipMemsetAsync(r->prm, 0, sizeof(rs_params), stream) != hipSuccess) {
     lt_set_error("lt_rayset_create_dev: hipMemsetAsync failed");
     rs_free(r);
     free(r);
@@ -923,23 +914,40 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
   return LT_OK;
 }
 
-// queues of k_sc_tris: every triangle is queued at most once as "big", and a workgroup of 256 triangles with
-// <= LT_SC_BIG candidates each leaves at most 256 * LT_SC_BIG / LT_SC_SLICE = 256 slices
-static int rs_reserve_large(lt_rayset* r, int n_faces) {
-  if (n_faces <= r->cap_large) return LT_OK;
-  if (r->large || r->slices) {
-    LT_HIP(hipDeviceSynchronize());
-    (void)hipFree(r->large);
-    (void)hipFree(r->slices);
-    r->large = nullptr;
-    r->slices = nullptr;
-    r->cap_large = r->cap_slices = 0;
+// Per-scene state of a render: the z-min cells (one per ray, armed = all-ones; k_sc_resolve re-arms what it reads,
+// so they are set once per allocation) and the queues of k_sc_tris -- every triangle is queued at most once as
+// "big", and a block of 256 triangles with <= LT_SC_BIG candidates each leaves at most
+// 256 * LT_SC_BIG / LT_SC_SLICE = 256 slices.
+static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) {
+  if (!s->sc_large_count) {
+    LT_HIP(hipMalloc((void**)&s->sc_large_count, 4 * sizeof(int)));
+    LT_HIP(hipMemsetAsync(s->sc_large_count, 0, 4 * sizeof(int), stream));
   }
-  const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
-  LT_HIP(hipMalloc((void**)&r->large, cap * sizeof(int)));
-  LT_HIP(hipMalloc((void**)&r->slices, cap * sizeof(int2)));
-  r->cap_large = (int)cap;
-  r->cap_slices = (int)cap;
+  if (n_rays > s->sc_cap_cells) {
+    if (s->sc_cell) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(s->sc_cell);
+      s->sc_cell = nullptr;
+      s->sc_cap_cells = 0;
+    }
+    LT_HIP(hipMalloc((void**)&s->sc_cell, (size_t)n_rays * sizeof(unsigned long long)));
+    s->sc_cap_cells = n_rays;
+    LT_HIP(hipMemsetAsync(s->sc_cell, 0xFF, (size_t)n_rays * sizeof(unsigned long long), stream));
+  }
+  if (n_faces > s->sc_cap_queue) {
+    if (s->sc_large || s->sc_slices) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(s->sc_large);
+      (void)hipFree(s->sc_slices);
+      s->sc_large = nullptr;
+      s->sc_slices = nullptr;
+      s->sc_cap_queue = 0;
+    }
+    const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
+    LT_HIP(hipMalloc((void**)&s->sc_large, cap * sizeof(int)));
+    LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int2)));
+    s->sc_cap_queue = (int)cap;
+  }
   return LT_OK;
 }
 
@@ -967,16 +975,16 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     lt_rayset* r = it[i].r;
     const int n = s->n_faces, R = r->n_rays;
     if (R <= 0) continue;  // nothing to write for this scan
-    LT_CHECK(rs_reserve_large(r, n));
+    LT_CHECK(sc_reserve(s, n, R, stream));
     sc_job& J = B.job[B.n++];
     J.verts = s->verts; J.faces = s->faces; J.colors = s->colors; J.rem = s->rem;
     J.prm = r->prm; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
-    J.cell = r->cell; J.large = r->large; J.large_count = r->large_count; J.slices = r->slices;
+    J.cell = s->sc_cell; J.large = s->sc_large; J.large_count = s->sc_large_count; J.slices = s->sc_slices;
     J.flags = s->flags; J.counters = s->counters;
     J.endpoints = it[i].endpoints; J.endcolors = it[i].endcolors; J.range = it[i].range; J.endrem = it[i].endrem;
     J.tri = it[i].tri;
     J.ox = it[i].origin[0]; J.oy = it[i].origin[1]; J.oz = it[i].origin[2];
-    J.n_verts = s->n_verts; J.n_faces = n; J.n_rays = R; J.cap_slices = r->cap_slices;
+    J.n_verts = s->n_verts; J.n_faces = n; J.n_rays = R; J.cap_slices = s->sc_cap_queue;
     J.out_flags = flags;
     J.tris_block0 = tb;
     J.resolve_block0 = rb;
@@ -1081,8 +1089,8 @@ extern "C" int lt_scene_render_batch_dev(int n_scans, lt_scene* const* scenes, l
       return LT_ERR_INVALID_ARG;
     }
     for (int k = 0; k < i; ++k)
-      if (raysets[k] == raysets[i]) {
-        lt_set_error("lt_scene_render_batch_dev: scans %d and %d share a rayset (one render per rayset at a time)", k, i);
+      if (scenes[k] == scenes[i]) {
+        lt_set_error("lt_scene_render_batch_dev: scans %d and %d are the same scene (a scene renders one scan at a time)", k, i);
         return LT_ERR_INVALID_ARG;
       }
     it[i] = {scenes[i], raysets[i], origins + 3 * i, endpoints ? endpoints[i] : nullptr,

@@ -198,7 +198,7 @@ class Scene:
     @staticmethod
     def render_batch(scenes, raysets, origins, outs=None, stream=None, write_misses=True, label_image=False):
         """``lt_scene_render_batch_dev``: the scans ``(scenes[i], raysets[i], origins[i])`` -- at most 8, every
-        scene with its own current mesh, every rayset distinct -- rendered with three kernel launches for all of
+        scene distinct and with its own current mesh, the raysets normally one shared ray set -- rendered with three kernel launches for all of
         them.  Returns the list of output dicts (``outs[i]`` or freshly allocated)."""
         n = len(scenes)
         if not (n == len(raysets) == len(origins)) or (outs is not None and len(outs) != n):

@@ -479,10 +479,66 @@ def test_render_batch_equals_separate_renders():
     for a, b in zip(single[::-1][:3], outs2):
         assert torch.equal(a["range"].view(torch.int32), b["range"].view(torch.int32))
     with pytest.raises(RuntimeError):
-        Scene.render_batch([scenes[0], scenes[1]], [raysets[0], raysets[0]], origins[:2])   # shared rayset
+        Scene.render_batch([scenes[0], scenes[0]], [raysets[0], raysets[1]], origins[:2])   # one scene, two scans
     for sc in scenes:
         sc.status()
     for rs in raysets:
+        rs.close()
+    for sc in scenes:
+        sc.close()
+
+
+def test_one_rayset_shared_by_scenes_and_streams():
+    """A ray set is read-only during renders (the z-min image of a scan in flight belongs to its scene): ONE ray
+    set must serve several scenes in one batch call and renders running concurrently on different streams, each
+    image identical to the one a private ray set gives."""
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    H, W = 32, 1024
+    rays = torch.from_numpy(create_rays(3.0, -25.0, H, W)).to(dev)
+    shared = RaySet(rays, H)
+    torch.cuda.synchronize()
+    meshes = [synth_scene(40 + i, 40000 + 15000 * i) for i in range(6)]
+    origins = [(0.1 * i, -0.2 * i, 0.05 * i) for i in range(6)]
+    scenes, want = [], []
+    for (v, f, c, r), org in zip(meshes, origins):
+        sc = Scene(0)
+        sc.set_mesh(*[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (v, f, c, r)])
+        private = RaySet(rays, H)
+        want.append({k: t.clone() for k, t in sc.render(private, org).items()})
+        torch.cuda.synchronize()
+        private.close()
+        scenes.append(sc)
+    # (a) one batch call, the same ray set six times
+    outs = Scene.render_batch(scenes, [shared] * 6, origins)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, outs)):
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), f"batch, scan {i}: {k} differs"
+    # (b) single renders of all scenes in flight at once on their own streams, several rounds
+    streams = [torch.cuda.Stream(dev) for _ in scenes]
+    bufs = [sc.alloc_outputs(H * W) for sc in scenes]
+    for _ in range(5):
+        for sc, st, org, o in zip(scenes, streams, origins, bufs):
+            sc.render(shared, org, out=o, stream=st)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, bufs)):
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), f"streams, scan {i}: {k} differs"
+    assert int((bufs[0]["tri"] >= 0).sum()) > 1000
+    # (c) one scene, ray sets of different sizes one after the other (its cells grow and stay armed)
+    small = RaySet(torch.from_numpy(create_rays(3.0, -25.0, 8, 128)).to(dev), 8)
+    big = RaySet(torch.from_numpy(create_rays(3.0, -25.0, 64, 2048)).to(dev), 64)
+    a1 = {k: t.clone() for k, t in scenes[0].render(small, origins[0]).items()}
+    b1 = {k: t.clone() for k, t in scenes[0].render(big, origins[0]).items()}
+    a2 = scenes[0].render(small, origins[0])
+    b2 = scenes[0].render(big, origins[0])
+    for x, y in ((a1, a2), (b1, b2)):
+        for k in ("tri", "range"):
+            assert torch.equal(x[k].view(torch.int32), y[k].view(torch.int32))
+    torch.cuda.synchronize()
+    for rs in (shared, small, big):
         rs.close()
     for sc in scenes:
         sc.close()
