@@ -466,9 +466,10 @@ __global__ __launch_bounds__(256) void k_rs_grid(const int* __restrict__ bin_sta
 
 // LDS state of one workgroup = 256 consecutive triangles
 struct sc_shared {
-  float tr[9][256];       // v0, e1, e2
-  int ra0[256], rna[256], re0[256];
-  float rinv[256];
+  // triangle record = three 16-B words (one ds_read_b128 each; phase B is sensitive to the NUMBER of LDS
+  // instructions -- a 4-ary search with 12 reads instead of the binary search's 9 cost 9 %):
+  //   q0 = (v0.x, v0.y, v0.z, e1.x)   q1 = (e1.y, e1.z, e2.x, e2.y)   q2 = (e2.z, a0 | na << 16, e0, 1 / na)
+  float4 q0[256], q1[256], q2[256];
   int pre[257];           // exclusive prefix sum of the candidate counts
   int wsum[4];
   int kept;
@@ -500,11 +501,11 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
           if (PUSH) large[atomicAdd(large_count, 1)] = f;
         } else {
           cnt = c32;
-          S.tr[0][tid] = v0x; S.tr[1][tid] = v0y; S.tr[2][tid] = v0z;
-          S.tr[3][tid] = v1x - v0x; S.tr[4][tid] = v1y - v0y; S.tr[5][tid] = v1z - v0z;
-          S.tr[6][tid] = v2x - v0x; S.tr[7][tid] = v2y - v0y; S.tr[8][tid] = v2z - v0z;
-          S.ra0[tid] = R.a0; S.rna[tid] = R.na; S.re0[tid] = R.e0;
-          S.rinv[tid] = f_rcp((float)R.na);  // 1-ulp reciprocal is enough, see sc_round_robin
+          S.q0[tid] = make_float4(v0x, v0y, v0z, v1x - v0x);
+          S.q1[tid] = make_float4(v1y - v0y, v1z - v0z, v2x - v0x, v2y - v0y);
+          // a0 < 8192, na <= LT_SC_BIG; 1-ulp reciprocal is enough, see sc_round_robin
+          S.q2[tid] = make_float4(v2z - v0z, __int_as_float(R.a0 | (R.na << 16)), __int_as_float(R.e0),
+                                  f_rcp((float)R.na));
         }
       }
     } else if (PUSH) {
@@ -557,39 +558,45 @@ __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_para
                                                unsigned& n_tests, unsigned& n_cand) {
   // LDS slots are addressed by BYTE offset j4 = 4 * j throughout (one shift less per search step / array read)
   auto ldi = [](const int* arr, unsigned j4) { return *(const int*)((const char*)arr + j4); };
-  auto ldf = [](const float* arr, unsigned j4) { return *(const float*)((const char*)arr + j4); };
-  auto locate = [&](int c, unsigned& j4) -> int {  // triangle j = largest j with pre[j] <= c; returns the bin
+  auto ldq = [](const float4* arr, unsigned j4) { return *(const float4*)((const char*)arr + 4u * j4); };
+  // triangle j = largest j with pre[j] <= c; returns the bin and the record's third word
+  auto locate = [&](int c, unsigned& j4, float4& q2) -> int {
     j4 = 0;
 #pragma unroll
     for (unsigned step4 = 512; step4 >= 4; step4 >>= 1)
       if (ldi(S.pre, j4 + step4) <= c) j4 += step4;
     const int local = c - ldi(S.pre, j4);
-    const int na = ldi(S.rna, j4);
+    q2 = ldq(S.q2, j4);
+    const int ab = __float_as_int(q2.y);
+    const int na = ab >> 16;
     // local / na: (local + 0.5) / na is >= 0.5 / na away from an integer and local / na <= LT_SC_BIG / na, so
     // a relative error of 2^-22 in the product cannot cross one
-    const int row = (int)(((float)local + 0.5f) * ldf(S.rinv, j4));
+    const int row = (int)(((float)local + 0.5f) * q2.w);
     // rows < 4096 and columns <= 8192 (lt_rayset_create_dev): 24-bit multiplies, full rate (v_mul_lo_u32 is 1/4)
-    int az = ldi(S.ra0, j4) + (local - __mul24(row, na));
+    int az = (ab & 0xFFFF) + (local - __mul24(row, na));
     if (az >= P.nb_az) az -= P.nb_az;
-    return __mul24(ldi(S.re0, j4) + row, P.nb_az) + az;
+    return __mul24(__float_as_int(q2.z) + row, P.nb_az) + az;
   };
   int c = c_begin + (int)threadIdx.x;
   if (c < c_end) {
     unsigned j4;
-    float4 g = *at<false>(grid, (unsigned)locate(c, j4));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
+    float4 q2;
+    float4 g = *at<false>(grid, (unsigned)locate(c, j4, q2));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
     for (;;) {
       // branch-free prefetch (index clamped to the last candidate) so the load stays in flight across the test
       const int cn = c + 256;
       unsigned jn4;
-      const float4 gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn4));
+      float4 q2n;
+      const float4 gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn4, q2n));
+      const float4 q0 = ldq(S.q0, j4), q1 = ldq(S.q1, j4);
       tri_rec T;
-      T.v0x = ldf(S.tr[0], j4); T.v0y = ldf(S.tr[1], j4); T.v0z = ldf(S.tr[2], j4);
-      T.e1x = ldf(S.tr[3], j4); T.e1y = ldf(S.tr[4], j4); T.e1z = ldf(S.tr[5], j4);
-      T.e2x = ldf(S.tr[6], j4); T.e2y = ldf(S.tr[7], j4); T.e2z = ldf(S.tr[8], j4);
+      T.v0x = q0.x; T.v0y = q0.y; T.v0z = q0.z;
+      T.e1x = q0.w; T.e1y = q1.x; T.e1z = q1.y;
+      T.e2x = q1.z; T.e2y = q1.w; T.e2z = q2.x;
       if (COUNT) ++n_cand;
       sc_test_cell<WIDE>(T, first_face + (int)(j4 >> 2), g, sdirs, ox, oy, oz, cell, n_tests);
       if (cn >= c_end) break;
-      c = cn; j4 = jn4; g = gn;
+      c = cn; j4 = jn4; g = gn; q2 = q2n;
     }
   }
 }
