@@ -544,6 +544,41 @@ def test_one_rayset_shared_by_scenes_and_streams():
         sc.close()
 
 
+def test_handles_release_their_device_memory():
+    """Scene / ray-set handles own device memory (LBVH workspace, z-min cells, queues, bin grid): creating, using and
+    destroying them in a loop must leave the free device memory where it was."""
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    v, f, c, r = synth_scene(3, 30000)
+    mesh = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (v, f, c, r)]
+    rays = torch.from_numpy(create_rays(3.0, -25.0, 32, 512)).to(dev)
+
+    def cycle():
+        sc = Scene(0)
+        rs = RaySet(rays, 32)
+        sc.set_mesh(*mesh)
+        a = sc.render(rs, (0.0, 0.0, 0.0))
+        sc.build()
+        b = sc.trace(rays, (0.0, 0.0, 0.0), 32)
+        assert torch.equal(a["tri"], b["tri"])
+        del a, b
+        rs.close()
+        sc.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory lost in 40 create/destroy cycles"
+
+
 @pytest.mark.parametrize("wl,seed,origin", [("C1", 5, (0.0, 0.0, 0.0)), ("C2", 2, (0.0, 0.0, 0.0)),
                                             ("C3", 1, (1.5, -2.25, 0.4)), ("C4", 0, (0.0, 0.0, 0.0))])
 def test_scatter_equals_lbvh_at_baseline_sizes(wl, seed, origin):
