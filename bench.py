@@ -406,8 +406,10 @@ def main():
         ach = alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section); collected on workload C2 only
-        # (profiles/r01/e_pmc_scatter.txt: k_sc_tris; profiles/r01/b_pmc_lbvh.txt: k_trace4)
-        traffic = {"scatter": 45.0e6 * spl, "lbvh": 12.4e6}[strategy] if args.workload == "C2" else None
+        # (k_sc_tris: profiles/r01/f_pmc_bench.txt, the passes run on this very command -- 351.9 MB per launch of
+        # 8 scans, 44.3 MB per single-scan launch; k_trace4: profiles/r01/b_pmc_lbvh.txt)
+        traffic = {"scatter": 351.9e6 * spl / 8 if spl > 1 else 44.3e6, "lbvh": 12.4e6}[strategy] \
+            if args.workload == "C2" else None
         d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
              "algorithmic_bytes_per_launch": int(alg), "scans_per_launch": spl,
