@@ -458,6 +458,15 @@ def main():
                           "frac": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "same kernel, launches of ONE scan each, back to back on one stream (nothing beside "
                                   "them), after the timed region"}
+        if args.strategy == "scatter" and args.workload == "C2" and args.batch == 8:
+            # all three kernels of a scan together (profiles/r01/f_pmc_bench.txt: 351.9 + 0.8 + 60.2 MB per batch of
+            # 8) at the measured scan rate: the HBM bandwidth the whole path sustains over the timed region
+            per_scan = (351.9e6 + 0.8e6 + 60.2e6) / 8
+            rl["whole_path"] = {"hbm_bytes_per_scan": int(per_scan),
+                                "sustained_GBs": round(K / dt * per_scan / 1e9, 1),
+                                "frac_of_peak": round(K / dt * per_scan / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "PMC traffic of k_sc_tris + k_sc_rest + k_sc_resolve per scan x scans/s of "
+                                        "this rank; 6290 GB/s is what a float4 copy reaches on this chip"}
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
