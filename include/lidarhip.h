@@ -128,8 +128,8 @@ typedef struct lt_rayset lt_rayset; /* opaque: normalised directions of one ray 
  * the seed) and bin them by azimuth x elevation.  A sensor model's rays do not change from scan to
  * scan (create_rays, laserscan.py:1092-1119, depends only on the YAML), so one rayset serves a whole
  * sequence -- it is read-only once created (the state of a render lives in the scene), so ONE rayset can be used by
- * any number of scenes and streams at the same time.  `rays` is not referenced after the call has completed on
- * `stream`; the rayset must not be used on another stream before that either. */
+ * any number of scenes and streams at the same time.  The call returns when the ray set is ready (it synchronises
+ * `stream` once -- a ray set is built once per sensor model); `rays` is not referenced afterwards. */
 int lt_rayset_create_dev(lt_rayset** rayset, const float* rays, int n_rays, int height, unsigned flags,
                          void* stream);
 int lt_rayset_destroy(lt_rayset* rayset);

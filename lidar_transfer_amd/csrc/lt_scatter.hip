@@ -619,7 +619,7 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
 #define LT_SC_MAX_BATCH 8
 struct sc_job {
   const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
-  const rs_params* prm; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set
+  rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
   unsigned long long* cell; int* large; int* large_count; int2* slices;
   unsigned* flags; unsigned long long* counters;
   float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   const int lb = (int)blockIdx.x - J.tris_block0;  // workgroup index inside the scan
   const int tid = threadIdx.x;
   const int first = lb * 256;
-  const rs_params P = *J.prm;
+  const rs_params P = J.P;
   const float ox = J.ox, oy = J.oy, oz = J.oz;
   const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P, J.large,
                                        J.large_count, J.flags);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   const float4* __restrict__ sdirs = J.sdirs;
   unsigned long long* __restrict__ cell = J.cell;
   const float ox = J.ox, oy = J.oy, oz = J.oz;
-  const rs_params P = *J.prm;
+  const rs_params P = J.P;
   const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
   unsigned n_tests = 0, n_cand = 0;
   for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
@@ -816,7 +816,9 @@ struct lt_rayset {
   float4* dirs;
   float2* ang;
   float* partial;
-  rs_params* prm;
+  rs_params* prm;      // bin grid parameters, fitted on the device ...
+  rs_params prm_host;  // ... and copied back once: the kernels get them as arguments instead of through a
+                       // dependent load at the start of every workgroup
   uint32_t* keys[2];
   uint32_t* vals[2];
   uint32_t* hist;
@@ -917,6 +919,15 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
     free(r);
     return LT_ERR_HIP;
   }
+  // the one synchronisation of a ray set's life (once per sensor model): from here on it is read-only and may be
+  // used on any stream
+  if (hipStreamSynchronize(stream) != hipSuccess ||
+      hipMemcpy(&r->prm_host, r->prm, sizeof(rs_params), hipMemcpyDeviceToHost) != hipSuccess) {
+    lt_set_error("lt_rayset_create_dev: ray set preparation failed: %s", hipGetErrorString(hipGetLastError()));
+    rs_free(r);
+    free(r);
+    return LT_ERR_HIP;
+  }
   *out = r;
   return LT_OK;
 }
@@ -985,7 +996,7 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     LT_CHECK(sc_reserve(s, n, R, stream));
     sc_job& J = B.job[B.n++];
     J.verts = s->verts; J.faces = s->faces; J.colors = s->colors; J.rem = s->rem;
-    J.prm = r->prm; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
+    J.P = r->prm_host; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
     J.cell = s->sc_cell; J.large = s->sc_large; J.large_count = s->sc_large_count; J.slices = s->sc_slices;
     J.flags = s->flags; J.counters = s->counters;
     J.endpoints = it[i].endpoints; J.endcolors = it[i].endcolors; J.range = it[i].range; J.endrem = it[i].endrem;
