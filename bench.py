@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- virtual-LiDAR synthesis throughput on MI355X (one process per GPU).
 
-A *step* is one pass of the hot path over one scan: a NEW triangle mesh (the mesh changes every scan;
-the reference rebuilds its BVH per call, RayTracer.cpp:54) -> closest hit of one ray per (beam, azimuth)
-cell -> range / colour(label) / remission / end point / triangle images, with mesh, rays and images
-resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle scene, 64x2048
+A *step* is one pass of the hot path over one batch of input: 8 scans (--batch), each with a NEW triangle
+mesh (the mesh changes every scan; the reference rebuilds its BVH per call, RayTracer.cpp:54) -> closest hit
+of one ray per (beam, azimuth) cell -> range / colour(label) / remission / end point / triangle images, with
+meshes, rays and images resident in HBM; the scatter strategy submits a step as ONE lt_scene_render_batch_dev call.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle scene, 64x2048
 HDL-64E target, fov +3/-25), synthetic.
 
 Two MI355X-native strategies produce bit-identical images (tests/test_trace_gpu.py):
@@ -54,10 +54,10 @@ LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is ~14 us: 4000 of them make a 55 ms timed region (filling and draining the pipeline of 16 scans in
-    # flight costs ~1 ms of it; at 1000 steps that would be 8 % of the region)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=200)
+    # a step = one batch of --batch (8) scans = ~105 us: 500 of them make a 52 ms timed region (filling and draining
+    # the pipeline of 16 scans in flight costs ~1 ms of it; at 125 steps that would be 8 % of the region)
+    ap.add_argument("--steps", type=int, default=500, help="timed steps; a step = one batch of --batch scans")
+    ap.add_argument("--warmup", type=int, default=25, help="untimed steps before the clock")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=12,
@@ -149,13 +149,18 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     H, W = wl["H"], wl["W"]
     R = H * W
-    K, Wm, S = args.steps, args.warmup, max(1, args.streams)
+    S = max(1, args.streams)
     args.batch = min(max(1, args.batch), 8)  # lt_scene_render_batch_dev takes at most 8 scans
     S = (S + args.batch - 1) // args.batch * args.batch  # whole batches of workers
+    # A STEP = one pass of the hot path over one batch of input = `--batch` scans, each with its own new mesh (one
+    # lt_scene_render_batch_dev call for the scatter strategy).  Everything below counts scans: K timed, Wm untimed.
+    SPS = args.batch
+    K, Wm = args.steps * SPS, args.warmup * SPS
     # every timed scan keeps its range + label image (8 B per ray) and rank 0 also holds the peers' (6 B per ray)
     need = K * R * 8 + (K * R * 6 * (world - 1) if rank == 0 else 0)
     if need > 0.7 * torch.cuda.get_device_properties(dev).total_memory:
-        raise SystemExit(f"bench.py: --steps {K} keeps {need / 2**30:.0f} GiB of images on this rank; use fewer steps")
+        raise SystemExit(f"bench.py: --steps {args.steps} ({K} scans) keeps {need / 2**30:.0f} GiB of images on this "
+                         f"rank; use fewer steps")
 
     # ---- synthetic inputs, resident in HBM before the clock starts -----------------------------------
     scenes = []
@@ -456,7 +461,7 @@ def main():
         Ko = max(20, K // 4) if oname == "lbvh" else max(K, 400)  # a scatter step is ~15x shorter than an LBVH step
         odt, okern, _ = run(oname, Ko, max(4, Wm // 4), keep=False)
         other = {"strategy": oname, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
-                 "ms_per_step": round(odt / Ko * 1e3, 4), "steps": Ko, "roofline": roofline(oname, okern)}
+                 "ms_per_scan": round(odt / Ko * 1e3, 4), "scans": Ko, "roofline": roofline(oname, okern)}
 
     iso_ms = isolated_kernel_ms(args.strategy)
     if rank == 0:
@@ -478,12 +483,13 @@ def main():
                                         "this rank; 6290 GB/s is what a float4 copy reaches on this chip"}
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {H}x{W} rays vs {n_faces}-triangle synthetic scene "
-                                   f"(fov {wl['fov_up']}/{wl['fov_down']}), 1 scan (new mesh) per step, "
-                                   f"{len(scenes)} distinct scenes cycled",
+                                   f"(fov {wl['fov_up']}/{wl['fov_down']}); 1 step = one batch of {SPS} scans, each "
+                                   f"with a new mesh; {len(scenes)} distinct scenes cycled",
+                       "scans_per_step": SPS, "ms_per_scan": round(dt / K * 1e3, 5),
                        "strategy": args.strategy,
                        "parallelism": f"scan-parallel x{world}" + (f", range f32 + label {str(label_dtype)[6:]} images gathered to rank 0 over RCCL (in 11 pieces inside the timed region, overlapped with the rendering)" if dist.is_initialized() else ""),
                        "streams_per_gpu": S, "scans_per_call": args.batch if args.strategy == "scatter" else 1},
