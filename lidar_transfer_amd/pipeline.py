@@ -1,0 +1,139 @@
+"""Scan pipeline: the reference's batch loop body (``lidar_deform.py:393-462`` -- per output scan: a mesh, one
+``throw_rays_at_mesh`` call, the unpacked images) kept fed on one MI355X.
+
+The reference renders one scan per loop iteration and waits for it.  Here the scans of a sequence are *submitted*:
+:class:`ScanPipeline` owns a pool of scene handles and HIP streams, groups consecutive scans into batches of up to
+8 and hands each batch to ``lt_scene_render_batch_dev`` (three kernel launches for the whole batch, DESIGN.md
+section 5b), with several batches in flight so that the small clean-up kernels of one batch run under the big
+kernel of the next.  All scans share ONE read-only ray set (one target sensor model).  This is the loop of
+``bench.py`` as a library facility; torch is only used for device memory and streams.
+
+    pipe = ScanPipeline(rays, H)                      # rays: [H*W, 3] f32 CUDA tensor (create_rays)
+    for k, (verts, faces, colors, rem) in enumerate(meshes):     # device tensors, layouts of throw_rays_at_mesh
+        pipe.submit(verts, faces, colors, rem, origin, range_out=ranges[k], label_out=labels[k])
+    pipe.flush()                                      # everything submitted so far is in `ranges` / `labels`
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+from .raytracer import RaySet, Scene
+
+
+class ScanPipeline:
+    """Render scans with a new mesh each through batched calls, ``in_flight`` batches deep.
+
+    A submitted scan's mesh tensors and output tensors must stay alive and untouched until :meth:`flush` (or until
+    ``in_flight`` further batches have been submitted: a pool slot is reused only after the stream it last ran on
+    has passed that batch).  Outputs that are not passed go to per-slot scratch tensors and are overwritten by the
+    scan that takes the slot next.
+    """
+
+    def __init__(self, rays, H, device=None, batch=8, in_flight=2, label_image=True, write_misses=True):
+        import torch
+        self._torch = torch
+        self.device = rays.device if device is None else torch.device(device)
+        if not 1 <= batch <= 8:
+            raise ValueError("batch: 1 .. 8 scans per lt_scene_render_batch_dev call")
+        if in_flight < 1:
+            raise ValueError("in_flight: at least one batch")
+        self.batch, self.in_flight = int(batch), int(in_flight)
+        self.label_image = bool(label_image)
+        self._lib = _lib.load()
+        self.rayset = RaySet(rays, H)  # returns a finished, read-only ray set
+        self.n_rays = self.rayset.n_rays
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        n = self.batch * self.in_flight
+        self._scenes = [Scene(idx) for _ in range(n)]
+        self._streams = [torch.cuda.Stream(self.device) for _ in range(self.in_flight)]
+        self._scratch = [self._scenes[0].alloc_outputs(self.n_rays, label_image=self.label_image) for _ in range(n)]
+        self._flags = (_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | \
+                      (_lib.LT_TRACE_LABEL_IMAGE if self.label_image else 0)
+        self._group = 0     # batch slot the pending scans belong to
+        self._pending = []  # [(origin, outputs dict)] of the batch being collected
+        self._keep = [[] for _ in range(self.in_flight)]  # tensors referenced by the batch in flight per group
+        self.n_submitted = 0
+
+    def submit(self, verts, faces, colors, rem, origin, range_out=None, label_out=None, endpoints_out=None,
+               rem_out=None, tri_out=None):
+        """Queue one scan: its mesh (device tensors in the reference's layouts: verts [V,3] f32, faces [F,3] i32,
+        colors [V,3] i32, rem [V] f32), the ray origin (3 floats, host) and where its images go.  ``label_out`` is
+        the [n_rays] int32 semantic-label image with ``label_image=True`` (``deform``'s unpack, laserscan.py:912),
+        else the [n_rays, 3] colour image."""
+        g, j = self._group, len(self._pending)
+        slot = g * self.batch + j
+        sc = self._scenes[slot]
+        if j == 0:
+            # the slots of this group were last used `in_flight` batches ago, on this group's stream: nothing to
+            # wait for on the device (stream order), but the host must not drop the tensors of that batch earlier
+            self._keep[g] = []
+        sc.set_mesh(verts, faces, colors, rem)
+        o = dict(self._scratch[slot])
+        for key, t in (("range", range_out), ("endcolors", label_out), ("endpoints", endpoints_out),
+                       ("endrem", rem_out), ("tri", tri_out)):
+            if t is not None:
+                if not t.is_cuda or not t.is_contiguous() or t.numel() != o[key].numel() or t.dtype != o[key].dtype:
+                    raise ValueError(f"{key}: contiguous {o[key].dtype} CUDA tensor with {o[key].numel()} elements expected")
+                o[key] = t
+        self._pending.append((tuple(float(x) for x in origin), o))
+        self._keep[g].append((verts, faces, colors, rem, o))
+        self.n_submitted += 1
+        if len(self._pending) == self.batch:
+            self._launch()
+
+    def _launch(self):
+        n = len(self._pending)
+        if n == 0:
+            return
+        g = self._group
+        vp = C.c_void_p
+        scenes = self._scenes[g * self.batch:g * self.batch + n]
+        arr = lambda vals: (vp * n)(*vals)  # noqa: E731
+        org = (C.c_float * (3 * n))(*[x for o, _ in self._pending for x in o])
+        col = lambda key: arr([o[key].data_ptr() for _, o in self._pending])  # noqa: E731
+        with self._torch.cuda.device(self.device):
+            # the meshes were produced on the caller's stream: this batch's stream starts after it
+            ev = self._torch.cuda.Event()
+            ev.record(self._torch.cuda.current_stream(self.device))
+            self._streams[g].wait_event(ev)
+            _lib.check(self._lib.lt_scene_render_batch_dev(n, arr([s._h for s in scenes]),
+                                                           arr([self.rayset._h] * n), org, col("endpoints"),
+                                                           col("endcolors"), col("range"), col("endrem"), col("tri"),
+                                                           self._flags, vp(self._streams[g].cuda_stream)),
+                       "lt_scene_render_batch_dev")
+        self._pending = []
+        self._group = (g + 1) % self.in_flight
+
+    def flush(self):
+        """Submit the partial batch and wait until every submitted scan's images are complete."""
+        self._launch()
+        for st in self._streams:
+            st.synchronize()
+        self._keep = [[] for _ in range(self.in_flight)]
+
+    def status(self):
+        """Raise if a mesh submitted since the last call referenced vertices outside ``[0, n_verts)``."""
+        self.flush()
+        for sc in self._scenes:
+            sc.status()
+
+    def close(self):
+        if getattr(self, "_scenes", None):
+            self.flush()
+            for sc in self._scenes:
+                sc.close()
+            self._scenes = []
+            self.rayset.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

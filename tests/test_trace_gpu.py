@@ -544,6 +544,50 @@ def test_one_rayset_shared_by_scenes_and_streams():
         sc.close()
 
 
+def test_scan_pipeline_equals_single_renders():
+    """lidar_transfer_amd.pipeline.ScanPipeline (the reference's batch loop body, kept fed): 37 scans -- meshes of
+    different sizes, one of them empty, moving origin -- submitted one after the other, rendered in batches of 8 with
+    two batches in flight; every image must be the one a lone Scene.render gives."""
+    import torch
+    from lidar_transfer_amd.pipeline import ScanPipeline
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    H, W = 32, 512
+    rays = torch.from_numpy(create_rays(3.0, -25.0, H, W)).to(dev)
+    base = [synth_scene(60 + i, 20000 + 9000 * i) for i in range(5)]
+    base.append((np.zeros((3, 3), np.float32), np.zeros((0, 3), np.int32), np.zeros((3, 3), np.int32),
+                 np.zeros(3, np.float32)))
+    meshes = [[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in m] for m in base]
+    n = 37
+    origins = [(0.05 * k, -0.03 * k, 0.01 * (k % 5)) for k in range(n)]
+    ranges = torch.full((n, H * W), -7.0, dtype=torch.float32, device=dev)
+    labels = torch.full((n, H * W), -7, dtype=torch.int32, device=dev)
+    tris = torch.full((n, H * W), -7, dtype=torch.int32, device=dev)
+    with ScanPipeline(rays, H, batch=8, in_flight=2) as pipe:
+        for k in range(n):
+            pipe.submit(*meshes[k % len(meshes)], origins[k], range_out=ranges[k], label_out=labels[k], tri_out=tris[k])
+        pipe.flush()
+        assert pipe.n_submitted == n
+        pipe.status()
+        # a second round through the same pool (slots, cells and queues re-armed), other batch geometry
+        r2 = torch.empty((5, H * W), dtype=torch.float32, device=dev)
+        for k in range(5):
+            pipe.submit(*meshes[k], origins[k], range_out=r2[k])
+        pipe.flush()
+    sc = Scene(0)
+    rs = RaySet(rays, H)
+    for k in range(n):
+        sc.set_mesh(*meshes[k % len(meshes)])
+        want = sc.render(rs, origins[k], label_image=True)
+        assert torch.equal(want["range"].view(torch.int32), ranges[k].view(torch.int32)), f"scan {k}: range"
+        assert torch.equal(want["endcolors"], labels[k]), f"scan {k}: label"
+        assert torch.equal(want["tri"], tris[k]), f"scan {k}: tri"
+        if k < 5:
+            assert torch.equal(want["range"].view(torch.int32), r2[k].view(torch.int32))
+    assert int((tris[0] >= 0).sum()) > 1000 and int((tris[5] >= 0).sum()) == 0
+    rs.close(); sc.close()
+
+
 def test_handles_release_their_device_memory():
     """Scene / ray-set handles own device memory (LBVH workspace, z-min cells, queues, bin grid): creating, using and
     destroying them in a loop must leave the free device memory where it was."""
