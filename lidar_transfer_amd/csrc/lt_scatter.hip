@@ -9,10 +9,11 @@
 // those rays only, and merges accepted hits with a 64-bit atomicMin on (t bits << 32 | face).
 // The result is, by construction, the minimum over (t, face index) of all accepted triangles -- the same
 // tree-independent definition the LBVH path implements, hence bit-identical images -- but the work is one
-// coalesced pass over the mesh with no sort, no tree and no dependent pointer chase; it is bound by the VALU
-// work of the angular bounds.
+// coalesced pass over the mesh with no sort, no tree and no dependent pointer chase.  What bounds it (the latency
+// chain of a workgroup at full occupancy, at ~45 % of the HBM roof and ~45 % of the VALU roof) and which
+// restructurings were measured and rejected: DESIGN.md section 5d.
 //
-//   rayset (built once per sensor model, reused across scans):
+//   rayset (built once per sensor model, read-only afterwards: shared by every scene and stream):
 //     k_rs_dirs    normalise (Vector3.h:73-89), azimuth/elevation, elevation range partials
 //     k_rs_fit     fit the azimuth grid (W or W - 1 columns) to the rays
 //     k_rs_keys    bin id per ray  ->  radix sort (k_hist/k_scan/k_scatter of lt_build.hip)
@@ -23,6 +24,7 @@
 //                  the excess of heavy workgroups and big triangles -> queues
 //     k_sc_rest    queued slices of heavy workgroups; up to 8 waves per queued big triangle
 //     k_sc_resolve one thread per ray: unpack (t, face), write-back (RayTracer.cpp:73-90), reset the cell
+//   (the z-min cells and the two queues are the state of a render in flight: they belong to the scene)
 #include "lt_internal.h"
 #include <math.h>
 #include <stdlib.h>
