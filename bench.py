@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=500, help="timed steps; a step = one batch of --batch scans")
     ap.add_argument("--warmup", type=int, default=25, help="untimed steps before the clock")
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--target", default="", help="target sensor YAML (lidar_deform.py --target: name, fov_up, fov_down, "
+                                                  "beams, angle_res_hor, fov_hor); overrides the workload's sensor model")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
     ap.add_argument("--scenes", type=int, default=12,
                     help="distinct scenes cycled through per rank (12 x 26 MB exceeds the 256 MB Infinity Cache, so a "
@@ -122,8 +124,38 @@ sys.stderr.write("LTBASE " + json.dumps({"times": ts, "threads": ob.num_threads(
     return None
 
 
+def launch_command(n_gpus: int, argv, port: int):
+    """The one-process-per-GPU launch of this script on one node (what the driver itself would type)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def relaunch_multi_gpu(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become N ranks (one process per GPU)
+    under torch.distributed.run on this node -- the job the reference's batch loop (lidar_deform.py:385-390,
+    :457-459) is sharded into.  Rank 0 prints the one JSON line on the inherited stdout."""
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node shows {n_dev} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer-to-peer transport needs it here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execve(sys.executable, launch_command(args.gpus, sys.argv[1:], port), env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_multi_gpu(args)  # does not return
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {os.environ['WORLD_SIZE']} ranks; "
+                         f"reporting n_gpus = {os.environ['WORLD_SIZE']}\n")
     # stdout carries exactly one JSON line: RCCL prints a version banner to stdout when its communicator is created
     # (and libraries may print what they like) -- everything else that is written to fd 1 goes to stderr
     sys.stdout.flush()
@@ -147,6 +179,10 @@ def main():
     if world > 1 or "RANK" in os.environ:  # also under `torchrun --nproc-per-node 1` (exercises the gather path)
         dist.init_process_group("nccl", device_id=dev)
     wl = dict(WORKLOADS[args.workload])
+    if args.target:  # the target scanner as the reference reads it (lidar_deform.py:302-315)
+        from lidar_transfer_amd.config import load_sensor
+        sensor = load_sensor(args.target)
+        wl.update(H=sensor.H, W=sensor.W, fov_up=float(sensor.fov_up), fov_down=float(sensor.fov_down))
     H, W = wl["H"], wl["W"]
     R = H * W
     S = max(1, args.streams)

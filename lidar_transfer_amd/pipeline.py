@@ -24,10 +24,12 @@ from .raytracer import RaySet, Scene
 class ScanPipeline:
     """Render scans with a new mesh each through batched calls, ``in_flight`` batches deep.
 
-    A submitted scan's mesh tensors and output tensors must stay alive and untouched until :meth:`flush` (or until
-    ``in_flight`` further batches have been submitted: a pool slot is reused only after the stream it last ran on
-    has passed that batch).  Outputs that are not passed go to per-slot scratch tensors and are overwritten by the
-    scan that takes the slot next.
+    A submitted scan's mesh tensors and output tensors must stay untouched until its batch has COMPLETED on the
+    device: :meth:`flush`, or ``submit`` returning for a scan that reuses the same pool slot (``submit`` waits on
+    the host for the batch that last used the slot -- an event recorded on the batch's stream after its render --
+    before it lets go of that batch's tensors; the pipeline itself keeps them referenced until then, so the caller
+    may drop its own references right after ``submit``).  Outputs that are not passed go to per-slot scratch
+    tensors and are overwritten by the scan that takes the slot next.
     """
 
     def __init__(self, rays, H, device=None, batch=8, in_flight=2, label_image=True, write_misses=True):
@@ -53,6 +55,10 @@ class ScanPipeline:
         self._group = 0     # batch slot the pending scans belong to
         self._pending = []  # [(origin, outputs dict)] of the batch being collected
         self._keep = [[] for _ in range(self.in_flight)]  # tensors referenced by the batch in flight per group
+        # completion of the batch last launched per group: the renders run on side streams, while the tensors were
+        # allocated on the caller's stream -- torch's caching allocator would hand their memory back to the caller
+        # the moment the last reference goes, whether or not the side stream is done with it
+        self._done = [None] * self.in_flight
         self.n_submitted = 0
 
     def submit(self, verts, faces, colors, rem, origin, range_out=None, label_out=None, endpoints_out=None,
@@ -65,8 +71,12 @@ class ScanPipeline:
         slot = g * self.batch + j
         sc = self._scenes[slot]
         if j == 0:
-            # the slots of this group were last used `in_flight` batches ago, on this group's stream: nothing to
-            # wait for on the device (stream order), but the host must not drop the tensors of that batch earlier
+            # the slots of this group were last used `in_flight` batches ago, on this group's stream: device-side
+            # the new batch is ordered behind it (same stream), but its tensors may only be released -- and its
+            # scene handles given a new mesh -- once that batch has really finished
+            if self._done[g] is not None:
+                self._done[g].synchronize()
+                self._done[g] = None
             self._keep[g] = []
         sc.set_mesh(verts, faces, colors, rem)
         o = dict(self._scratch[slot])
@@ -102,6 +112,9 @@ class ScanPipeline:
                                                            col("endcolors"), col("range"), col("endrem"), col("tri"),
                                                            self._flags, vp(self._streams[g].cuda_stream)),
                        "lt_scene_render_batch_dev")
+            done = self._torch.cuda.Event()
+            done.record(self._streams[g])
+            self._done[g] = done
         self._pending = []
         self._group = (g + 1) % self.in_flight
 
@@ -111,6 +124,7 @@ class ScanPipeline:
         for st in self._streams:
             st.synchronize()
         self._keep = [[] for _ in range(self.in_flight)]
+        self._done = [None] * self.in_flight
 
     def status(self):
         """Raise if a mesh submitted since the last call referenced vertices outside ``[0, n_verts)``."""

@@ -1,0 +1,104 @@
+"""Scan-parallel rendering over RCCL: needs >= 2 MI355X on the node (skipped otherwise -- the single-GPU test box).
+
+SURVEY.md section 4 item 4 / section 8e: the same scans rendered by 1 rank and by 2 ranks (block partition of the scan
+list, lidar_deform.py:385-390, :457-459, one gather of the images to rank 0) are byte-identical; and
+`python bench.py --gpus 2` really becomes a 2-rank job."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def _render_fn_factory(dev_index):
+    import torch
+    from lidar_transfer_amd.laserscan import create_rays
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    from lidar_transfer_amd.synth import synth_scene
+    dev = torch.device("cuda", dev_index)
+    H, W = 16, 256
+    rays = torch.from_numpy(create_rays(3.0, -25.0, H, W)).to(dev)
+    rs = RaySet(rays, H)
+    sc = Scene(dev_index)
+    keep = []
+
+    def render(idx):
+        mesh = tuple(torch.from_numpy(x).to(dev) for x in synth_scene(100 + idx, 20000))
+        keep.append(mesh)
+        sc.set_mesh(*mesh)
+        o = sc.render(rs, (0.1 * idx, 0.0, 0.0), label_image=True)
+        torch.cuda.synchronize(dev)
+        return {"range": o["range"].clone(), "label": o["endcolors"].clone(), "tri": o["tri"].clone()}
+    return render
+
+
+def _worker(rank, world, port, indices, q):
+    import torch
+    import torch.distributed as dist
+    from lidar_transfer_amd.dist import render_scans
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    out = render_scans(indices, _render_fn_factory(rank), ("range", "label", "tri"))
+    if rank == 0:
+        q.put({k: v.cpu().numpy() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs on the node")
+def test_two_ranks_gather_equals_one_rank_bytewise():
+    import torch.multiprocessing as mp
+    from lidar_transfer_amd.dist import render_scans
+    indices = list(range(5))
+    single = render_scans(indices, _render_fn_factory(0), ("range", "label", "tri"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, indices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k in ("range", "label", "tri"):
+        a, b = single[k].cpu().numpy(), got[k]
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    assert (got["range"] > 0).any()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs on the node")
+def test_bench_gpus_2_prints_two_ranks():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-other"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "RCCL" in out["config"]["parallelism"]
+    assert np.isfinite(out["value"]) and out["value"] > 0
+
+
+def test_bench_gpus_more_than_present_fails_loudly():
+    n = _n_gpus()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert res.returncode != 0 and f"--gpus {n + 1}" in res.stderr and not res.stdout.strip()

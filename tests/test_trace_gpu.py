@@ -588,6 +588,40 @@ def test_scan_pipeline_equals_single_renders():
     rs.close(); sc.close()
 
 
+def test_scan_pipeline_holds_meshes_until_their_batch_completed():
+    """The caller drops its mesh tensors right after submit() and immediately scribbles over freshly allocated
+    tensors of the same sizes (torch's caching allocator hands freed blocks straight back to the allocating stream):
+    the pipeline must keep every mesh referenced until the side stream has finished the batch that reads it."""
+    import torch
+    from lidar_transfer_amd.pipeline import ScanPipeline
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    H, W = 32, 512
+    rays = torch.from_numpy(create_rays(3.0, -25.0, H, W)).to(dev)
+    base = [synth_scene(160 + i, 150000) for i in range(3)]
+    n = 40
+    ranges = torch.zeros((n, H * W), dtype=torch.float32, device=dev)
+    tris = torch.zeros((n, H * W), dtype=torch.int32, device=dev)
+    with ScanPipeline(rays, H, batch=8, in_flight=2) as pipe:
+        for k in range(n):
+            mesh = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in base[k % 3]]
+            pipe.submit(*mesh, (0.0, 0.0, 0.0), range_out=ranges[k], tri_out=tris[k])
+            sizes = [(t.shape, t.dtype) for t in mesh]
+            del mesh
+            junk = [torch.full(sh, 1e30 if dt == torch.float32 else 0x7fffffff, dtype=dt, device=dev) for sh, dt in sizes]
+            del junk
+        pipe.flush()
+        pipe.status()
+    sc, rs = Scene(0), RaySet(rays, H)
+    for k in range(3):
+        sc.set_mesh(*[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in base[k]])
+        want = sc.render(rs, (0.0, 0.0, 0.0))
+        for kk in range(k, n, 3):
+            assert torch.equal(want["range"].view(torch.int32), ranges[kk].view(torch.int32)), f"scan {kk}"
+            assert torch.equal(want["tri"], tris[kk]), f"scan {kk}"
+    rs.close(); sc.close()
+
+
 def test_handles_release_their_device_memory():
     """Scene / ray-set handles own device memory (LBVH workspace, z-min cells, queues, bin grid): creating, using and
     destroying them in a loop must leave the free device memory where it was."""
