@@ -351,6 +351,9 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   const float z_near = zmin > 0.f ? zmin : (zmax < 0.f ? zmax : 0.f);
   const float dlo2 = fmaxf((pierced ? 0.f : rho_edges2) + z_near * z_near, 0.0025f);
   const float pad = 3e-4f + 2e-4f * __builtin_amdgcn_rsqf(dlo2);
+  // the same positional slop seen in AZIMUTH subtends slop / rho (horizontal distance), not slop / distance: a
+  // triangle high above or below the origin whose edge passes close to the vertical axis needs the wider pad
+  const float pad_az = 3e-4f + 2e-4f * __builtin_amdgcn_rsqf(fmaxf(rho_edges2, 0.0025f));
   // elevation: z / rho over the triangle
   float th_hi, th_lo;
   f_atan_pair(zmax, zmax > 0.f ? rho_min : rho_max, zmin, zmin < 0.f ? rho_min : rho_max, th_hi, th_lo);
@@ -388,8 +391,8 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
     else if (g0 >= g1) { a_lo = mid; a_hi = lo + 2.0f * LT_PI_F; }
     else { a_lo = hi; a_hi = mid + 2.0f * LT_PI_F; }
   }
-  a_lo -= pad;
-  a_hi += pad;
+  a_lo -= pad_az;
+  a_hi += pad_az;
   const float fa0 = ceilf((a_lo + LT_PI_F) * P.az_scale - P.az_off - da);
   const float fa1 = floorf((a_hi + LT_PI_F) * P.az_scale - P.az_off + da);
   const int na = (int)(fa1 - fa0) + 1;

@@ -97,11 +97,21 @@ def compare(source_label, source_color, target_label, source_range, target_range
     dev = _device()
     H, W = np.asarray(source_label).shape
     n = H * W
+    src_l = np.asarray(source_label, np.int32).reshape(-1)
+    tgt_l = np.asarray(target_label, np.int32).reshape(-1)
+    mx = int(max(np.max(src_l), np.max(tgt_l), 0)) + 1
+    lo = int(min(np.min(src_l), np.min(tgt_l), 0))
+    if lo < 0:
+        # The reference renumbers the labels by rank among the values present (np.unique, laserscan.py:1216-1222)
+        # BEFORE they index the confusion matrix, so a negative label is simply the lowest class.  The histogram
+        # kernel counts non-negative codes: negatives travel as codes above the largest label (mx - 1 - v) -- raw 0
+        # stays 0, which is what the background rule tests -- and are put back in value order below.
+        src_l = np.where(src_l < 0, mx - 1 - src_l, src_l).astype(np.int32)
+        tgt_l = np.where(tgt_l < 0, mx - 1 - tgt_l, tgt_l).astype(np.int32)
     NL = 1
-    mx = int(max(np.max(source_label), np.max(target_label), 0)) + 1
-    while NL < mx:
+    while NL < mx - lo:
         NL <<= 1
-    sl, tl = _dev(np.asarray(source_label, np.int32).reshape(-1), dev), _dev(np.asarray(target_label, np.int32).reshape(-1), dev)
+    sl, tl = _dev(src_l, dev), _dev(tgt_l, dev)
     sc = _dev(np.asarray(source_color, np.float32).reshape(-1, 3), dev)
     sr, tr = _dev(np.asarray(source_range, np.float32).reshape(-1), dev), _dev(np.asarray(target_range, np.float32).reshape(-1), dev)
     sm, tm = _dev(np.asarray(source_rem, np.float32).reshape(-1), dev), _dev(np.asarray(target_rem, np.float32).reshape(-1), dev)
@@ -119,7 +129,13 @@ def compare(source_label, source_color, target_label, source_range, target_range
     conf = conf.cpu().numpy()          # conf[target, source] over raw labels
     # class compaction + iouEval on the (tiny) confusion matrix: host bookkeeping, no image work
     present = np.nonzero(conf.sum(0) + conf.sum(1))[0]
+    if lo < 0:  # codes of negative labels back into value order: code c >= mx stands for mx - 1 - c
+        value = np.where(present >= mx, mx - 1 - present, present)
+        present = present[np.argsort(value, kind="stable")]
     k = len(present)
+    if k > nclasses:
+        # np.add.at would raise IndexError in the reference (np_ioueval.py:47)
+        raise IndexError(f"compare: {k} distinct labels present but nclasses = {nclasses}")
     cm = np.zeros((nclasses, nclasses), np.int64)
     cm[:k, :k] = conf[np.ix_(present, present)]
     ignore = np.arange(k, nclasses)

@@ -319,3 +319,15 @@ def test_product_never_imports_the_oracle_and_fails_loudly_without_its_library(m
         C_Trace(np.array([1, 0, 0], np.float32), z3, np.zeros(9, np.float32), np.array([0, 1, 2], np.int32),
                 np.zeros(9, np.int32), np.zeros(3, np.float32), z3.copy(), np.zeros(3, np.int32), z.copy(), z.copy(),
                 1, 1)
+
+
+def test_compare_restatement_vs_reference_python():
+    """oracle/compare.py == the reference's compare() + iouEval on the F7 golden (made by the reference's own Python)."""
+    from oracle.compare import compare
+    g = np.load(os.path.join(GOLD, "f7_post.npz"))
+    r = compare(g["cmp_source_label"], g["cmp_source_color"], g["cmp_target_label"], g["cmp_source_range"],
+                g["cmp_target_range"], g["cmp_source_rem"], g["cmp_target_rem"], nclasses=20)
+    assert np.array_equal(r["range_diff"].view(np.int32), g["cmp_range_diff"].view(np.int32))
+    assert np.array_equal(r["rem_diff"].view(np.int32), g["cmp_rem_diff"].view(np.int32))
+    assert r["m_iou"] == float(g["cmp_m_iou"]) and r["m_acc"] == float(g["cmp_m_acc"])
+    assert np.float32(r["MSE"]) == g["cmp_mse"]

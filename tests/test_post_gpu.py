@@ -100,3 +100,29 @@ def test_pack_scan_fuzz_vs_numpy_filter(seed):
     exp_b = np.concatenate([pts[keep].astype(np.float32), rem[keep][:, None]], axis=1)
     assert b.shape == exp_b.shape and np.array_equal(b.view(np.int32), exp_b.view(np.int32))
     assert np.array_equal(l, lab[keep].astype(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_compare_fuzz_incl_negative_labels_vs_oracle(seed):
+    """Random label images -- every second seed with negative labels, which the reference treats as the lowest
+    classes (labels are renumbered by rank before they index the confusion matrix, laserscan.py:1216-1222) --
+    against the numpy restatement pinned to the reference (oracle/compare.py)."""
+    from lidar_transfer_amd.post import compare
+    from oracle.compare import compare as ocompare
+    rng = np.random.default_rng(100 + seed)
+    H, W = 16, 256
+    vals = np.array([0, 1, 10, 40, 48, 50, 70, 259] + ([-1, -7] if seed % 2 else []), np.int32)
+    sl = rng.choice(vals, (H, W)).astype(np.int32)
+    tl = np.where(rng.random((H, W)) < 0.8, sl, rng.choice(vals, (H, W))).astype(np.int32)
+    sc = rng.random((H, W, 3))
+    sc[rng.random((H, W)) < 0.1] = 0
+    sr, tr = rng.uniform(0, 80, (H, W)).astype(np.float32), rng.uniform(0, 80, (H, W)).astype(np.float32)
+    sm, tm = rng.random((H, W)).astype(np.float32), rng.random((H, W)).astype(np.float32)
+    got = compare(sl, sc, tl, sr, tr, sm, tm, nclasses=20)
+    want = ocompare(sl, sc, tl, sr, tr, sm, tm, nclasses=20)
+    assert np.array_equal(got["source_label"], want["source_label"])
+    assert np.array_equal(got["target_label"], want["target_label"])
+    assert np.array_equal(got["range_diff"].view(np.int32), want["range_diff"].view(np.int32))
+    assert np.array_equal(got["rem_diff"].view(np.int32), want["rem_diff"].view(np.int32))
+    assert abs(got["m_iou"] - want["m_iou"]) < 1e-12 and abs(got["m_acc"] - want["m_acc"]) < 1e-12
+    assert np.allclose(got["iou"], want["iou"], atol=1e-12)

@@ -368,6 +368,44 @@ def test_scatter_on_sensor_grids_vs_adversarial_soup(oracle, H, W, fov_up, fov_d
         assert a["stats"]["n_hits"] == int((ref["tri"] >= 0).sum()) > 0
 
 
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_near_vertical_rays_vs_triangles_grazing_the_axis(oracle, sign):
+    """Triangles high above / far below the sensor whose edges pass the vertical axis at 1 mm .. 10 cm, under a
+    dense cone of near-vertical rays (an arbitrary ray set -- no LiDAR looks there): the azimuth error of the
+    float Moller-Trumbore slop scales with slop / rho, not slop / distance, and the azimuth pad must cover it."""
+    rng = np.random.default_rng(7 if sign > 0 else 8)
+    n = 4000
+    z = sign * rng.uniform(5.0, 60.0, (n, 1))
+    rho = rng.choice([1e-3, 3e-3, 1e-2, 3e-2, 1e-1], size=(n, 1))
+    phi = rng.uniform(-np.pi, np.pi, (n, 1))
+    # an edge tangent to the circle of radius rho around the axis, third vertex further out
+    tx, ty = -np.sin(phi), np.cos(phi)
+    half = rng.uniform(0.05, 2.0, (n, 1))
+    p = np.concatenate([rho * np.cos(phi), rho * np.sin(phi)], 1)
+    a = np.concatenate([p - half * np.concatenate([tx, ty], 1), z], 1)
+    b = np.concatenate([p + half * np.concatenate([tx, ty], 1), z + rng.normal(size=(n, 1)) * 0.2], 1)
+    out = rng.uniform(0.1, 3.0, (n, 1))
+    c3 = np.concatenate([p * (1 + out / rho), z + rng.normal(size=(n, 1)) * 0.2], 1)
+    tri = np.stack([a, b, c3], 1)
+    v = np.ascontiguousarray(tri.reshape(-1, 3).astype(np.float32))
+    f = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    c = rng.integers(0, 256, (3 * n, 3)).astype(np.int32)
+    r = rng.uniform(0, 1, 3 * n).astype(np.float32)
+    H, W = 16, 1024
+    th = rng.uniform(0, 2 * np.pi, H * W)
+    # ray offsets from the axis chosen so that at the triangles' heights they land within ~1e-4 .. 0.2 m of it
+    off = 10.0 ** rng.uniform(-5.5, -2.0, H * W)
+    rays = np.stack([off * np.cos(th), off * np.sin(th), np.full(H * W, sign)], 1).astype(np.float32)
+    for origin in ((0.0, 0.0, 0.0), (1e-3, -2e-3, 0.5)):
+        a_, b_ = _both_strategies(v, f, c, r, rays, origin, H)
+        ref = oracle.oracle_trace(rays, np.asarray(origin, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE,
+                                  norm=oracle.NORM_SSE_TABLE)
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(a_[k], ref[k], f"scatter {k} origin={origin}")
+            _assert_bits(b_[k], ref[k], f"lbvh {k} origin={origin}")
+        assert int((ref["tri"] >= 0).sum()) > 1000
+
+
 @pytest.mark.parametrize("H,W", [(5, 8), (16, 64)])
 def test_non_finite_rays_and_origin_are_misses_on_a_deep_tree(oracle, H, W):
     """Zero-length, NaN and unnormalised rays, and a NaN origin, on the adversarial soup (a deep, overlapping
