@@ -40,8 +40,10 @@ extern "C" {
                                  /* are left untouched for misses, as in RayTracer.cpp:73)            */
 #define LT_TRACE_COUNT 2u        /* accumulate nodes visited / triangles tested into the scene stats  */
 #define LT_TRACE_NORM_EXACT 4u   /* seed the direction normalisation (Vector3.h:73-89) with a correctly */
-                                 /* rounded 1/sqrt instead of the replayed x86 RSQRTSS seed (default);  */
-                                 /* vendor independent, differs from the reference in the last ulp      */
+                                 /* rounded 1/sqrt instead of the replayed x86 RSQRTSS seed (default:   */
+                                 /* the Intel table); vendor independent, last-ulp different            */
+#define LT_TRACE_NORM_AMD 16u    /* replay the RSQRTSS seed of an AMD host (measured on EPYC 9575F, Zen 5) instead */
+                                 /* of the Intel one: the reference as it runs on the MI355X box's own CPU      */
 #define LT_TRACE_LABEL_IMAGE 8u  /* `endcolors` receives [n_rays] ints: colour channel 2 only = the      */
                                  /* semantic label image `deform` unpacks (label_image = ray_colors[:, :, */
                                  /* 2], laserscan.py:912) instead of [n_rays, 3]; device-pointer calls    */

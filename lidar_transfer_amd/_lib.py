@@ -16,6 +16,7 @@ LT_TRACE_WRITE_MISSES = 1
 LT_TRACE_COUNT = 2
 LT_TRACE_NORM_EXACT = 4
 LT_TRACE_LABEL_IMAGE = 8
+LT_TRACE_NORM_AMD = 16
 LT_PROJ_REMOVE = 1
 LT_PROJ_NEW = 2
 LT_TSDF_MERGE = 1

@@ -1,5 +1,6 @@
 // lt_api.hip -- C-ABI entry points of liblidarhip.so (declared in include/lidarhip.h).
 #include "lt_internal.h"
+#include <cpuid.h>
 #include <mutex>
 #include <vector>
 #include <stdarg.h>
@@ -289,6 +290,28 @@ extern "C" int lt_scene_status(lt_scene* s) {
   return LT_OK;
 }
 
+// LIDARHIP_NORMALIZE selects the 1/sqrt seed of the reference's normalize() (Vector3.h:83, _mm_rsqrt_ps -- its bits
+// depend on the CPU vendor the reference runs on) for lt_ctrace:
+//   intel (default)  replay the seed measured on GenuineIntel (the golden vectors were made on such a host)
+//   amd              replay the seed measured on AuthenticAMD (EPYC 9575F, the MI355X box's host)
+//   host             whichever of the two this process's CPU is: "the reference as it would run right here"
+//   exact            correctly rounded 1/sqrt, vendor independent (LT_TRACE_NORM_EXACT)
+unsigned lt_env_norm_flag() {
+  const char* nm = getenv("LIDARHIP_NORMALIZE");
+  if (!nm || !*nm || strcmp(nm, "intel") == 0) return 0u;
+  if (strcmp(nm, "exact") == 0) return LT_TRACE_NORM_EXACT;
+  if (strcmp(nm, "amd") == 0) return LT_TRACE_NORM_AMD;
+  if (strcmp(nm, "host") == 0) {
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    char vendor[13] = {0};
+    if (__get_cpuid(0, &a, &b, &c, &d)) {
+      memcpy(vendor, &b, 4); memcpy(vendor + 4, &d, 4); memcpy(vendor + 8, &c, 4);
+    }
+    return strcmp(vendor, "AuthenticAMD") == 0 ? LT_TRACE_NORM_AMD : 0u;
+  }
+  return 0u;
+}
+
 // ---- one-call drop-in for the reference's ctrace -------------------------------------------------------
 // A process-wide scratch scene (workspace + staging buffers) is kept between calls so that a
 // sequence of scans does not pay hipMalloc every time; calls are serialised like the reference's
@@ -359,10 +382,7 @@ static int ctrace_locked(const float* rays, const float* origin, const float* ve
   }
   lt_stats st;
   memset(&st, 0, sizeof(st));
-  // LIDARHIP_NORMALIZE=exact selects the vendor-independent 1/sqrt seed (LT_TRACE_NORM_EXACT);
-  // default is the replayed RSQRTSS seed of the reference's normalize() (Vector3.h:83).
-  const char* nm = getenv("LIDARHIP_NORMALIZE");
-  const unsigned norm_flag = (nm && strcmp(nm, "exact") == 0) ? LT_TRACE_NORM_EXACT : 0u;
+  const unsigned norm_flag = lt_env_norm_flag();
   // LIDARHIP_STRATEGY=lbvh: build the linear BVH and traverse it; default: single-origin triangle
   // scatter (lt_scatter.hip) -- both produce identical images.
   const char* sg = getenv("LIDARHIP_STRATEGY");

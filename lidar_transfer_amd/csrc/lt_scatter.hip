@@ -29,22 +29,11 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
-#define LT_TABLE_ATTR __device__
-#include "lt_rsqrt_sse_table.h"
+#include "lt_normalize.h"
 
 #define LT_PI_F 3.14159265358979f
 #define LT_BIN_SLACK 4e-3f  // bins; float rounding of a grid coordinate is < 8192 * 2^-22
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
-
-__device__ __forceinline__ float sc_rsqrt_sse(float x) {  // see lt_trace.hip:rsqrt_sse
-  const unsigned b = __float_as_uint(x);
-  const int e = (int)((b >> 23) & 255u);
-  if (e == 0) return INFINITY;
-  if (e == 255) return (b & 0x7fffffu) ? x : 0.0f;
-  const int p = (e - 127) & 1;
-  const int k = (e - 127 - p) / 2;
-  return __uint_as_float(LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((unsigned)k << 23));
-}
 
 // Bin grid of a rayset.  A ray with azimuth phi and elevation th has the continuous grid coordinates
 //   x = (phi + pi) * az_scale - az_off   (nb_az columns, periodic),   y = (th - el_lo) * el_scale   (nb_el rows)
@@ -81,7 +70,7 @@ __global__ __launch_bounds__(256) void k_rs_dirs(const float* __restrict__ rays,
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float rx = rays[3 * (size_t)i], ry = rays[3 * (size_t)i + 1], rz = rays[3 * (size_t)i + 2];
     const float D = (rx * rx + ry * ry) + rz * rz;
-    const float r0 = (flags & LT_TRACE_NORM_EXACT) ? 1.0f / sqrtf(D) : sc_rsqrt_sse(D);
+    const float r0 = lt_rsqrt_seed(D, flags);
     const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
     const float dx = rx * r, dy = ry * r, dz = rz * r;
     dirs[i] = make_float4(dx, dy, dz, 0.f);
@@ -866,7 +855,7 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
   const int n = W * height;  // RayTracer.cpp:56: rays beyond W * height are ignored
   r->n_rays = n;
   r->height = height;
-  r->norm_flags = flags & LT_TRACE_NORM_EXACT;
+  r->norm_flags = flags & (LT_TRACE_NORM_EXACT | LT_TRACE_NORM_AMD);
   r->nb_az = W < 1 ? 1 : (W > 8192 ? 8192 : W);
   r->nb_el = height > 4096 ? 4096 : height;
   const size_t nbins = (size_t)r->nb_az * r->nb_el + 1;  // + the NaN bin

@@ -16,22 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
-#define LT_TABLE_ATTR __device__
-#include "lt_rsqrt_sse_table.h"
-
-// x86 RSQRTSS replayed from the measured 2 x 1024 table (generator + exhaustive proof:
-// oracle/gen_rsqrt_table.c).  The reference seeds its normalize() with _mm_rsqrt_ps
-// (Vector3.h:83); replaying the seed makes the ray directions -- and with them every output
-// bit -- those the reference produces on the CPU family the table was measured on.
-__device__ __forceinline__ float rsqrt_sse(float x) {
-  const unsigned b = __float_as_uint(x);
-  const int e = (int)((b >> 23) & 255u);
-  if (e == 0) return INFINITY;                       // zero / denormal source is treated as zero
-  if (e == 255) return (b & 0x7fffffu) ? x : 0.0f;   // NaN -> NaN, +inf -> 0
-  const int p = (e - 127) & 1;
-  const int k = (e - 127 - p) / 2;
-  return __uint_as_float(LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((unsigned)k << 23));
-}
+#include "lt_normalize.h"  // the reference's RSQRTSS seed, replayed (Intel / AMD table) or exact
 
 #define LT_DONE ((int)0x80000000)
 #define LT_TILE_H 4
@@ -63,7 +48,7 @@ __global__ __launch_bounds__(256) void k_trace(
     const float rx = rays[3 * ray], ry = rays[3 * ray + 1], rz = rays[3 * ray + 2];
     // normalize (Vector3.h:73-89): D = (x^2 + y^2) + z^2, r0 ~ 1/sqrt(D), one Newton-Raphson step
     const float D = (rx * rx + ry * ry) + rz * rz;
-    const float r0 = (flags & LT_TRACE_NORM_EXACT) ? 1.0f / sqrtf(D) : rsqrt_sse(D);
+    const float r0 = lt_rsqrt_seed(D, flags);
     const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
     dx = rx * r; dy = ry * r; dz = rz * r;
   }
@@ -269,7 +254,7 @@ __global__ __launch_bounds__(256) void k_trace4(
   if (active) {
     const float rx = rays[3 * ray], ry = rays[3 * ray + 1], rz = rays[3 * ray + 2];
     const float D = (rx * rx + ry * ry) + rz * rz;  // normalize, Vector3.h:73-89
-    const float r0 = (flags & LT_TRACE_NORM_EXACT) ? 1.0f / sqrtf(D) : rsqrt_sse(D);
+    const float r0 = lt_rsqrt_seed(D, flags);
     const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
     dx = rx * r; dy = ry * r; dz = rz * r;
   }

@@ -77,6 +77,19 @@ def C_Trace(rays, origin, verts, faces, colors, rem, ray_endpoints, ray_colors, 
         stats.update(st.asdict())
 
 
+def _norm_flag(mode):
+    """``exact_normalize`` argument -> trace flag: False / "intel" (default: the replayed RSQRTSS seed of an Intel
+    host, where the golden vectors were made), True / "exact" (correctly rounded), "amd" (the seed of an AMD host,
+    measured on the MI355X box's EPYC)."""
+    if mode in (False, None, "intel"):
+        return 0
+    if mode in (True, "exact"):
+        return _lib.LT_TRACE_NORM_EXACT
+    if mode == "amd":
+        return _lib.LT_TRACE_NORM_AMD
+    raise ValueError("exact_normalize: False | True | 'intel' | 'exact' | 'amd'")
+
+
 class Scene:
     """Device-resident mesh + BVH (``lt_scene`` in include/lidarhip.h).
 
@@ -155,7 +168,7 @@ class Scene:
             out = self.alloc_outputs(n_rays, label_image=label_image)
         org = (C.c_float * 3)(*[float(v) for v in origin])
         flags = ((_lib.LT_TRACE_WRITE_MISSES if write_misses else 0) | (_lib.LT_TRACE_COUNT if count else 0)
-                 | (_lib.LT_TRACE_NORM_EXACT if exact_normalize else 0)
+                 | _norm_flag(exact_normalize)
                  | (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0))
         st = _lib.Stats()
 
@@ -261,7 +274,7 @@ class RaySet:
         h = C.c_void_p()
         with torch.cuda.device(rays.device):
             _lib.check(self._lib.lt_rayset_create_dev(C.byref(h), rays.data_ptr(), rays.numel() // 3, int(H),
-                                                      _lib.LT_TRACE_NORM_EXACT if exact_normalize else 0,
+                                                      _norm_flag(exact_normalize),
                                                       C.c_void_p(st.cuda_stream)), "lt_rayset_create_dev")
             st.synchronize()
         self._h = h

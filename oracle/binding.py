@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 MODE_REF_BVH, MODE_BRUTE, MODE_LBVH = 0, 1, 2
-NORM_SSE, NORM_EXACT, NORM_SSE_TABLE = 0, 1, 2
+NORM_SSE, NORM_EXACT, NORM_SSE_TABLE, NORM_AMD_TABLE = 0, 1, 2, 3
 
 
 class Stats(C.Structure):

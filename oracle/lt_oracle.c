@@ -41,6 +41,9 @@
  *                      equals LTO_NORM_SSE on Intel hosts, and is what the HIP
  *                      library computes by default, so that its images equal the
  *                      reference's as run on the machine the goldens came from.
+ *   LTO_NORM_AMD_TABLE the same for an AMD host (2x4096 table measured on an EPYC 9575F,
+ *                      the MI355X box's CPU; LT_TRACE_NORM_AMD in the HIP library);
+ *                      equals LTO_NORM_SSE on AMD Zen 5 hosts.
  */
 #include <math.h>
 #include <stdint.h>
@@ -59,7 +62,9 @@
 #define LTO_NORM_EXACT 1
 #define LTO_NORM_SSE_TABLE 2 /* RSQRTSS emulated from oracle/rsqrt_sse_table.h (measured on an Intel CPU) */
 
+#define LTO_NORM_AMD_TABLE 3 /* ... from oracle/rsqrt_amd_table.h (measured on the GPU box's AMD EPYC host) */
 #include "rsqrt_sse_table.h"
+#include "rsqrt_amd_table.h"
 
 typedef struct {
   double t_setup_ms, t_build_ms, t_trace_ms;
@@ -93,8 +98,8 @@ static inline v3 v3cross(v3 a, v3 b) {
   return r;
 }
 
-/* RSQRTSS replayed from the measured table; D is a sum of squares (never negative) */
-static inline float lto_rsqrt_sse_table(float x) {
+/* RSQRTSS replayed from a measured table of 2 x 2^bits entries; D is a sum of squares (never negative) */
+static inline float lto_rsqrt_table(const unsigned int* table, int bits, float x) {
   uint32_t b;
   memcpy(&b, &x, 4);
   const int e = (int)((b >> 23) & 255u);
@@ -102,7 +107,7 @@ static inline float lto_rsqrt_sse_table(float x) {
   if (e == 255) return (b & 0x7fffffu) ? x : 0.0f; /* NaN -> NaN, inf -> 0 */
   const int p = (e - 127) & 1;
   const int k = (e - 127 - p) / 2;
-  const uint32_t t = LT_RSQRT_SSE_TABLE[p * 1024 + ((b >> 13) & 1023u)] - ((uint32_t)k << 23);
+  const uint32_t t = table[(p << bits) + ((b >> (23 - bits)) & ((1u << bits) - 1u))] - ((uint32_t)k << 23);
   float r;
   memcpy(&r, &t, 4);
   return r;
@@ -115,7 +120,9 @@ static inline v3 lto_normalize(v3 a, int norm_mode) {
   if (norm_mode == LTO_NORM_SSE) {
     r0 = _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(D)));
   } else if (norm_mode == LTO_NORM_SSE_TABLE) {
-    r0 = lto_rsqrt_sse_table(D);
+    r0 = lto_rsqrt_table(LT_RSQRT_SSE_TABLE, LT_RSQRT_SSE_TABLE_BITS, D);
+  } else if (norm_mode == LTO_NORM_AMD_TABLE) {
+    r0 = lto_rsqrt_table(LT_RSQRT_AMD_TABLE, LT_RSQRT_AMD_TABLE_BITS, D);
   } else {
     r0 = 1.0f / sqrtf(D);
   }

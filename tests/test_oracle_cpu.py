@@ -65,6 +65,25 @@ def test_rsqrt_table_replays_this_host_when_intel(oracle):
     assert _host_rsqrt_is_table(oracle)
 
 
+def test_rsqrt_amd_table_replays_this_host_when_amd(oracle):
+    """The 2 x 4096 table measured on the MI355X box's EPYC (oracle/rsqrt_amd_table.h) is what an AMD host's
+    RSQRTSS returns (skipped on other vendors -- it runs with the CPU suite on the GPU box, not here)."""
+    if "authenticamd" not in open("/proc/cpuinfo").read(4096).lower():
+        pytest.skip("table was measured on an AMD CPU")
+    rng = np.random.default_rng(1)
+    r = (rng.normal(size=(1 << 16, 3)) * 10.0 ** rng.uniform(-6, 6, (1 << 16, 1))).astype(np.float32)
+    assert _bits_equal(oracle.normalize_rays(r, oracle.NORM_SSE), oracle.normalize_rays(r, oracle.NORM_AMD_TABLE))
+
+
+def test_the_two_vendor_tables_differ_only_in_the_last_bits(oracle):
+    rng = np.random.default_rng(2)
+    r = (rng.normal(size=(4096, 3)) * rng.uniform(1e-3, 1e3, (4096, 1))).astype(np.float32)
+    a, b = oracle.normalize_rays(r, oracle.NORM_SSE_TABLE), oracle.normalize_rays(r, oracle.NORM_AMD_TABLE)
+    e = oracle.normalize_rays(r, oracle.NORM_EXACT)
+    assert not _bits_equal(a, b)                       # vendor specific ...
+    assert np.abs(a - b).max() < 3e-7 and np.abs(a - e).max() < 3e-7 and np.abs(b - e).max() < 3e-7  # ... in the last ulps
+
+
 # ---- restatement vs golden vectors -------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["f2_three_triangles", "f3_demo_geometry"])
 def test_restatement_vs_golden_small(oracle, name):

@@ -191,6 +191,71 @@ def test_exact_normalisation_mode(oracle):
     sc.close()
 
 
+def test_amd_normalisation_mode(oracle):
+    """LT_TRACE_NORM_AMD: the RSQRTSS seed of an AMD host replayed from the 2 x 4096 table measured on the MI355X
+    box's EPYC -- both strategies against the oracle with that table, and, when this very host is an AMD CPU, against
+    the REAL reference (oracle/_ref/libref_strict.so, compiled from /root/reference) executing the instruction."""
+    import torch
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    dev = torch.device("cuda", 0)
+    v, f, c, r = synth_scene(4, 20000)
+    H, W = 16, 128
+    rays = create_rays(3, -25, H, W) * np.float32(1.7)
+    org = np.zeros(3, np.float32)
+    sc = Scene(0)
+    sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
+    sc.build()
+    trays = torch.from_numpy(rays).to(dev)
+    out_l = sc.trace(trays, (0.0, 0.0, 0.0), H, exact_normalize="amd")
+    rs = RaySet(trays, H, exact_normalize="amd")
+    out_s = sc.render(rs, (0.0, 0.0, 0.0))
+    ref = oracle.oracle_trace(rays, org, v, f, c, r, H, mode=oracle.MODE_BRUTE, norm=oracle.NORM_AMD_TABLE)
+    intel = oracle.oracle_trace(rays, org, v, f, c, r, H, mode=oracle.MODE_BRUTE, norm=oracle.NORM_SSE_TABLE)
+    assert not np.array_equal(ref["range"].view(np.int32), intel["range"].view(np.int32))  # the modes do differ
+    for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+        _assert_bits(out_l[k].cpu().numpy(), ref[k], "lbvh " + k)
+        _assert_bits(out_s[k].cpu().numpy(), ref[k], "scatter " + k)
+    if "authenticamd" in open("/proc/cpuinfo").read(4096).lower() and oracle.ref_available("strict"):
+        real = oracle.ref_trace(rays, org, v, f, c, r, H, kind="strict")
+        for k in ("endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(out_s[k].cpu().numpy(), real[k].reshape(out_s[k].shape), "scatter vs real reference on this AMD host: " + k)
+    rs.close(); sc.close()
+
+
+def test_bare_lt_ctrace_symbol_on_golden_three_triangles():
+    """The 14-parameter drop-in symbol itself (RayTracer.cpp:116-124 signature), called through ctypes on golden F2
+    (made by the real reference): outputs bit-identical, misses untouched."""
+    import ctypes as C
+    from lidar_transfer_amd import _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f2_three_triangles.npz"))
+    lib = _lib.load()
+    rays = np.ascontiguousarray(g["rays"], np.float32).reshape(-1)
+    org = np.ascontiguousarray(g["origin"], np.float32).reshape(-1)
+    v = np.ascontiguousarray(g["verts"], np.float32).reshape(-1)
+    f = np.ascontiguousarray(g["faces"], np.int32).reshape(-1)
+    c = np.ascontiguousarray(g["colors"], np.int32).reshape(-1)
+    r = np.ascontiguousarray(g["rem"], np.float32).reshape(-1)
+    H = int(g["H"])
+    n = rays.size // 3
+    # a sentinel instead of zeros: the reference leaves rays that hit nothing untouched (RayTracer.cpp:73)
+    ep = np.full(3 * n, -5.0, np.float32); ec = np.full(3 * n, -5, np.int32)
+    rg = np.full(n, -5.0, np.float32); rm = np.full(n, -5.0, np.float32)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    rc = lib.lt_ctrace(rays.ctypes.data_as(fp), org.ctypes.data_as(fp), v.ctypes.data_as(fp), f.ctypes.data_as(ip),
+                       c.ctypes.data_as(ip), r.ctypes.data_as(fp), n, v.size // 3, f.size // 3, H,
+                       ep.ctypes.data_as(fp), ec.ctypes.data_as(ip), rg.ctypes.data_as(fp), rm.ctypes.data_as(fp))
+    assert rc == 0, lib.lt_last_error()
+    want = g["range"].reshape(-1)
+    hit = want > 0
+    assert hit.any() and (~hit).any()
+    _assert_bits(rg[hit], want[hit], "range")
+    _assert_bits(rm[hit], g["endrem"].reshape(-1)[hit], "endrem")
+    _assert_bits(ec.reshape(-1, 3)[hit], g["endcolors"].reshape(-1, 3)[hit], "endcolors")
+    _assert_bits(ep.reshape(-1, 3)[hit], g["endpoints"].reshape(-1, 3)[hit], "endpoints")
+    assert (rg[~hit] == -5.0).all() and (rm[~hit] == -5.0).all() and (ec.reshape(-1, 3)[~hit] == -5).all() \
+        and (ep.reshape(-1, 3)[~hit] == -5.0).all()
+
+
 # ---- golden vectors generated from the REAL reference (tests/golden/make_golden.py) -----------------
 import glob
 import os
