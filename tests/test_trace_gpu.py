@@ -200,7 +200,9 @@ def test_amd_normalisation_mode(oracle):
     dev = torch.device("cuda", 0)
     v, f, c, r = synth_scene(4, 20000)
     H, W = 16, 128
-    rays = create_rays(3, -25, H, W) * np.float32(1.7)
+    # un-normalised rays of many lengths: every length picks its own table entry
+    rays = np.ascontiguousarray(create_rays(3, -25, H, W) *
+                                np.random.default_rng(3).uniform(0.5, 4.0, (H * W, 1)).astype(np.float32))
     org = np.zeros(3, np.float32)
     sc = Scene(0)
     sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in (v, f, c, r)])
