@@ -167,3 +167,30 @@ def tsdf_integrate(vols, dims, origin, voxel_size, fov_up, fov_down, color_im, d
     lib.lto_tsdf_integrate(*[v.ctypes.data_as(fp) for v in vols], int(dims[0]), int(dims[1]), int(dims[2]),
                            org.ctypes.data_as(fp), float(voxel_size), int(H), int(W), float(voxel_size * 5), float(obs_weight), float(fov_up), float(fov_down),
                            *[x.ctypes.data_as(fp) for x in ims], int(bool(merge)))
+
+
+def marching_cubes(tsdf, color_vol, rem_vol, voxel_size, origin):
+    """``get_mesh`` restatement (oracle/lt_mc_oracle.c; fusion_lidar.py:403-424): returns
+    ``(verts [V,3] f32 world, faces [F,3] i32, colors [V,3] i32 (r, g, b after the uint8 wrap), rem [V] f32)``."""
+    lib = _lib()
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.lto_marching_cubes.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int,
+                                       C.c_int, ip, ip]
+    lib.lto_marching_cubes.restype = C.c_int
+    vols = [np.ascontiguousarray(v, dtype=np.float32) for v in (tsdf, color_vol, rem_vol)]
+    nx, ny, nz = vols[0].shape
+    org = np.ascontiguousarray(origin, dtype=np.float32)
+    nv, nf = C.c_int(0), C.c_int(0)
+    args = [v.ctypes.data_as(fp) for v in vols] + [nx, ny, nz, float(voxel_size), org.ctypes.data_as(fp)]
+    rc = lib.lto_marching_cubes(*args, None, None, None, None, 0, 0, C.byref(nv), C.byref(nf))
+    if rc != 0:
+        raise RuntimeError(f"lto_marching_cubes (count) failed rc={rc}")
+    verts = np.zeros((max(nv.value, 1), 3), np.float32)
+    faces = np.zeros((max(nf.value, 1), 3), np.int32)
+    colors = np.zeros((max(nv.value, 1), 3), np.int32)
+    rem = np.zeros(max(nv.value, 1), np.float32)
+    rc = lib.lto_marching_cubes(*args, verts.ctypes.data_as(fp), faces.ctypes.data_as(ip), colors.ctypes.data_as(ip),
+                                rem.ctypes.data_as(fp), verts.shape[0], faces.shape[0], C.byref(nv), C.byref(nf))
+    if rc != 0:
+        raise RuntimeError(f"lto_marching_cubes failed rc={rc}")
+    return verts[:nv.value], faces[:nf.value], colors[:nv.value], rem[:nv.value]
