@@ -242,6 +242,38 @@ int lt_tsdf_volumes(lt_tsdf* vol, int* dims, float* origin, float** tsdf, float*
                     float** rem);
 int lt_tsdf_destroy(lt_tsdf* vol);
 
+/* ---- between fusion and render: marching cubes on the device, the mesh is born in HBM -------------------------- */
+
+typedef struct lt_mesh lt_mesh; /* opaque: an indexed triangle mesh in device memory + the extraction workspace */
+
+int lt_mesh_create(lt_mesh** mesh, int device);
+int lt_mesh_destroy(lt_mesh* mesh);
+
+/* Extract the level-0 surface of the volume's current state into `mesh`.  Replaces TSDFVolume.get_mesh
+ * (auxiliary/fusion_lidar.py:403-424): the three device-to-host volume copies of get_volume (:395-400),
+ * skimage.measure.marching_cubes_lewiner on the CPU (:407), the vertex attribute look-ups (:409-423: nearest-voxel
+ * colour / remission, voxel -> world coordinates, colour unfolding incl. the uint8 wrap of labels 256..259) and
+ * the later upload of the mesh for the ray cast (:433-451).  The mesh is indexed like scikit-image's (one vertex
+ * per sign-changing lattice edge, shared by the cells around it; vertex positions by its centre-of-mass rule);
+ * triangulation and element order are this library's (generated watertight case table; owner voxel / cell order) --
+ * scikit-image is not part of the reference and cannot be run here: parity unpinned, see DESIGN.md section 7c.
+ * The call synchronises `stream` once (the sizes of the mesh are needed on the host).  ms: NULL, or two floats that
+ * receive the duration of the sign pass (the one stream over the float field) and of everything else. */
+int lt_tsdf_extract_mesh_dev(lt_tsdf* vol, lt_mesh* mesh, void* stream, float* ms);
+
+/* The same on caller-owned DEVICE fields [nx][ny][nz] f32 (z fastest); origin: HOST pointer to 3 floats. */
+int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny, int nz,
+                          float voxel_size, const float* origin, lt_mesh* mesh, void* stream, float* ms);
+
+/* Sizes and DEVICE pointers of the last extraction: verts [V,3] f32 (world), faces [F,3] i32, colors [V,3] i32
+ * (r, g, b; the label in channel 2, as get_mesh + throw_rays_at_mesh hand it to ctrace), rem [V] f32.  The
+ * pointers stay valid until the next extraction into this mesh or lt_mesh_destroy.  Any argument may be NULL. */
+int lt_mesh_get(lt_mesh* mesh, int* n_verts, int* n_faces, float** verts, int** faces, int** colors, float** rem);
+
+/* lt_scene_set_mesh_dev with the arrays of `mesh` (borrowed until the next extraction): the render reads the
+ * mesh where marching cubes wrote it -- no PCIe traffic between fusion and range image. */
+int lt_scene_set_mesh(lt_scene* scene, lt_mesh* mesh);
+
 /* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
 
 /* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new

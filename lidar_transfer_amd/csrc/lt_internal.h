@@ -88,6 +88,17 @@ struct lt_scene {
   lt_stats stats;
 };
 
+// TSDF volume (lt_tsdf.hip): four float32 fields [dim_x][dim_y][dim_z], z fastest (numpy C order)
+struct lt_tsdf {
+  int device;
+  int dim[3];
+  float origin[3];
+  float voxel_size, trunc_margin;
+  double fov_up_deg, fov_down_deg;
+  size_t n;
+  float *tsdf, *weight, *color, *rem;
+};
+
 #define LT_BOUNDS_BLOCKS 256
 #define LT_DBG_WAVES 16384   // wave start/end clocks kept by a LT_TRACE_COUNT launch (debug)
 #define LT_FLAG_BAD_INDEX 1u

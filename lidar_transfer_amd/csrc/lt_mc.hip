@@ -1,0 +1,548 @@
+// lt_mc.hip -- marching cubes on the device: the mesh of a TSDF volume is born in HBM.
+//
+// Replaces `TSDFVolume.get_mesh` of the reference (auxiliary/fusion_lidar.py:403-424): get_volume's device-to-host
+// copies of three volumes (:395-400), scikit-image's CPU marching cubes (:407), the numpy attribute look-ups
+// (:409-423) -- and, downstream, the upload of the mesh for the ray cast (fusion_lidar.py:433-451).  The mesh is
+// written as the four arrays the ray cast consumes (verts [V,3] f32 world, faces [F,3] i32, colors [V,3] i32,
+// rem [V] f32), indexed (one vertex per sign-changing lattice edge, shared by the cells around it) like
+// scikit-image emits it.
+//
+// The 800 M-voxel default volume (2000 x 2000 x 200, 3.2 GB per field) is 99.8 % empty space, so the float field is
+// read ONCE, as a stream, and everything else works on one SIGN BIT per voxel:
+//
+//   k_mc_signs    tsdf -> sign bit per voxel (wave ballot; rows of nz bits padded to 64-bit words): 3.2 GB in, 128 MB out
+//   k_mc_words    one thread per 64-voxel word: crossing-edge masks ex / ey / ez of the edges its voxels own
+//                 (m ^ neighbour word, shifted for z), active-cell mask (the 8 corner words are not all equal), number
+//                 of vertices (popcounts) and triangles (case table, only on the set bits); per-workgroup totals
+//   k_mc_scan     exclusive scan of the workgroup totals (one workgroup) -> V, F
+//   k_mc_compact  word -> compact index of the active words (the ~2 % that own a vertex or a triangle); per active
+//                 word a record {word, vertex base, triangle base, ex, ey, ez}
+//   k_mc_emit     one WAVE per active word, one lane per voxel: the lane's up to three vertices (position by
+//                 scikit-image's centre-of-mass rule in double, attributes from the nearest voxel) and its cell's
+//                 triangles; the index of a vertex owned by a neighbouring word comes from that word's record
+//                 (8 neighbour records staged in LDS per wave): base + popcount of the edge masks below the bit
+//
+// Vertex order = (owner voxel x, y, z ascending, edge axis); face order = (cell ascending, table order):
+// deterministic, no atomics anywhere.  Case table: lt_mc_table.h (generated, oracle/gen_mc_table.py).
+// PARITY: unpinned against scikit-image (not importable here); bit-identical to the CPU oracle
+// (oracle/lt_mc_oracle.c) -- DESIGN.md section 7c.
+#include "lt_internal.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#define LT_TABLE_ATTR __device__
+#include "lt_mc_table.h"
+
+typedef unsigned long long u64;
+
+struct mc_dims {
+  int nx, ny, nz;
+  int wz;        // 64-bit words per (x, y) row
+  int n_words;   // nx * ny * wz
+};
+
+struct mc_rec {  // one per active word
+  int w, vbase, tbase, pad;
+  u64 ex, ey, ez;
+};
+
+struct lt_mesh {
+  int device;
+  float* verts; int* faces; int* colors; float* rem;
+  int cap_v, cap_f, n_verts, n_faces;
+  u64* bits; unsigned* cnt; int* cmap; size_t cap_words;
+  int* blk; size_t cap_blocks;          // 3 ints per workgroup of 256 words, then 4 totals
+  int* totals_host;                     // pinned: {active words, vertices, triangles, -}
+  mc_rec* rec; size_t cap_rec;
+  float ms_signs, ms_rest;              // last extraction (when timed)
+  hipEvent_t ev[3];
+};
+
+// ---- k_mc_signs ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mc_signs(const float* __restrict__ tsdf, mc_dims D, u64* __restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int n_waves = gridDim.x * 4;
+  // four words per wave and iteration: four independent loads in flight (a pure HBM stream)
+  for (int w0 = blockIdx.x * 4 + (threadIdx.x >> 6); w0 < D.n_words; w0 += 4 * n_waves) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = w0 + k * n_waves;
+      v[k] = 1.0f;
+      if (w < D.n_words) {
+        const int row = w / D.wz, wz = w - row * D.wz;
+        const int z = wz * 64 + lane;
+        if (z < D.nz) v[k] = tsdf[(size_t)row * D.nz + z];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = w0 + k * n_waves;
+      const u64 m = __ballot(v[k] < 0.0f);  // level 0; NaN is "not inside"
+      if (lane == 0 && w < D.n_words) bits[w] = m;
+    }
+  }
+}
+
+// ---- masks of one word ---------------------------------------------------------------------------------------------
+struct mc_masks {
+  u64 m[2][2];  // sign bits of the rows (x + dx, y + dy)
+  u64 s[2][2];  // the same shifted by one z (bit b = voxel z + 1)
+  u64 ex, ey, ez, ac;
+};
+
+__device__ __forceinline__ u64 low_bits(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
+
+__device__ __forceinline__ mc_masks mc_load(const u64* __restrict__ bits, const mc_dims& D, int x, int y, int wz) {
+  mc_masks M;
+  const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny, hz = wz + 1 < D.wz;
+  const int row = x * D.ny + y;
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const bool have = (dx == 0 || hx) && (dy == 0 || hy);
+      const size_t i = (size_t)(row + dx * D.ny + dy) * D.wz + wz;
+      const u64 m = have ? bits[i] : 0ull;
+      const u64 nxt = (have && hz) ? bits[i + 1] : 0ull;
+      M.m[dx][dy] = m;
+      M.s[dx][dy] = (m >> 1) | (nxt << 63);
+    }
+  const u64 vzn = low_bits(D.nz - wz * 64);      // voxels that exist
+  const u64 vz = low_bits(D.nz - 1 - wz * 64);   // voxels with a +z neighbour
+  M.ex = hx ? ((M.m[0][0] ^ M.m[1][0]) & vzn) : 0ull;
+  M.ey = hy ? ((M.m[0][0] ^ M.m[0][1]) & vzn) : 0ull;
+  M.ez = (M.m[0][0] ^ M.s[0][0]) & vz;
+  M.ac = 0ull;
+  if (hx && hy) {
+    const u64 any = M.m[0][0] | M.m[0][1] | M.m[1][0] | M.m[1][1] | M.s[0][0] | M.s[0][1] | M.s[1][0] | M.s[1][1];
+    const u64 all = M.m[0][0] & M.m[0][1] & M.m[1][0] & M.m[1][1] & M.s[0][0] & M.s[0][1] & M.s[1][0] & M.s[1][1];
+    M.ac = (any & ~all) & vz;
+  }
+  return M;
+}
+
+// case index of the cell at bit b: corner i at (dx, dy, dz) = (i & 1, (i >> 1) & 1, (i >> 2) & 1)
+__device__ __forceinline__ int mc_case(const mc_masks& M, int b) {
+  int cs = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 m = (i & 4) ? M.s[i & 1][(i >> 1) & 1] : M.m[i & 1][(i >> 1) & 1];
+    cs |= (int)((m >> b) & 1ull) << i;
+  }
+  return cs;
+}
+
+// block-wide sum / exclusive scan of three small counters packed into one 64-bit word (20 bits each)
+__device__ __forceinline__ u64 pack3(unsigned a, unsigned v, unsigned t) { return (u64)a | ((u64)v << 20) | ((u64)t << 40); }
+
+__device__ __forceinline__ u64 wave_incl_scan(u64 p) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u64 q = __shfl_up(p, o, 64);
+    if (lane >= o) p += q;
+  }
+  return p;
+}
+
+// ---- k_mc_words -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
+                                                  int* __restrict__ blk) {
+  __shared__ u64 wsum[4];
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  unsigned nv = 0, nt = 0;
+  if (w < D.n_words) {
+    const int row = w / D.wz, wz = w - row * D.wz;
+    const int x = row / D.ny, y = row - x * D.ny;
+    const mc_masks M = mc_load(bits, D, x, y, wz);
+    nv = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
+    for (u64 a = M.ac; a; a &= a - 1) nt += LT_MC_NTRIS[mc_case(M, __ffsll((long long)a) - 1)];
+    cnt[w] = nv | (nt << 16);
+  }
+  u64 p = pack3((nv | nt) ? 1u : 0u, nv, nt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    blk[3 * blockIdx.x] = (int)(p & 0xFFFFF);
+    blk[3 * blockIdx.x + 1] = (int)((p >> 20) & 0xFFFFF);
+    blk[3 * blockIdx.x + 2] = (int)((p >> 40) & 0xFFFFF);
+  }
+}
+
+// ---- k_mc_scan: exclusive scan of the per-workgroup totals, in place; totals[0..2] = grand totals --------------------
+__global__ __launch_bounds__(1024) void k_mc_scan(int* __restrict__ blk, int n_blocks, int* __restrict__ totals) {
+  __shared__ long long part[3][1024];
+  const int t = threadIdx.x;
+  const int per = (n_blocks + 1023) / 1024;
+  const int b0 = min(t * per, n_blocks), b1 = min(b0 + per, n_blocks);
+  long long s[3] = {0, 0, 0};
+  for (int b = b0; b < b1; ++b)
+    for (int k = 0; k < 3; ++k) s[k] += blk[3 * b + k];
+  for (int k = 0; k < 3; ++k) part[k][t] = s[k];
+  __syncthreads();
+  // Hillis-Steele over the 1024 partial sums
+  for (int o = 1; o < 1024; o <<= 1) {
+    long long v[3];
+    for (int k = 0; k < 3; ++k) v[k] = t >= o ? part[k][t - o] : 0;
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) part[k][t] += v[k];
+    __syncthreads();
+  }
+  long long run[3];
+  for (int k = 0; k < 3; ++k) run[k] = part[k][t] - s[k];  // exclusive prefix of this thread's chunk
+  for (int b = b0; b < b1; ++b)
+    for (int k = 0; k < 3; ++k) {
+      const int c = blk[3 * b + k];
+      blk[3 * b + k] = (int)min(run[k], 2147483647ll);
+      run[k] += c;
+    }
+  if (t == 1023)
+    for (int k = 0; k < 3; ++k) totals[k] = (int)min(part[k][1023], 2147483647ll);
+}
+
+// ---- k_mc_compact ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits, mc_dims D,
+                                                    const unsigned* __restrict__ cnt, const int* __restrict__ blk,
+                                                    int* __restrict__ cmap, mc_rec* __restrict__ rec, int cap_rec) {
+  __shared__ u64 wsum[4];
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const unsigned c = w < D.n_words ? cnt[w] : 0u;
+  const unsigned nv = c & 0xFFFFu, nt = c >> 16;
+  const u64 mine = pack3(c ? 1u : 0u, nv, nt);
+  const u64 inc = wave_incl_scan(mine);
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  u64 off = 0;
+  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += wsum[k];
+  const u64 ex = off + inc - mine;
+  if (w >= D.n_words) return;
+  int ci = -1;
+  if (c) {
+    ci = blk[3 * blockIdx.x] + (int)(ex & 0xFFFFF);
+    if (ci < cap_rec) {
+      const int row = w / D.wz, wz = w - row * D.wz;
+      const int x = row / D.ny, y = row - x * D.ny;
+      const mc_masks M = mc_load(bits, D, x, y, wz);
+      mc_rec r;
+      r.w = w;
+      r.vbase = blk[3 * blockIdx.x + 1] + (int)((ex >> 20) & 0xFFFFF);
+      r.tbase = blk[3 * blockIdx.x + 2] + (int)((ex >> 40) & 0xFFFFF);
+      r.pad = 0;
+      r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
+      rec[ci] = r;
+    } else {
+      ci = -1;
+    }
+  }
+  cmap[w] = ci;
+}
+
+// ---- k_mc_emit --------------------------------------------------------------------------------------------------------
+struct mc_nb { u64 ex, ey, ez; int vbase; int have; };
+
+// float32 vertex coordinate along the edge from lattice coordinate c (value v1) to c + 1 (value v2): scikit-image's
+// centre-of-mass rule (Cell._add_face_from_edge_index), evaluated in double, stored as float32
+__device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
+  const double w1 = 1.0 / ((double)FLT_EPSILON + fabs((double)v1));
+  const double w2 = 1.0 / ((double)FLT_EPSILON + fabs((double)v2));
+  return (float)((double)c + w2 / (w1 + w2));
+}
+
+__global__ __launch_bounds__(256) void k_mc_emit(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
+                                                 const float* __restrict__ rem_vol, const u64* __restrict__ bits,
+                                                 mc_dims D, const int* __restrict__ cmap,
+                                                 const mc_rec* __restrict__ rec, int n_active, float voxel_size,
+                                                 float ox, float oy, float oz, float* __restrict__ verts,
+                                                 int* __restrict__ faces, int* __restrict__ colors,
+                                                 float* __restrict__ rem, int cap_v, int cap_f) {
+  __shared__ mc_nb nb[4][8];
+  const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
+  const int ci = blockIdx.x * 4 + wave;
+  const bool live = ci < n_active;
+  mc_rec R;
+  R.w = 0; R.vbase = 0; R.tbase = 0; R.ex = R.ey = R.ez = 0;
+  if (live) R = rec[ci];
+  const int row = R.w / D.wz, wz = R.w - row * D.wz;
+  const int x = row / D.ny, y = row - x * D.ny;
+  // the records of the (up to) 8 words a triangle of this word's cells can reference: slot = dx | dy << 1 | dwz << 2
+  if (b < 8) {
+    mc_nb e;
+    e.ex = e.ey = e.ez = 0; e.vbase = 0; e.have = 0;
+    const int dx = b & 1, dy = (b >> 1) & 1, dw = b >> 2;
+    if (live && x + dx < D.nx && y + dy < D.ny && wz + dw < D.wz) {
+      const int w2 = ((x + dx) * D.ny + (y + dy)) * D.wz + wz + dw;
+      const int c2 = b == 0 ? ci : cmap[w2];
+      if (c2 >= 0) {
+        const mc_rec r2 = rec[c2];
+        e.ex = r2.ex; e.ey = r2.ey; e.ez = r2.ez; e.vbase = r2.vbase; e.have = 1;
+      }
+    }
+    nb[wave][b] = e;
+  }
+  __syncthreads();
+  if (!live) return;
+  const int z = wz * 64 + b;
+  const u64 lm = (1ull << b) - 1ull;
+  // ---- vertices of the edges this lane's voxel owns
+  const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull), fz = (int)((R.ez >> b) & 1ull);
+  if (fx | fy | fz) {
+    const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
+    const size_t i = (size_t)x * sx + (size_t)y * sy + z;
+    const float v0 = tsdf[i];
+    int vid = R.vbase + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int f = a == 0 ? fx : (a == 1 ? fy : fz);
+      if (!f) continue;
+      if (vid < cap_v) {
+        const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : 1))];
+        float p[3] = {(float)x, (float)y, (float)z};
+        p[a] = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
+        // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
+        // (clamped: a NaN field value must not become a wild address; numpy would raise there)
+        const int i0 = min(max((int)rintf(p[0]), 0), D.nx - 1), i1 = min(max((int)rintf(p[1]), 0), D.ny - 1),
+                  i2 = min(max((int)rintf(p[2]), 0), D.nz - 1);
+        const size_t j = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
+        // verts * voxel_size + vol_origin in float32 (:412)
+        verts[3 * (size_t)vid] = p[0] * voxel_size + ox;
+        verts[3 * (size_t)vid + 1] = p[1] * voxel_size + oy;
+        verts[3 * (size_t)vid + 2] = p[2] * voxel_size + oz;
+        // colour unfolding (:419-423) in float32, .astype(np.uint8) = truncation to 8 bits
+        const float rgb = color_vol[j];
+        const float cb = floorf(rgb / (float)(256 * 256));
+        const float cg = floorf((rgb - cb * 256.0f * 256.0f) / 256.0f);
+        const float cr = rgb - cb * 256.0f * 256.0f - cg * 256.0f;
+        colors[3 * (size_t)vid] = (int)floorf(cr) & 255;
+        colors[3 * (size_t)vid + 1] = (int)floorf(cg) & 255;
+        colors[3 * (size_t)vid + 2] = (int)floorf(cb) & 255;
+        rem[vid] = rem_vol[j];
+      }
+      ++vid;
+    }
+  }
+  // ---- triangles of this lane's cell (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz: nb[][3] / [4] are there)
+  int cs = 0, nt = 0;
+  {
+    const mc_masks M = mc_load(bits, D, x, y, wz);
+    if ((M.ac >> b) & 1ull) {
+      cs = mc_case(M, b);
+      nt = LT_MC_NTRIS[cs];
+    }
+  }
+  int inc = nt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int q = __shfl_up(inc, o, 64);
+    if (b >= o) inc += q;
+  }
+  int tid = R.tbase + inc - nt;
+  for (int t = LT_MC_FIRST[cs], te = t + 3 * nt; t < te; t += 3, ++tid) {
+    if (tid >= cap_f) break;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int code = LT_MC_TRIS[t + k], c0 = code & 7, a = code >> 3;
+      int b2 = b + ((c0 >> 2) & 1), slot = c0 & 3;
+      if (b2 == 64) { b2 = 0; slot |= 4; }
+      const mc_nb& e = nb[wave][slot];
+      const u64 l2 = (1ull << b2) - 1ull;
+      int id = e.vbase + __popcll(e.ex & l2) + __popcll(e.ey & l2) + __popcll(e.ez & l2);
+      if (a > 0) id += (int)((e.ex >> b2) & 1ull);
+      if (a > 1) id += (int)((e.ey >> b2) & 1ull);
+      faces[3 * (size_t)tid + k] = id;
+    }
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+extern "C" int lt_mesh_create(lt_mesh** out, int device) {
+  if (!out) {
+    lt_set_error("lt_mesh_create: NULL out pointer");
+    return LT_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  if (device < 0) LT_HIP(hipGetDevice(&device));
+  LT_HIP(hipSetDevice(device));
+  lt_mesh* m = (lt_mesh*)calloc(1, sizeof(lt_mesh));
+  if (!m) return LT_ERR_NO_MEMORY;
+  m->device = device;
+  if (hipHostMalloc((void**)&m->totals_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    lt_set_error("lt_mesh_create: hipHostMalloc failed");
+    free(m);
+    return LT_ERR_NO_MEMORY;
+  }
+  for (int k = 0; k < 3; ++k) (void)hipEventCreate(&m->ev[k]);
+  *out = m;
+  return LT_OK;
+}
+
+extern "C" int lt_mesh_destroy(lt_mesh* m) {
+  if (!m) return LT_OK;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+  if (m->totals_host) (void)hipHostFree(m->totals_host);
+  for (int k = 0; k < 3; ++k)
+    if (m->ev[k]) (void)hipEventDestroy(m->ev[k]);
+  free(m);
+  return LT_OK;
+}
+
+extern "C" int lt_mesh_get(lt_mesh* m, int* n_verts, int* n_faces, float** verts, int** faces, int** colors,
+                           float** rem) {
+  if (!m) {
+    lt_set_error("lt_mesh_get: NULL mesh");
+    return LT_ERR_INVALID_ARG;
+  }
+  if (n_verts) *n_verts = m->n_verts;
+  if (n_faces) *n_faces = m->n_faces;
+  if (verts) *verts = m->verts;
+  if (faces) *faces = m->faces;
+  if (colors) *colors = m->colors;
+  if (rem) *rem = m->rem;
+  return LT_OK;
+}
+
+template <class T>
+static int mc_grow(T** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return LT_OK;
+  if (*p) {
+    LT_HIP(hipDeviceSynchronize());
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  const size_t n = need + need / 4 + 1024;
+  LT_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  *cap = n;
+  return LT_OK;
+}
+
+extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
+                                     int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
+                                     float* ms) {
+  if (!tsdf || !color_vol || !rem_vol || !origin || !m || nx <= 0 || ny <= 0 || nz <= 0) {
+    lt_set_error("lt_marching_cubes_dev: invalid argument");
+    return LT_ERR_INVALID_ARG;
+  }
+  if ((double)nx * ny * nz >= 2147483647.0) {
+    lt_set_error("lt_marching_cubes_dev: more than 2^31 - 1 voxels");
+    return LT_ERR_TOO_LARGE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  LT_HIP(hipSetDevice(m->device));
+  mc_dims D;
+  D.nx = nx; D.ny = ny; D.nz = nz;
+  D.wz = (nz + 63) / 64;
+  const size_t n_words = (size_t)nx * ny * D.wz;
+  if (n_words >= 2147483647ull) {
+    lt_set_error("lt_marching_cubes_dev: volume too large");
+    return LT_ERR_TOO_LARGE;
+  }
+  D.n_words = (int)n_words;
+  const int n_blocks = (D.n_words + 255) / 256;
+  if (n_words > m->cap_words || !m->bits) {
+    if (m->bits) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(m->bits); (void)hipFree(m->cnt); (void)hipFree(m->cmap);
+      m->bits = nullptr; m->cnt = nullptr; m->cmap = nullptr;
+      m->cap_words = 0;
+    }
+    LT_HIP(hipMalloc((void**)&m->bits, (n_words + 1) * sizeof(u64)));
+    LT_HIP(hipMalloc((void**)&m->cnt, n_words * sizeof(unsigned)));
+    LT_HIP(hipMalloc((void**)&m->cmap, n_words * sizeof(int)));
+    m->cap_words = n_words;
+  }
+  LT_CHECK(mc_grow(&m->blk, &m->cap_blocks, (size_t)3 * n_blocks + 4));
+  int* totals_dev = m->blk + 3 * (size_t)n_blocks;
+  if (ms) LT_HIP(hipEventRecord(m->ev[0], stream));
+  hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)65536, (n_words + 3) / 4)), dim3(256), 0, stream, tsdf, D,
+                     m->bits);
+  if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
+  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk);
+  hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, stream, m->blk, n_blocks, totals_dev);
+  LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  LT_HIP(hipStreamSynchronize(stream));  // the one synchronisation: the sizes of the mesh
+  const int n_active = m->totals_host[0], nv = m->totals_host[1], nf = m->totals_host[2];
+  if (nv == 2147483647 || nf == 2147483647) {
+    lt_set_error("lt_marching_cubes_dev: mesh exceeds 2^31 - 1 vertices / faces");
+    return LT_ERR_TOO_LARGE;
+  }
+  if (nf >= LT_MAX_FACES) {
+    lt_set_error("lt_marching_cubes_dev: %d faces exceed LT_MAX_FACES", nf);
+    return LT_ERR_TOO_LARGE;
+  }
+  LT_CHECK(mc_grow(&m->rec, &m->cap_rec, (size_t)n_active));
+  if (nv > m->cap_v || !m->verts) {
+    if (m->verts) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(m->verts); (void)hipFree(m->colors); (void)hipFree(m->rem);
+      m->verts = nullptr; m->colors = nullptr; m->rem = nullptr;
+    }
+    const size_t cap = (size_t)nv + nv / 4 + 1024;
+    LT_HIP(hipMalloc((void**)&m->verts, cap * 12));
+    LT_HIP(hipMalloc((void**)&m->colors, cap * 12));
+    LT_HIP(hipMalloc((void**)&m->rem, cap * 4));
+    m->cap_v = (int)min(cap, (size_t)2147483647);
+  }
+  if (nf > m->cap_f || !m->faces) {
+    if (m->faces) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(m->faces);
+      m->faces = nullptr;
+    }
+    const size_t cap = (size_t)nf + nf / 4 + 1024;
+    LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
+    m->cap_f = (int)min(cap, (size_t)2147483647);
+  }
+  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk, m->cmap, m->rec,
+                     (int)min(m->cap_rec, (size_t)2147483647));
+  if (n_active > 0)
+    hipLaunchKernelGGL(k_mc_emit, dim3((n_active + 3) / 4), dim3(256), 0, stream, tsdf, color_vol, rem_vol, m->bits, D,
+                       m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], m->verts, m->faces,
+                       m->colors, m->rem, m->cap_v, m->cap_f);
+  LT_HIP(hipGetLastError());
+  m->n_verts = nv;
+  m->n_faces = nf;
+  if (ms) {
+    LT_HIP(hipEventRecord(m->ev[2], stream));
+    LT_HIP(hipStreamSynchronize(stream));
+    LT_HIP(hipEventElapsedTime(&m->ms_signs, m->ev[0], m->ev[1]));
+    LT_HIP(hipEventElapsedTime(&m->ms_rest, m->ev[1], m->ev[2]));
+    ms[0] = m->ms_signs;
+    ms[1] = m->ms_rest;
+  }
+  return LT_OK;
+}
+
+// Marching cubes over a TSDF volume's current state (level 0): replaces TSDFVolume.get_mesh (fusion_lidar.py:403-424).
+extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, float* ms) {
+  if (!t || !m) {
+    lt_set_error("lt_tsdf_extract_mesh_dev: NULL volume / mesh");
+    return LT_ERR_INVALID_ARG;
+  }
+  if (t->device != m->device) {
+    lt_set_error("lt_tsdf_extract_mesh_dev: volume on device %d, mesh on device %d", t->device, m->device);
+    return LT_ERR_INVALID_ARG;
+  }
+  return lt_marching_cubes_dev(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m,
+                               stream, ms);
+}
+
+extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {
+  if (!s || !m) {
+    lt_set_error("lt_scene_set_mesh: NULL scene / mesh");
+    return LT_ERR_INVALID_ARG;
+  }
+  if (s->device != m->device) {
+    lt_set_error("lt_scene_set_mesh: scene on device %d, mesh on device %d", s->device, m->device);
+    return LT_ERR_INVALID_ARG;
+  }
+  return lt_scene_set_mesh_dev(s, m->verts, m->faces, m->colors, m->rem, m->n_verts, m->n_faces);
+}

@@ -18,16 +18,6 @@
 
 #define LT_PI_D 3.14159265358979323846
 
-struct lt_tsdf {
-  int device;
-  int dim[3];
-  float origin[3];
-  float voxel_size, trunc_margin;
-  double fov_up_deg, fov_down_deg;
-  size_t n;
-  float *tsdf, *weight, *color, *rem;
-};
-
 __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, float* __restrict__ weight,
                                                    float* __restrict__ color, float* __restrict__ rem, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

@@ -1,8 +1,8 @@
 """``throw_rays_at_mesh`` -- Python side of the drop-in boundary
 (reference: ``TSDFVolume.throw_rays_at_mesh``, auxiliary/fusion_lidar.py:426-455).
 
-The TSDF fusion and marching cubes that PRODUCE the mesh are consumed unchanged (out of scope,
-SURVEY.md section 8f); this module only replaces what happens to the mesh afterwards.  Either call
+The mesh may come from anywhere -- the reference's own ``TSDFVolume.get_mesh`` (host arrays, uploaded per call) or
+this module's device-resident :class:`TSDFVolume` (fusion, marching cubes and ray cast all in HBM).  Either call
 :func:`throw_rays_at_mesh` with any object that has the reference's ``get_mesh(color_lut)``, or
 :func:`install` it on the reference's class::
 
@@ -79,8 +79,9 @@ class TSDFVolume:
 
     Same constructor and ``integrate`` signature; the four volumes live in HBM (``lt_tsdf``) and every
     ``integrate`` is one launch of the HIP kernel -- no per-launch image round trip, no grid loop.
-    ``merge=True`` (default) is the class-aware branch the reference runs.  Marching cubes (``get_mesh``) is
-    consumed unchanged from the reference / skimage and is out of scope here.
+    ``merge=True`` (default) is the class-aware branch the reference runs.  ``get_mesh`` / ``extract_mesh`` run
+    marching cubes on the device (``lt_mc.hip``): the mesh is born in HBM and
+    ``throw_rays_at_mesh`` renders it there.
     """
 
     def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, device=None, merge=True):
@@ -108,6 +109,11 @@ class TSDFVolume:
         self._h = h
 
     def close(self):
+        for name in ("_rs", "_scene", "_mesh"):
+            obj = getattr(self, name, None)
+            if obj is not None:
+                (obj[2] if name == "_rs" else obj).close()
+                setattr(self, name, None)
         if getattr(self, "_h", None):
             self._lib.lt_tsdf_destroy(self._h)
             self._h = None
@@ -144,6 +150,65 @@ class TSDFVolume:
         t, w, c, r = self.get_volume_tensors()
         return t.cpu().numpy(), c.cpu().numpy(), r.cpu().numpy()
 
+    def extract_mesh(self, mesh=None, timed=False):
+        """Marching cubes on the device over the current volume (``lt_tsdf_extract_mesh_dev``): returns a
+        :class:`DeviceMesh` whose arrays stay in HBM -- ``Scene.set_device_mesh(mesh)`` renders it without any PCIe
+        traffic.  Pass the previous ``mesh`` to reuse its buffers."""
+        C = self._C
+        if mesh is None:
+            mesh = getattr(self, "_mesh", None) or DeviceMesh(self.device.index)
+            self._mesh = mesh
+        ms = (C.c_float * 2)()
+        st = self._torch.cuda.current_stream(self.device)
+        self._libmod.check(self._lib.lt_tsdf_extract_mesh_dev(self._h, mesh._h, C.c_void_p(st.cuda_stream),
+                                                              ms if timed else None), "lt_tsdf_extract_mesh_dev")
+        mesh.last_ms = (ms[0], ms[1]) if timed else None
+        return mesh
+
+    def get_mesh(self, color_lut=None):
+        """``(verts, faces, norms, colors, rem)`` as numpy arrays like fusion_lidar.py:403-424: verts ``[V,3]`` f32 in
+        world coordinates, faces ``[F,3]`` i32, colors ``[V,3]`` uint8 (r, g, b), rem ``[V]`` f32.  ``norms`` is
+        ``None``: scikit-image's vertex normals are returned by the reference but read by nothing on the path
+        (only by the PLY writer that is commented out, fusion_lidar.py:430-431)."""
+        v, f, c, r = self.extract_mesh().tensors()
+        return v.cpu().numpy(), f.cpu().numpy(), None, c.cpu().numpy().astype(np.uint8), r.cpu().numpy()
+
+    def throw_rays_at_mesh_device(self, rayset, origin, out=None, scene=None, label_image=False):
+        """Fusion -> range image without leaving HBM: marching cubes on the device, then the single-origin render of
+        ``rayset`` (a :class:`~lidar_transfer_amd.raytracer.RaySet`).  Returns the dict of device tensors of
+        ``Scene.render`` plus ``mesh`` (the :class:`DeviceMesh`)."""
+        from .raytracer import Scene
+        mesh = self.extract_mesh()
+        if scene is None:
+            scene = getattr(self, "_scene", None) or Scene(self.device.index)
+            self._scene = scene
+        scene.set_device_mesh(mesh)
+        o = dict(scene.render(rayset, origin, out=out, label_image=label_image))
+        o["mesh"] = mesh
+        return o
+
+    def throw_rays_at_mesh(self, rays, origin, H, W, color_lut=None):
+        """Same arguments and 7-tuple as fusion_lidar.py:426-455 -- ``(ray_endpoints [R,3] f32, ray_colors [R,3] i32,
+        verts, colors, faces, range_image [H,W] f32, rem_image [H,W] f32)`` -- computed without the mesh ever
+        visiting the host on its way from the volume to the ray cast; the tuple's mesh members (which ``deform`` only
+        keeps for the visualiser) and the images are downloaded at the end."""
+        from .raytracer import RaySet
+        torch = self._torch
+        rays_t = torch.from_numpy(np.ascontiguousarray(np.asarray(rays, np.float32).reshape(-1, 3))).to(self.device)
+        key = (rays_t.shape[0], int(H))
+        cached = getattr(self, "_rs", None)
+        if cached is None or cached[0] != key or not torch.equal(cached[1], rays_t):
+            if cached is not None:
+                cached[2].close()
+            cached = (key, rays_t, RaySet(rays_t, int(H)))
+            self._rs = cached
+        o = self.throw_rays_at_mesh_device(cached[2], [float(x) for x in np.asarray(origin).reshape(-1)[:3]])
+        torch.cuda.synchronize(self.device)
+        v, f, c, r = o["mesh"].tensors()
+        return (o["endpoints"].cpu().numpy().reshape(-1, 3), o["endcolors"].cpu().numpy().reshape(-1, 3),
+                v.cpu().numpy(), c.cpu().numpy().astype(np.uint8), f.cpu().numpy(),
+                o["range"].cpu().numpy().reshape(-1, W), o["endrem"].cpu().numpy().reshape(-1, W))
+
     def get_volume_tensors(self):
         """Zero-copy ``torch`` views of the four device volumes (tsdf, weight, color, rem)."""
         torch, C = self._torch, self._C
@@ -159,10 +224,87 @@ class TSDFVolume:
         return out
 
 
-def _wrap_device_pointer(torch, ptr, n, device):
+class DeviceMesh:
+    """An indexed triangle mesh in HBM (``lt_mesh`` in include/lidarhip.h): what marching cubes writes and the ray cast
+    reads.  ``verts [V,3] f32`` (world), ``faces [F,3] i32``, ``colors [V,3] i32`` (r, g, b -- label in channel 2),
+    ``rem [V] f32`` are zero-copy ``torch`` views, valid until the next extraction into this object."""
+
+    def __init__(self, device=None):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        self._C, self._torch, self._libmod = C, torch, _lib
+        self._lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        h = C.c_void_p()
+        _lib.check(self._lib.lt_mesh_create(C.byref(h), self.device.index), "lt_mesh_create")
+        self._h = h
+        self.last_ms = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract(self, tsdf, color_vol, rem_vol, voxel_size, origin, timed=False):
+        """Marching cubes (level 0) over caller-owned device fields ``[nx, ny, nz]`` f32 (``lt_marching_cubes_dev``)."""
+        torch, C = self._torch, self._C
+        for t in (tsdf, color_vol, rem_vol):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                    and t.shape == tsdf.shape and t.dim() == 3):
+                raise ValueError("extract: three contiguous float32 CUDA tensors [nx, ny, nz] expected")
+        org = (C.c_float * 3)(*[float(x) for x in origin])
+        ms = (C.c_float * 2)()
+        st = torch.cuda.current_stream(self.device)
+        nx, ny, nz = tsdf.shape
+        self._libmod.check(self._lib.lt_marching_cubes_dev(tsdf.data_ptr(), color_vol.data_ptr(), rem_vol.data_ptr(), nx,
+                                                           ny, nz, float(voxel_size), org, self._h,
+                                                           C.c_void_p(st.cuda_stream), ms if timed else None),
+                           "lt_marching_cubes_dev")
+        self.last_ms = (ms[0], ms[1]) if timed else None
+        return self
+
+    def _get(self):
+        C = self._C
+        nv, nf = C.c_int(0), C.c_int(0)
+        ptrs = [C.c_void_p() for _ in range(4)]
+        self._libmod.check(self._lib.lt_mesh_get(self._h, C.byref(nv), C.byref(nf), *[C.byref(p) for p in ptrs]),
+                           "lt_mesh_get")
+        return nv.value, nf.value, [p.value for p in ptrs]
+
+    @property
+    def n_verts(self):
+        return self._get()[0]
+
+    @property
+    def n_faces(self):
+        return self._get()[1]
+
+    def tensors(self):
+        """``(verts, faces, colors, rem)`` as zero-copy device tensors."""
+        torch = self._torch
+        nv, nf, (pv, pf, pc, pr) = self._get()
+        def wrap(ptr, n, typestr, dt, *shape):
+            if n == 0:
+                return torch.empty(shape, dtype=dt, device=self.device)
+            return _wrap_device_pointer(torch, ptr, n, self.device, typestr).view(*shape)
+
+        return (wrap(pv, 3 * nv, "<f4", torch.float32, nv, 3), wrap(pf, 3 * nf, "<i4", torch.int32, nf, 3),
+                wrap(pc, 3 * nv, "<i4", torch.int32, nv, 3), wrap(pr, nv, "<f4", torch.float32, nv))
+
+
+def _wrap_device_pointer(torch, ptr, n, device, typestr="<f4"):
     """torch tensor over a raw device pointer (no copy, no ownership) via the CUDA array interface."""
     class _Holder:
         pass
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 3}
     return torch.as_tensor(h, device=device)

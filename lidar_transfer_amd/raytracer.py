@@ -142,6 +142,12 @@ class Scene:
                                                    rem.data_ptr(), verts.numel() // 3, faces.numel() // 3),
                    "lt_scene_set_mesh_dev")
 
+    def set_device_mesh(self, mesh):
+        """Attach a :class:`~lidar_transfer_amd.fusion.DeviceMesh` (``lt_scene_set_mesh``): the arrays marching cubes
+        wrote are borrowed until the next extraction into ``mesh``."""
+        self._mesh = mesh
+        _lib.check(self._lib.lt_scene_set_mesh(self._h, mesh._h), "lt_scene_set_mesh")
+
     def _stream(self, stream):
         torch = self._torch
         if stream is None:

@@ -74,6 +74,8 @@ int lto_marching_cubes(const float* tsdf, const float* color_vol, const float* r
             int ind[3];
             for (int k = 0; k < 3; ++k) {
               ind[k] = (int)rintf(p[k]);                        /* np.round: half to even, on the float32 value */
+              if (!(ind[k] >= 0)) ind[k] = 0;                   /* (a NaN field value: numpy would raise) */
+              if (ind[k] > dim[k] - 1) ind[k] = dim[k] - 1;
               verts[3 * (size_t)nv + k] = p[k] * voxel_size + origin[k]; /* float32 multiply, then float32 add */
             }
             const size_t j = ind[0] * sx + ind[1] * sy + ind[2];
