@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- virtual-LiDAR synthesis throughput on MI355X (one process per GPU).
 
-A *step* is one pass of the hot path over one batch of input: 8 scans (--batch), each with a NEW triangle
-mesh (the mesh changes every scan; the reference rebuilds its BVH per call, RayTracer.cpp:54) -> closest hit
+A *step* is one pass of the hot path over one batch of input: 64 scans (--calls-per-step 8 x --batch 8), each with a NEW
+triangle mesh (the mesh changes every scan; the reference rebuilds its BVH per call, RayTracer.cpp:54) -> closest hit
 of one ray per (beam, azimuth) cell -> range / colour(label) / remission / end point / triangle images, with
-meshes, rays and images resident in HBM; the scatter strategy submits a step as ONE lt_scene_render_batch_dev call.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle scene, 64x2048
+meshes, rays and images resident in HBM; the scatter strategy submits 8 scans per lt_scene_render_batch_dev call.  Workload at N=1: BASELINE.json configs[1] ("C2": ~1 M-triangle scene, 64x2048
 HDL-64E target, fov +3/-25), synthetic.
 
 Two MI355X-native strategies produce bit-identical images (tests/test_trace_gpu.py):
@@ -44,9 +44,11 @@ PCIE_PEAK_GBS = 55.0   # PCIe Gen5 x16 per direction after protocol overhead (64
 PROBE_EVERY = int(os.environ.get("LT_BENCH_PROBE_EVERY", "8"))  # HIP-event pair around every n-th dominant launch
 
 # ---- algorithmic bytes per unit ----------------------------------------------------
-# scatter, kernel k_sc_tris: per triangle 3 indices (12 B) + 3 vertices (36 B); per Moller-Trumbore test one
-# 16-B grid entry (normalised direction + ray index); per accepted hit one 8-B atomic
-SC_B_TRI, SC_B_TEST, SC_B_HIT = 48, 16, 8
+# scatter, kernel k_sc_tris: per triangle 3 indices (12 B); per VERTEX of the mesh 12 B once (an indexed mesh shares
+# a vertex between ~6 triangles: the gathers of a block hit the same lines, so a vertex is charged once, not once
+# per incident triangle); per Moller-Trumbore test one 16-B grid entry (normalised direction + ray index); per
+# accepted hit one 8-B atomic
+SC_B_TRI, SC_B_VERT, SC_B_TEST, SC_B_HIT = 12, 12, 16, 8
 # lbvh, kernel k_trace4: one 4-wide node 128 B, one triangle record 48 B; per ray 12 B direction in + 44 B out
 # (range 4, rem 4, xyz 12, colour 12, tri 4) + 40 B hit gather
 LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
@@ -55,10 +57,13 @@ LB_B_NODE, LB_B_TRI, LB_B_RAY = 128, 48, 12 + 44 + 40
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step = one batch of --batch (8) scans = ~105 us: 500 of them make a 52 ms timed region (filling and draining
-    # the pipeline of 16 scans in flight costs ~1 ms of it; at 125 steps that would be 8 % of the region)
-    ap.add_argument("--steps", type=int, default=500, help="timed steps; a step = one batch of --batch scans")
-    ap.add_argument("--warmup", type=int, default=25, help="untimed steps before the clock")
+    # a step = one batch of input = --calls-per-step x --batch = 64 scans, each with a new mesh, ~0.84 ms: filling and
+    # draining the pipeline of 16 scans in flight costs ~1 ms per timed region, so that even a 20-step run (17 ms)
+    # measures the steady state to ~5 %; the default 64 steps = 4096 scans = 54 ms
+    ap.add_argument("--steps", type=int, default=64, help="timed steps; a step = --calls-per-step batches of --batch scans")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps before the clock")
+    ap.add_argument("--calls-per-step", type=int, default=int(os.environ.get("LT_BENCH_CALLS_PER_STEP", "8")),
+                    help="lt_scene_render_batch_dev calls (of --batch scans each) that make up one step")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--target", default="", help="target sensor YAML (lidar_deform.py --target: name, fov_up, fov_down, "
                                                   "beams, angle_res_hor, fov_hor); overrides the workload's sensor model")
@@ -73,6 +78,7 @@ def parse():
                          "--streams / --batch batches are in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive clock (host buffers in and out)")
+    ap.add_argument("--no-chain", action="store_true", help="skip the fusion -> marching cubes -> render sub-record")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other strategy")
     ap.add_argument("--cpu-reps", type=int, default=0, help="reference runs for the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -192,7 +198,7 @@ def main():
     S = (S + args.batch - 1) // args.batch * args.batch  # whole batches of workers
     # A STEP = one pass of the hot path over one batch of input = `--batch` scans, each with its own new mesh (one
     # lt_scene_render_batch_dev call for the scatter strategy).  Everything below counts scans: K timed, Wm untimed.
-    SPS = args.batch
+    SPS = args.batch * max(1, args.calls_per_step)
     K, Wm = args.steps * SPS, args.warmup * SPS
     # every timed scan keeps its range + label image (8 B per ray) and rank 0 also holds the peers' (6 B per ray)
     need = K * R * 8 + (K * R * 6 * (world - 1) if rank == 0 else 0)
@@ -206,6 +212,7 @@ def main():
         v, f, c, r = synth_scene(1000 * rank + i, wl["tris"])
         scenes.append(tuple(torch.from_numpy(x).to(dev) for x in (v, f, c, r)))
     n_faces = int(scenes[0][1].shape[0])
+    n_verts = int(np.mean([int(sc_[0].shape[0]) for sc_ in scenes]))
     # semantic labels travel as int16 when every label of this rank's scenes fits (decided before the clock;
     # SemanticKITTI labels are < 260): 6 instead of 8 bytes per ray on the xGMI links into the root
     lab_lo = min(int(sc_[2][:, 2].min()) for sc_ in scenes)
@@ -443,37 +450,120 @@ def main():
     phase = workers[0].build(stats=True) if (args.strategy == "lbvh" or not args.no_other) else {}
     torch.cuda.synchronize()
 
-    def roofline(strategy, kern_ms):
+    KERNEL_SOURCES = {"scatter": ["lt_scatter.hip", "lt_internal.h", "lt_normalize.h"],
+                      "lbvh": ["lt_trace.hip", "lt_build.hip", "lt_internal.h", "lt_normalize.h"]}
+
+    def kernel_source_hash(strategy):
+        import hashlib
+        h = hashlib.sha256()
+        for name in KERNEL_SOURCES[strategy]:
+            with open(os.path.join(ROOT, "lidar_transfer_amd", "csrc", name), "rb") as fh:
+                h.update(name.encode() + fh.read())
+        return h.hexdigest()[:16]
+
+    def measured_traffic(strategy, spl, kernel=None):
+        """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/rNN/pmc.json
+        (tools/pmc_to_json.py: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section).  An entry counts only for
+        the workload, launch shape AND kernel sources it was collected on -- otherwise null, never a stale constant."""
+        import glob
+        want = kernel_source_hash(strategy)
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc.json")), reverse=True):
+            try:
+                doc = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            for e in doc.get("entries", []):
+                if (e.get("workload") == args.workload and e.get("strategy") == strategy and not args.target
+                        and e.get("scans_per_launch") == spl and e.get("kernel_source_hash") == want
+                        and e.get("kernel") == (kernel or {"scatter": "k_sc_tris", "lbvh": "k_trace4"}[strategy])):
+                    return float(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), e
+        return None, None, None
+
+    def roofline(strategy, serial_ms, insitu_ms):
         spl = args.batch if strategy == "scatter" else 1  # scans per launch of the dominant kernel
         c = np.mean(np.array(cnt[strategy], dtype=np.float64), axis=0)
         if strategy == "scatter":
-            alg = n_faces * SC_B_TRI + c[1] * SC_B_TEST + c[2] * SC_B_HIT
-            extra = {"kernel": "k_sc_tris", "mt_tests_per_ray": round(c[1] / R, 2),
+            alg = n_faces * SC_B_TRI + n_verts * SC_B_VERT + c[1] * SC_B_TEST + c[2] * SC_B_HIT
+            extra = {"kernel": "k_sc_tris", "bound": "hbm", "mt_tests_per_ray": round(c[1] / R, 2),
                      "candidate_bins_per_triangle": round(c[0] / n_faces, 3)}
         else:
+            # k_trace4 walks an L2-resident tree: its HBM traffic is ~12 MB per launch against ~0.5 GB of algorithmic
+            # bytes, so "hbm" only says which peak the contract figure is priced against -- what bounds the kernel is
+            # the dependent chain of node fetches (`latency` below)
             alg = c[0] * LB_B_NODE + c[1] * LB_B_TRI + R * LB_B_RAY
-            extra = {"kernel": "k_trace4", "nodes_per_ray": round(c[0] / R, 2), "tris_per_ray": round(c[1] / R, 2)}
+            extra = {"kernel": "k_trace4", "bound": "hbm", "nodes_per_ray": round(c[0] / R, 2),
+                     "tris_per_ray": round(c[1] / R, 2)}
         alg_scan = alg
         alg = alg * spl
-        ach = alg / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
-        # MI355X_MICROARCH.md HBM section); collected on workload C2 only
-        # (k_sc_tris: profiles/r01/f_pmc_bench.txt, the passes run on this very command -- 351.9 MB per launch of
-        # 8 scans, 44.3 MB per single-scan launch; k_trace4: profiles/r01/b_pmc_lbvh.txt)
-        traffic = {"scatter": 351.9e6 * spl / 8 if spl > 1 else 44.3e6, "lbvh": 12.4e6}[strategy] \
-            if args.workload == "C2" else None
-        d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_ms": round(kern_ms, 5),
+        ach = alg / (serial_ms * 1e-3) / 1e9
+        traffic, traffic_src, te = measured_traffic(strategy, spl)
+        d = {"bound": extra.pop("bound"), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+             "avg_kernel_ms": round(serial_ms, 5),
              "algorithmic_bytes_per_launch": int(alg), "scans_per_launch": spl,
              "algorithmic_bytes_per_scan": int(alg_scan),
-             "probe": f"HIP events on the launch stream around every {PROBE_EVERY}th launch of the timed region"}
+             "probe": "HIP events on the launch stream around the dominant kernel, launches of the timed region's shape "
+                      "issued back to back on ONE stream right after the timed region (exclusive durations: nothing "
+                      "runs beside the kernel)"}
+        if traffic:
+            d["traffic_frac_of_peak"] = round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if insitu_ms == insitu_ms:
+            d["in_situ"] = {"avg_kernel_ms": round(insitu_ms, 5),
+                            "achieved": round(alg / (insitu_ms * 1e-3) / 1e9, 1),
+                            "frac": round(alg / (insitu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": f"the same launches inside the timed region (every {PROBE_EVERY}th sampled), where "
+                                    "several launches overlap: the duration is NOT exclusive"}
+        if strategy == "lbvh":
+            # latency roofline of the traversal: a quad's visits are a dependent chain, one L2 round trip each
+            visits = c[0] / R + c[1] / R / 4.0  # node steps + leaf steps (a leaf step tests up to 4 triangles)
+            l2_ns = 200 / 2.4  # ~200 cycles L2 hit (MI355X_MICROARCH.md) at 2.4 GHz
+            floor_ms = visits * l2_ns * 1e-6
+            d["latency"] = {"dependent_steps_per_ray": round(visits, 1), "l2_hit_ns": round(l2_ns, 1),
+                            "chain_floor_ms": round(floor_ms, 5), "frac": round(floor_ms / serial_ms, 4),
+                            "note": "dependent node / leaf fetches x L2 hit latency = the shortest a ray's walk can "
+                                    "be; with enough rays resident the launch could approach it"}
         d.update(extra)
         return d
 
+    def serial_probe_ms(strategy, n=24):
+        """Launches of the timed region's shape (scatter: one lt_scene_render_batch_dev of --batch scans; lbvh: build +
+        trace of one scan), back to back on ONE stream, events around the dominant kernel: exclusive durations."""
+        import ctypes as C
+        from lidar_transfer_amd import _lib
+        lib = _lib.load()
+        vp = C.c_void_p
+        evs = []
+        B = args.batch if strategy == "scatter" else 1
+        st = streams[0]
+        org_b = (C.c_float * (3 * B))(*(list(origin) * B))
+        with torch.cuda.stream(st):
+            for i in range(n + 4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if strategy == "lbvh":
+                    w = workers[0]
+                    w.set_mesh(*scenes[i % len(scenes)])
+                    w.build()
+                    w.set_probe(e0, e1)
+                    w.trace(rays, origin, H, out=scratch[0])
+                else:
+                    for j in range(B):
+                        workers[j].set_mesh(*scenes[(i * B + j) % len(scenes)])
+                    workers[0].set_probe(e0, e1)
+                    arr = lambda vals: (vp * B)(*vals)  # noqa: E731
+                    outs = {k: arr([scratch[j][k].data_ptr() for j in range(B)]) for k in
+                            ("endpoints", "endcolors", "range", "endrem", "tri")}
+                    _lib.check(lib.lt_scene_render_batch_dev(B, arr([workers[j]._h for j in range(B)]),
+                                                             arr([raysets[j]._h for j in range(B)]), org_b,
+                                                             outs["endpoints"], outs["endcolors"], outs["range"],
+                                                             outs["endrem"], outs["tri"],
+                                                             _lib.LT_TRACE_WRITE_MISSES, vp(st.cuda_stream)),
+                               "serial probe")
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs[4:]]))
+
     def isolated_kernel_ms(strategy, n=24):
-        """Outside the clock: the dominant kernel alone on an otherwise idle GPU (one scan at a time).  `frac`
-        above is measured inside the timed region, where `streams_per_gpu` scans share the chip and every
-        launch is stretched by its neighbours; this is the same kernel without them."""
+        """Outside the clock: the dominant kernel alone on an otherwise idle GPU, ONE scan per launch."""
         # back to back on ONE stream (launches of one stream do not overlap), one synchronisation at the end: a
         # host round trip between launches lets the GPU drop its clocks and measures that instead
         w, evs = workers[0], []
@@ -520,34 +610,108 @@ def main():
                          "note": "the larger direction's bytes / call time (the link is full duplex)"},
                 "hits": int((rg > 0).sum())}
 
+    def fusion_chain(n=6):
+        """Upstream + hot path without the mesh ever leaving HBM (SURVEY.md section 8f-1/2 + 8a): per output scan
+        reset the TSDF volume, integrate one observation (fusion_lidar.py:252-287), marching cubes on the device
+        (:403-424), render the target sensor's image from the mesh where it was written.  Volume = the reference's
+        default voxel_bounds at 5 cm (config/lidar_transfer.yaml: 2000 x 2000 x 200 voxels, 4 x 3.2 GB)."""
+        import ctypes as C
+        from lidar_transfer_amd import _lib
+        from lidar_transfer_amd.fusion import DeviceMesh, TSDFVolume
+        lib = _lib.load()
+        if torch.cuda.get_device_properties(dev).total_memory < 60 * 2**30:
+            return None
+        vp = C.c_void_p
+        w = workers[0]
+        w.set_mesh(*scenes[0])
+        o = w.render(raysets[0], origin)   # the observation: this very sensor looking at scene 0
+        torch.cuda.synchronize()
+        lab = o["endcolors"][:, 2].reshape(H, W).float().contiguous()
+        folded = (lab * 65536.0).contiguous()   # label in channel 0 (laserscan.py:893-895), folded as fusion_lidar.py:261-264
+        depth = o["range"].reshape(H, W).contiguous()
+        remi = o["endrem"].reshape(H, W).contiguous()
+        vol = TSDFVolume(np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]]), 0.05, wl["fov_up"], wl["fov_down"])
+        mesh = DeviceMesh(local_rank)
+        st = torch.cuda.current_stream(dev)
+        sp = vp(st.cuda_stream)
+        org = (C.c_float * 3)(*origin)
+        out = scratch[0]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ms = np.zeros((n, 4))
+        t_wall = []
+        for i in range(n + 1):
+            t0 = time.perf_counter()
+            ev[0].record()
+            _lib.check(lib.lt_tsdf_reset(vol._h, sp), "reset")
+            ev[1].record()
+            _lib.check(lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), depth.data_ptr(), remi.data_ptr(), H, W, 1.0,
+                                                 _lib.LT_TSDF_MERGE, sp), "integrate")
+            ev[2].record()
+            _lib.check(lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None), "marching cubes")
+            ev[3].record()
+            _lib.check(lib.lt_scene_set_mesh(w._h, mesh._h), "set mesh")
+            _lib.check(lib.lt_scene_render_dev(w._h, raysets[0]._h, org, out["endpoints"].data_ptr(),
+                                               out["endcolors"].data_ptr(), out["range"].data_ptr(),
+                                               out["endrem"].data_ptr(), out["tri"].data_ptr(),
+                                               _lib.LT_TRACE_WRITE_MISSES, sp, None), "render")
+            ev[4].record()
+            torch.cuda.synchronize()
+            if i > 0:
+                t_wall.append(time.perf_counter() - t0)
+                ms[i - 1] = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+        hits_c = int((out["range"] > 0).sum().item())
+        nv, nf = mesh.n_verts, mesh.n_faces
+        t = float(np.median(t_wall))
+        m = np.median(ms, axis=0)
+        nvox = int(np.prod(vol._vol_dim))
+        mesh.close()
+        vol.close()
+        return {"what": "per output scan: reset 2000x2000x200 TSDF volume -> integrate one 64x2048 observation -> marching "
+                        "cubes on the device -> render the target image; the mesh never leaves HBM (no PCIe between "
+                        "fusion and range image)",
+                "ms_per_scan": round(t * 1e3, 3), "scans_per_s": round(1.0 / t, 1), "value": round(R / t / 1e6, 2),
+                "unit": "Mrays/s", "voxels": nvox, "mesh_verts": nv, "mesh_faces": nf, "hit_fraction": round(hits_c / R, 4),
+                "phase_ms": {"reset": round(float(m[0]), 3), "integrate": round(float(m[1]), 3),
+                             "marching_cubes": round(float(m[2]), 3), "render": round(float(m[3]), 3)},
+                "hbm": {"reset_GBs": round(4 * nvox * 4 / (m[0] * 1e-3) / 1e9, 1),
+                        "marching_cubes_field_stream_GBs": round(nvox * 4 / (m[2] * 1e-3) / 1e9, 1),
+                        "note": "reset writes 4 fields; marching cubes reads the tsdf field once (and 128 MB of sign bits)"}}
+
     dt, kern_ms, hits = run(args.strategy, K, Wm, keep=True)
+    ser_ms = serial_probe_ms(args.strategy)
     other = None
     if not args.no_other:
         oname = "lbvh" if args.strategy == "scatter" else "scatter"
-        Ko = max(20, K // 4) if oname == "lbvh" else max(K, 400)  # a scatter step is ~15x shorter than an LBVH step
-        odt, okern, _ = run(oname, Ko, max(4, Wm // 4), keep=False)
+        Ko = max(20, K // 16) if oname == "lbvh" else max(K, 400)  # a scatter scan is ~15x shorter than an LBVH scan
+        odt, okern, _ = run(oname, Ko, max(4, Wm // 16), keep=False)
         other = {"strategy": oname, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
-                 "ms_per_scan": round(odt / Ko * 1e3, 4), "scans": Ko, "roofline": roofline(oname, okern)}
+                 "ms_per_scan": round(odt / Ko * 1e3, 4), "scans": Ko,
+                 "roofline": roofline(oname, serial_probe_ms(oname, n=12), okern)}
 
     iso_ms = isolated_kernel_ms(args.strategy)
     e2e = e2e_host_call() if (rank == 0 and not args.no_e2e) else None
+    chain = fusion_chain() if (rank == 0 and not args.no_chain and world == 1) else None
     if rank == 0:
         value = world * K * R / dt / 1e6
-        rl = roofline(args.strategy, kern_ms)
+        rl = roofline(args.strategy, ser_ms, kern_ms)
         rl["isolated"] = {"avg_kernel_ms": round(iso_ms, 5),
                           "achieved": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9, 1),
                           "frac": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "same kernel, launches of ONE scan each, back to back on one stream (nothing beside "
                                   "them), after the timed region"}
-        if args.strategy == "scatter" and args.workload == "C2" and args.batch == 8:
-            # all three kernels of a scan together (profiles/r01/f_pmc_bench.txt: 351.9 + 0.8 + 60.2 MB per batch of
-            # 8) at the measured scan rate: the HBM bandwidth the whole path sustains over the timed region
-            per_scan = (351.9e6 + 0.8e6 + 60.2e6) / 8
-            rl["whole_path"] = {"hbm_bytes_per_scan": int(per_scan),
-                                "sustained_GBs": round(K / dt * per_scan / 1e9, 1),
-                                "frac_of_peak": round(K / dt * per_scan / 1e9 / HBM_PEAK_GBS, 4),
-                                "note": "PMC traffic of k_sc_tris + k_sc_rest + k_sc_resolve per scan x scans/s of "
-                                        "this rank; 6290 GB/s is what a float4 copy reaches on this chip"}
+        if args.strategy == "scatter":
+            # all three kernels of a scan together at the measured scan rate: the HBM bandwidth the whole path
+            # sustains over the timed region (PMC traffic per launch from profiles/rNN/pmc.json, null when stale)
+            parts = [measured_traffic("scatter", args.batch, k)[0] for k in ("k_sc_tris", "k_sc_rest", "k_sc_resolve")]
+            if all(p is not None for p in parts):
+                per_scan = sum(parts) / args.batch
+                rl["whole_path"] = {"hbm_bytes_per_scan": int(per_scan),
+                                    "sustained_GBs": round(K / dt * per_scan / 1e9, 1),
+                                    "frac_of_peak": round(K / dt * per_scan / 1e9 / HBM_PEAK_GBS, 4),
+                                    "note": "PMC traffic of k_sc_tris + k_sc_rest + k_sc_resolve per scan x scans/s of "
+                                            "this rank; 6290 GB/s is what a float4 copy reaches on this chip"}
+            else:
+                rl["whole_path"] = None
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -570,6 +734,8 @@ def main():
             out["other_strategy"] = other
         if e2e:
             out["e2e"] = e2e
+        if chain:
+            out["fusion_chain"] = chain
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             cb = cpu_baseline(wl, 0, args.cpu_reps or 12)
             out["cpu_baseline"] = cb
