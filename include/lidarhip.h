@@ -21,6 +21,8 @@
 #ifndef LIDARHIP_H
 #define LIDARHIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -78,7 +80,8 @@ typedef struct lt_scene lt_scene; /* opaque: device workspace + BVH of one mesh 
  *                          float* endpoints, int* endcolors, float* range, float* endrem)
  * (auxiliary/raytracer/RayTracer.cpp:116-124), but returns a status instead of void.
  * All pointers are HOST pointers; the call uploads the mesh and rays to the current HIP device,
- * builds the BVH, casts the rays and copies the four outputs back.  As in the reference, outputs
+ * casts the rays and copies the four outputs back.  State (workspace, stream, the binned ray set of the previous
+ * call) is kept per calling THREAD: concurrent callers do not serialise each other.  As in the reference, outputs
  * are written only for rays that hit (the caller pre-zeroes them, fusion_lidar.py:440-447).
  */
 int lt_ctrace(const float* rays, const float* origin, const float* verts, const int* faces,
@@ -92,6 +95,43 @@ int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, con
                  const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
                  float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
                  lt_stats* stats);
+
+/* ---- host buffers, pipelined: a sequence of scans with their transfers overlapped -------------------------------- */
+
+typedef struct lt_hostpipe lt_hostpipe; /* opaque: `depth` scans in flight, a worker thread, three HIP streams */
+
+/*
+ * The work of lt_ctrace for a SEQUENCE of scans that share one ray set (one target sensor model, as in the reference's
+ * batch loop lidar_deform.py:393-462, which calls throw_rays_at_mesh -> ctrace once per output scan,
+ * fusion_lidar.py:434-451): while scan i renders, scan i + 1 uploads and scan i - 1 downloads.
+ *   rays    HOST [n_rays,3] f32, uploaded and binned once;  depth = scans in flight (3 is enough to overlap)
+ *   flags   LT_TRACE_LABEL_IMAGE | LT_TRACE_NORM_EXACT | LT_TRACE_NORM_AMD
+ * Unlike lt_ctrace the pipe writes EVERY cell of the output images (misses: 0, tri -1) -- what the reference's
+ * pre-zeroed arrays (fusion_lidar.py:440-447) contain after ctrace -- so nothing is uploaded for the outputs.
+ */
+int lt_hostpipe_create(lt_hostpipe** pipe, const float* rays, int n_rays, int height, int depth, unsigned flags,
+                       int device);
+
+/* Queue one scan: mesh in HOST arrays with the layouts of ctrace (RayTracer.cpp:116-124), except that `colors` may be
+ * the uint8 [n_verts,3] array get_mesh returns (colors_are_u8 != 0; fusion_lidar.py:423) instead of its int32 copy
+ * (:435) -- a quarter of the bytes on the link.  Output HOST arrays as for lt_ctrace_ex (any may be NULL).  Returns
+ * immediately; every input and output array must stay valid and untouched until lt_hostpipe_wait(ticket),
+ * lt_hostpipe_flush, or until `depth` further scans have been submitted (a submit that needs the slot of an older
+ * scan completes that scan first -- its status is what this call returns).  Pageable and pinned memory both run at
+ * the wire rate here; pinned (lt_host_alloc) input additionally frees the worker thread during the transfer. */
+int lt_hostpipe_submit(lt_hostpipe* pipe, const float* origin, const float* verts, const int* faces,
+                       const void* colors, int colors_are_u8, const float* rem, int n_verts, int n_faces,
+                       float* endpoints, int* endcolors, float* range, float* endrem, int* tri, int* ticket);
+
+/* Block until the scan with this ticket is complete: its images are in the caller's arrays. */
+int lt_hostpipe_wait(lt_hostpipe* pipe, int ticket);
+/* Complete everything submitted so far; reports deferred device-side errors (LT_ERR_BAD_INDEX). */
+int lt_hostpipe_flush(lt_hostpipe* pipe);
+int lt_hostpipe_destroy(lt_hostpipe* pipe);
+
+/* Page-locked host memory (hipHostMalloc) for callers that want their arrays DMA-able without staging. */
+int lt_host_alloc(void** p, size_t bytes);
+int lt_host_free(void* p);
 
 /* ---- split API: build once, trace many, device-resident buffers ----------------------------- */
 

@@ -28,7 +28,8 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_render_batch_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
            "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
            "lt_tsdf_volumes", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
-           "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh"]
+           "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
+           "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free"]
 
 
 class Stats(C.Structure):
@@ -66,10 +67,13 @@ def load():
     # libhsa-runtime64.  If the system copy were loaded first (as a dependency of liblidarhip.so)
     # and torch's second, torch would find "No HIP GPUs".  Importing torch first makes the dynamic
     # linker resolve our DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # LIDARHIP_NO_TORCH=1: a numpy-only process (C_Trace / HostScanPipeline callers) that will never import torch may
+    # skip this and run on the system ROCm runtime instead of the one bundled with the torch wheel.
+    if os.environ.get("LIDARHIP_NO_TORCH", "") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         lib = C.CDLL(path)
     except OSError as e:
@@ -120,6 +124,17 @@ def load():
     lib.lt_scene_set_mesh.argtypes = [vp, vp]
     for name in ("lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev", "lt_marching_cubes_dev",
                  "lt_mesh_get", "lt_scene_set_mesh"):
+        getattr(lib, name).restype = C.c_int
+    lib.lt_hostpipe_create.argtypes = [C.POINTER(vp), fp, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int]
+    lib.lt_hostpipe_submit.argtypes = [vp, fp, fp, ip, vp, C.c_int, fp, C.c_int, C.c_int, fp, ip, fp, fp, ip,
+                                       C.POINTER(C.c_int)]
+    lib.lt_hostpipe_wait.argtypes = [vp, C.c_int]
+    lib.lt_hostpipe_flush.argtypes = [vp]
+    lib.lt_hostpipe_destroy.argtypes = [vp]
+    lib.lt_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.lt_host_free.argtypes = [vp]
+    for name in ("lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait", "lt_hostpipe_flush",
+                 "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free"):
         getattr(lib, name).restype = C.c_int
     lib.lt_scene_set_probe.argtypes = [vp, vp, vp]
     lib.lt_scene_set_probe.restype = C.c_int

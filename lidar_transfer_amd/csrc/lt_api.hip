@@ -1,8 +1,6 @@
 // lt_api.hip -- C-ABI entry points of liblidarhip.so (declared in include/lidarhip.h).
 #include "lt_internal.h"
 #include <cpuid.h>
-#include <mutex>
-#include <vector>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -134,7 +132,7 @@ extern "C" int lt_scene_destroy(lt_scene* s) {
   return LT_OK;
 }
 
-static int check_mesh_args(const char* who, const void* verts, const void* faces, const void* colors,
+int lt_check_mesh_args(const char* who, const void* verts, const void* faces, const void* colors,
                            const void* rem, int n_verts, int n_faces) {
   if (n_verts < 0 || n_faces < 0 || (n_faces > 0 && (!verts || !faces || !colors || !rem))) {
     lt_set_error("%s: invalid mesh (n_verts=%d n_faces=%d, NULL array?)", who, n_verts, n_faces);
@@ -153,14 +151,14 @@ extern "C" int lt_scene_set_mesh_dev(lt_scene* s, const float* verts, const int*
     lt_set_error("lt_scene_set_mesh_dev: NULL scene");
     return LT_ERR_INVALID_ARG;
   }
-  LT_CHECK(check_mesh_args("lt_scene_set_mesh_dev", verts, faces, colors, rem, n_verts, n_faces));
+  LT_CHECK(lt_check_mesh_args("lt_scene_set_mesh_dev", verts, faces, colors, rem, n_verts, n_faces));
   s->verts = verts; s->faces = faces; s->colors = colors; s->rem = rem;
   s->n_verts = n_verts; s->n_faces = n_faces;
   s->built = 0;
   return LT_OK;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }  // (also in lt_host.hip)
 
 extern "C" int lt_scene_set_mesh_host(lt_scene* s, const float* verts, const int* faces, const int* colors,
                                       const float* rem, int n_verts, int n_faces, void* stream_) {
@@ -168,7 +166,7 @@ extern "C" int lt_scene_set_mesh_host(lt_scene* s, const float* verts, const int
     lt_set_error("lt_scene_set_mesh_host: NULL scene");
     return LT_ERR_INVALID_ARG;
   }
-  LT_CHECK(check_mesh_args("lt_scene_set_mesh_host", verts, faces, colors, rem, n_verts, n_faces));
+  LT_CHECK(lt_check_mesh_args("lt_scene_set_mesh_host", verts, faces, colors, rem, n_verts, n_faces));
   hipStream_t stream = (hipStream_t)stream_;
   LT_HIP(hipSetDevice(s->device));
   const size_t bv = align256((size_t)n_verts * 12), bf = align256((size_t)n_faces * 12), bc = bv,
@@ -310,135 +308,4 @@ unsigned lt_env_norm_flag() {
     return strcmp(vendor, "AuthenticAMD") == 0 ? LT_TRACE_NORM_AMD : 0u;
   }
   return 0u;
-}
-
-// ---- one-call drop-in for the reference's ctrace -------------------------------------------------------
-// A process-wide scratch scene (workspace + staging buffers) is kept between calls so that a
-// sequence of scans does not pay hipMalloc every time; calls are serialised like the reference's
-// (Cython holds the GIL around ctrace, RayTracerCython.pyx:30-33).
-static std::mutex g_mu;
-static lt_scene* g_scene = nullptr;
-static int g_scene_dev = -1;
-static void* g_io = nullptr;
-static size_t g_io_bytes = 0;
-// ray set of the previous call: a sensor model's rays are the same for every scan of a sequence, so the
-// binned ray set is rebuilt only when the caller's rays (compared on the host) actually change
-static lt_rayset* g_rs = nullptr;
-static std::vector<float> g_rs_rays;
-static int g_rs_height = 0;
-static unsigned g_rs_norm = 0;
-
-static int ctrace_locked(const float* rays, const float* origin, const float* verts, const int* faces,
-                         const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
-                         float* endpoints, int* endcolors, float* range, float* endrem, int* tri, lt_stats* stats) {
-  int dev = 0;
-  LT_HIP(hipGetDevice(&dev));
-  if (g_scene && g_scene_dev != dev) {
-    lt_scene_destroy(g_scene);
-    g_scene = nullptr;
-    if (g_rs) (void)lt_rayset_destroy(g_rs);
-    g_rs = nullptr;
-    if (g_io) (void)hipFree(g_io);
-    g_io = nullptr;
-    g_io_bytes = 0;
-  }
-  if (!g_scene) {
-    LT_CHECK(lt_scene_create(&g_scene, dev));
-    g_scene_dev = dev;
-  }
-  lt_scene* s = g_scene;
-  hipStream_t stream = nullptr;
-  const int W = n_rays / height;
-  const size_t R = (size_t)W * height;
-  // staging: rays | endpoints | endcolors | range | endrem | tri
-  const size_t b3 = align256(R * 12), b1 = align256(R * 4);
-  const size_t total = 3 * b3 + 3 * b1 + 256;
-  if (total > g_io_bytes) {
-    if (g_io) {
-      LT_HIP(hipDeviceSynchronize());
-      (void)hipFree(g_io);
-      g_io = nullptr;
-      g_io_bytes = 0;
-    }
-    LT_HIP(hipMalloc(&g_io, total));
-    g_io_bytes = total;
-  }
-  char* io = (char*)g_io;
-  float* d_rays = (float*)io;
-  float* d_end = (float*)(io + b3);
-  int* d_col = (int*)(io + 2 * b3);
-  float* d_range = (float*)(io + 3 * b3);
-  float* d_rem = (float*)(io + 3 * b3 + b1);
-  int* d_tri = (int*)(io + 3 * b3 + 2 * b1);
-  LT_CHECK(lt_scene_set_mesh_host(s, verts, faces, colors, rem, n_verts, n_faces, stream));
-  if (R > 0) {
-    LT_HIP(hipMemcpyAsync(d_rays, rays, R * 12, hipMemcpyHostToDevice, stream));
-    // outputs are written only for hits (RayTracer.cpp:73): start from the caller's contents
-    if (endpoints) LT_HIP(hipMemcpyAsync(d_end, endpoints, R * 12, hipMemcpyHostToDevice, stream));
-    if (endcolors) LT_HIP(hipMemcpyAsync(d_col, endcolors, R * 12, hipMemcpyHostToDevice, stream));
-    if (range) LT_HIP(hipMemcpyAsync(d_range, range, R * 4, hipMemcpyHostToDevice, stream));
-    if (endrem) LT_HIP(hipMemcpyAsync(d_rem, endrem, R * 4, hipMemcpyHostToDevice, stream));
-    if (tri) LT_HIP(hipMemcpyAsync(d_tri, tri, R * 4, hipMemcpyHostToDevice, stream));
-  }
-  lt_stats st;
-  memset(&st, 0, sizeof(st));
-  const unsigned norm_flag = lt_env_norm_flag();
-  // LIDARHIP_STRATEGY=lbvh: build the linear BVH and traverse it; default: single-origin triangle
-  // scatter (lt_scatter.hip) -- both produce identical images.
-  const char* sg = getenv("LIDARHIP_STRATEGY");
-  if (sg && strcmp(sg, "lbvh") == 0) {
-    LT_CHECK(lt_build_launch(s, stream, stats ? &st : nullptr));
-    LT_CHECK(lt_trace_launch(s, d_rays, origin, (int)R, height, endpoints ? d_end : nullptr,
-                             endcolors ? d_col : nullptr, range ? d_range : nullptr, endrem ? d_rem : nullptr,
-                             tri ? d_tri : nullptr, (stats ? LT_TRACE_COUNT : 0u) | norm_flag, stream,
-                             stats ? &st : nullptr));
-  } else {
-    const bool same = g_rs && g_rs_height == height && g_rs_norm == norm_flag && g_rs_rays.size() == R * 3 &&
-                      (R == 0 || memcmp(g_rs_rays.data(), rays, R * 12) == 0);
-    if (!same) {
-      if (g_rs) (void)lt_rayset_destroy(g_rs);
-      g_rs = nullptr;
-      LT_CHECK(lt_rayset_create_dev(&g_rs, d_rays, (int)R, height, norm_flag, stream));
-      g_rs_rays.assign(rays, rays + R * 3);
-      g_rs_height = height;
-      g_rs_norm = norm_flag;
-    }
-    LT_CHECK(lt_scene_render_dev(s, g_rs, origin, endpoints ? d_end : nullptr, endcolors ? d_col : nullptr,
-                                 range ? d_range : nullptr, endrem ? d_rem : nullptr, tri ? d_tri : nullptr,
-                                 (stats ? LT_TRACE_COUNT : 0u), stream, stats ? &st : nullptr));
-  }
-  if (R > 0) {
-    if (endpoints) LT_HIP(hipMemcpyAsync(endpoints, d_end, R * 12, hipMemcpyDeviceToHost, stream));
-    if (endcolors) LT_HIP(hipMemcpyAsync(endcolors, d_col, R * 12, hipMemcpyDeviceToHost, stream));
-    if (range) LT_HIP(hipMemcpyAsync(range, d_range, R * 4, hipMemcpyDeviceToHost, stream));
-    if (endrem) LT_HIP(hipMemcpyAsync(endrem, d_rem, R * 4, hipMemcpyDeviceToHost, stream));
-    if (tri) LT_HIP(hipMemcpyAsync(tri, d_tri, R * 4, hipMemcpyDeviceToHost, stream));
-  }
-  LT_HIP(hipStreamSynchronize(stream));
-  if (stats) *stats = st;
-  return lt_scene_status(s);
-}
-
-extern "C" int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, const int* faces,
-                            const int* colors, const float* rem, int n_rays, int n_verts, int n_faces,
-                            int height, float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
-                            lt_stats* stats) {
-  if (height <= 0 || n_rays < 0 || !origin || (n_rays > 0 && !rays)) {
-    lt_set_error("lt_ctrace: invalid argument (n_rays=%d height=%d)", n_rays, height);
-    return LT_ERR_INVALID_ARG;
-  }
-  LT_CHECK(check_mesh_args("lt_ctrace", verts, faces, colors, rem, n_verts, n_faces));
-  std::lock_guard<std::mutex> lock(g_mu);
-  const int rc = ctrace_locked(rays, origin, verts, faces, colors, rem, n_rays, n_verts, n_faces, height, endpoints,
-                               endcolors, range, endrem, tri, stats);
-  // a failure half way may leave copies from / to the caller's arrays queued: they must not outlive the call
-  if (rc != LT_OK) (void)hipStreamSynchronize(nullptr);
-  return rc;
-}
-
-extern "C" int lt_ctrace(const float* rays, const float* origin, const float* verts, const int* faces,
-                         const int* colors, const float* rem, int n_rays, int n_verts, int n_faces, int height,
-                         float* endpoints, int* endcolors, float* range, float* endrem) {
-  return lt_ctrace_ex(rays, origin, verts, faces, colors, rem, n_rays, n_verts, n_faces, height, endpoints,
-                      endcolors, range, endrem, nullptr, nullptr);
 }

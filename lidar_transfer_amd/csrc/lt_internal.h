@@ -107,6 +107,8 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats);
 int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_rays, int height,
                     float* endpoints, int* endcolors, float* range, float* endrem, int* tri,
                     unsigned flags, hipStream_t stream, lt_stats* stats);
+int lt_check_mesh_args(const char* who, const void* verts, const void* faces, const void* colors, const void* rem,
+                        int n_verts, int n_faces);
 unsigned lt_env_norm_flag();  // LIDARHIP_NORMALIZE -> 0 | LT_TRACE_NORM_EXACT | LT_TRACE_NORM_AMD
 bool lt_binary_path();  // LIDARHIP_TRACE=binary: one ray per lane over binary nodes (A/B cross-check)
 int lt_scene_reserve(lt_scene* s, int n_faces);

@@ -151,3 +151,101 @@ class ScanPipeline:
             self.close()
         except Exception:
             pass
+
+
+class HostScanPipeline:
+    """The reference's loop over output scans with HOST meshes (``throw_rays_at_mesh`` -> ``C_Trace`` per scan,
+    fusion_lidar.py:434-451), pipelined: ``lt_hostpipe`` keeps ``depth`` scans in flight -- scan i + 1 uploads while
+    scan i renders and scan i - 1 downloads -- so that a sequence runs at the rate of the PCIe link instead of the sum
+    of its phases.  numpy in, numpy out; nothing here touches torch.
+
+        pipe = HostScanPipeline(rays, H)                       # rays: [H*W, 3] float32 (create_rays)
+        for verts, faces, colors, rem in meshes:               # get_mesh's arrays; colors uint8 [V,3] or int32
+            t = pipe.submit(verts, faces, colors, rem, origin)
+            ...
+            images = pipe.wait(t)                              # dict: endpoints, endcolors, range, endrem, tri
+        pipe.close()
+
+    Every cell of the images is written (misses: 0, ``tri`` -1), like the reference's pre-zeroed arrays hold after
+    ``ctrace``.  ``label_image=True`` makes ``endcolors`` the [H*W] semantic-label image (``deform``'s unpack,
+    laserscan.py:912)."""
+
+    def __init__(self, rays, H, depth=3, label_image=False, device=None, normalize="intel"):
+        import numpy as np
+        self._np = np
+        self._lib = _lib.load()
+        rays = np.ascontiguousarray(np.asarray(rays, np.float32).reshape(-1, 3))
+        self.n_rays = (rays.shape[0] // int(H)) * int(H)
+        self.label_image = bool(label_image)
+        flags = (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0) | \
+            {"intel": 0, "exact": _lib.LT_TRACE_NORM_EXACT, "amd": _lib.LT_TRACE_NORM_AMD}[normalize]
+        h = C.c_void_p()
+        _lib.check(self._lib.lt_hostpipe_create(C.byref(h), rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0],
+                                                int(H), int(depth), flags, -1 if device is None else int(device)),
+                   "lt_hostpipe_create")
+        self._h = h
+        self.depth = int(depth)
+        self._live = {}  # ticket -> (inputs kept alive, outputs)
+
+    def alloc_outputs(self):
+        np = self._np
+        R = self.n_rays
+        return dict(endpoints=np.empty((R, 3), np.float32),
+                    endcolors=np.empty((R,) if self.label_image else (R, 3), np.int32),
+                    range=np.empty(R, np.float32), endrem=np.empty(R, np.float32), tri=np.empty(R, np.int32))
+
+    def submit(self, verts, faces, colors, rem, origin, out=None):
+        """Queue one scan; returns its ticket.  The arrays are referenced (not copied) until :meth:`wait`."""
+        np = self._np
+        verts = np.ascontiguousarray(verts, np.float32)
+        faces = np.ascontiguousarray(faces, np.int32)
+        rem = np.ascontiguousarray(rem, np.float32)
+        colors = np.asarray(colors)
+        u8 = colors.dtype == np.uint8
+        colors = np.ascontiguousarray(colors, np.uint8 if u8 else np.int32)
+        org = np.ascontiguousarray(np.asarray(origin, np.float32).reshape(-1)[:3])
+        if out is None:
+            out = self.alloc_outputs()
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+
+        def p(key, typ):
+            a = out.get(key)
+            return a.ctypes.data_as(typ) if a is not None else None
+
+        t = C.c_int(-1)
+        rc = self._lib.lt_hostpipe_submit(self._h, org.ctypes.data_as(fp), verts.ctypes.data_as(fp),
+                                          faces.ctypes.data_as(ip), colors.ctypes.data_as(C.c_void_p), int(u8),
+                                          rem.ctypes.data_as(fp), verts.size // 3, faces.size // 3, p("endpoints", fp),
+                                          p("endcolors", ip), p("range", fp), p("endrem", fp), p("tri", ip), C.byref(t))
+        if t.value >= 0:
+            self._live[t.value] = ((verts, faces, colors, rem, org), out)
+            self._live.pop(t.value - self.depth, None)  # that scan was completed by this submit
+        _lib.check(rc, "lt_hostpipe_submit")
+        return t.value
+
+    def wait(self, ticket):
+        """Images of the scan with this ticket (complete when the call returns)."""
+        _lib.check(self._lib.lt_hostpipe_wait(self._h, int(ticket)), "lt_hostpipe_wait")
+        item = self._live.get(ticket)
+        return item[1] if item is not None else None
+
+    def flush(self):
+        _lib.check(self._lib.lt_hostpipe_flush(self._h), "lt_hostpipe_flush")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_hostpipe_destroy(self._h)
+            self._h = None
+            self._live = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

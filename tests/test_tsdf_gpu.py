@@ -74,6 +74,33 @@ def test_plain_average_branch_vs_reference_numpy_cpu_mode():
     vol.close()
 
 
+def test_class_aware_branch_degenerates_to_the_pinned_average_for_a_single_class():
+    """The strongest pin of `merge == true` available without running CUDA: when every pixel carries label 0 -- the
+    label the fresh colour volume holds -- the class-aware kernel only ever takes its same-class branch
+    (fusion_lidar.py:191-203), whose tsdf / weight arithmetic is the plain running average.  Its volumes must then be
+    the golden ones of the reference's numpy CPU mode (F8: tsdf and weight there do not depend on the labels), and
+    bit-identical to this library's own `merge == false` kernel on tsdf, weight and remission."""
+    from lidar_transfer_amd.fusion import TSDFVolume
+    g = np.load(os.path.join(GOLD, "f8_tsdf_cpu_mode.npz"))
+    zero3 = np.zeros_like(g["label3"])
+    vols = {}
+    for merge in (True, False):
+        vol = TSDFVolume(g["bnds"], float(g["voxel"]), float(g["fov_up"]), float(g["fov_down"]), merge=merge)
+        for _ in range(2):
+            vol.integrate(zero3, g["depth_im"], g["rem_im"], np.eye(4), obs_weight=1.)
+        vols[merge] = [t.cpu().numpy() for t in vol.get_volume_tensors()]
+        vol.close()
+    tsdf, weight, color, rem = vols[True]
+    for k in (0, 1, 3):  # tsdf, weight, remission: the two kernels agree bit for bit
+        assert np.array_equal(vols[True][k].view(np.int32), vols[False][k].view(np.int32)), k
+    assert float(np.abs(color).max()) == 0.0
+    n = tsdf.size
+    same_w = weight == g["weight"]
+    assert (~same_w).sum() <= 2e-3 * n, f"{(~same_w).sum()} of {n} weights differ"
+    assert (g["weight"] > 0).sum() > 0.02 * n and (weight == 2).sum() > 0.01 * n
+    assert np.abs(tsdf[same_w] - g["tsdf"][same_w]).max() < 2e-4
+
+
 def test_volume_geometry_and_reset():
     from lidar_transfer_amd.fusion import TSDFVolume
     vol = TSDFVolume(np.array([[-1.0, 1.0], [-2.0, 2.0], [0.0, 0.55]]), 0.1, 3.0, -25.0)

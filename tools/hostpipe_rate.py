@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Throughput of the pipelined host-buffer path (lt_hostpipe) on C2 and where its time goes (one JSON line)."""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from lidar_transfer_amd import _lib
+from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.pipeline import HostScanPipeline
+from lidar_transfer_amd.synth import WORKLOADS, synth_scene
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+n_meshes = int(sys.argv[3]) if len(sys.argv) > 3 else 4      # distinct host meshes cycled
+few_out = len(sys.argv) > 4 and sys.argv[4] == "range"        # download the range image only
+wl = WORKLOADS["C2"]; H, W = wl["H"], wl["W"]
+host = []
+for i in range(n_meshes):
+    v, f, c, r = synth_scene(i, wl["tris"])
+    host.append((v, f, (c & 255).astype(np.uint8), r))
+rays = create_rays(wl["fov_up"], wl["fov_down"], H, W); org = np.zeros(3, np.float32)
+lib = _lib.load()
+lib.lt_debug_hostpipe_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+with HostScanPipeline(rays, H, depth=depth) as pipe:
+    outs = [pipe.alloc_outputs() for _ in range(depth + 1)]
+    if few_out:
+        outs = [{"range": o["range"]} for o in outs]
+    for o in outs:
+        for a in o.values(): a.fill(0)
+    for k in range(8): pipe.submit(*host[k % n_meshes], org, out=outs[k % len(outs)])
+    pipe.flush()
+    t0d = (C.c_double * 4)(); lib.lt_debug_hostpipe_times(pipe._h, t0d)
+    t0 = time.perf_counter(); tick = []
+    for k in range(n):
+        tick.append(pipe.submit(*host[k % n_meshes], org, out=outs[k % len(outs)]))
+        if k >= depth - 1: pipe.wait(tick[k - depth + 1])
+    pipe.flush()
+    dt = (time.perf_counter() - t0) / n
+    t1d = (C.c_double * 4)(); lib.lt_debug_hostpipe_times(pipe._h, t1d)
+    tr = (C.c_double * (256 * 6))(); lib.lt_debug_hostpipe_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.lt_debug_hostpipe_trace(pipe._h, tr)
+    tr = np.array(tr).reshape(256, 6)
+    last = (8 + n - 1) & 255
+    rows = [(last - 12 + i) & 255 for i in range(10)]
+    base = tr[rows[0], 0]
+    for rI in rows:
+        sys.stderr.write("ticket%%256=%3d submit %7.3f | issue %7.3f upload_end %7.3f issue_end %7.3f | collect %7.3f .. %7.3f\n" % ((rI,) + tuple((tr[rI] - base) * 1e3)))
+h2d = sum(a.nbytes for a in host[0])
+d2h = sum(a.nbytes for a in outs[0].values())
+hits = int((outs[(n - 1) % len(outs)]["range"] > 0).sum())
+print(json.dumps({"h2d_bytes": h2d, "d2h_bytes": d2h, "hits": hits, "n_scans": n, "torch_in_process": "torch" in sys.modules,
+                  "depth": depth, "meshes": n_meshes, "outputs": "range" if few_out else "all", "ms_per_scan": round(dt * 1e3, 4), "h2d_MB": round(h2d / 1e6, 2), "GBs": round(h2d / dt / 1e9, 2),
+                  "worker_issue_ms": round((t1d[1] - t0d[1]) / n * 1e3, 4), "worker_upload_ms": round((t1d[2] - t0d[2]) / n * 1e3, 4),
+                  "caller_collect_ms": round((t1d[3] - t0d[3]) / n * 1e3, 4)}))
