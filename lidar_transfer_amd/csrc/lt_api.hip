@@ -73,6 +73,17 @@ int lt_scene_reserve_rays(lt_scene* s, int n_rays) {
     s->overflow = nullptr;
   }
   LT_CHECK(dev_alloc(&s->overflow, (size_t)n_rays * (LT_STACK4_MAX - LT_STACK4_LDS)));  // >= the binary kernel's 32
+  if (s->tail_stack) (void)hipFree(s->tail_stack);
+  if (s->tail_meta) (void)hipFree(s->tail_meta);
+  if (s->tail_queue) (void)hipFree(s->tail_queue);
+  s->tail_stack = nullptr; s->tail_meta = nullptr; s->tail_queue = nullptr;
+  LT_CHECK(dev_alloc(&s->tail_stack, (size_t)n_rays * LT_TAIL_SAVE));
+  LT_CHECK(dev_alloc(&s->tail_meta, (size_t)n_rays));
+  LT_CHECK(dev_alloc(&s->tail_queue, (size_t)n_rays));
+  if (!s->tail_count) {
+    LT_CHECK(dev_alloc(&s->tail_count, 4));
+    LT_HIP(hipMemset(s->tail_count, 0, 4 * sizeof(int)));
+  }
   s->cap_rays = n_rays;
   return LT_OK;
 }
@@ -123,6 +134,10 @@ extern "C" int lt_scene_destroy(lt_scene* s) {
   if (s->flags) (void)hipFree(s->flags);
   if (s->counters) (void)hipFree(s->counters);
   if (s->overflow) (void)hipFree(s->overflow);
+  if (s->tail_stack) (void)hipFree(s->tail_stack);
+  if (s->tail_meta) (void)hipFree(s->tail_meta);
+  if (s->tail_queue) (void)hipFree(s->tail_queue);
+  if (s->tail_count) (void)hipFree(s->tail_count);
   if (s->sc_cell) (void)hipFree(s->sc_cell);
   if (s->sc_large) (void)hipFree(s->sc_large);
   if (s->sc_slices) (void)hipFree(s->sc_slices);

@@ -46,6 +46,10 @@ void lt_set_error(const char* fmt, ...);
 #define LT_STACK_MAX 64        // Karras depth bound for 62-bit unique keys
 #define LT_STACK4_LDS 40       // quad traversal (4-wide nodes): stack entries per ray kept in LDS
 #define LT_STACK4_MAX 104      // 40 + 64 spill entries: <= 3 pushes per level, <= 31 levels of a collapsed Karras tree
+#define LT_TAIL_SAVE (LT_STACK4_MAX + 1)  // a handed-over ray: its stack + the reference it was about to visit
+#define LT_TAIL_STACK 512      // k_trace4_tail: work stack of a wave (LDS); above LT_TAIL_DFS entries one quad pops at a time
+#define LT_TAIL_DFS 256
+#define LT_TRACE4_STEP_CAP 40  // node + leaf steps a ray may take in k_trace4 before it is handed over (LIDARHIP_STEP_CAP)
 
 struct lt_scene {
   int device;
@@ -73,6 +77,13 @@ struct lt_scene {
   unsigned long long* counters;  // device: nodes, tris, hits, overflows (LT_TRACE_COUNT), then LT_DBG_WAVES clock pairs
   int* overflow;        // [cap_rays * (LT_STACK4_MAX - LT_STACK4_LDS)] stack spill area
   int cap_rays;
+  // hand-over of the rays whose walk exceeds the step cap of k_trace4 to k_trace4_tail (one wave per ray)
+  int* tail_stack;      // [cap_rays * LT_TAIL_SAVE] saved stack entries (node / leaf references, top last)
+  float4* tail_meta;    // [cap_rays] (best_t, best_face bits, entries saved, -)
+  int* tail_queue;      // [cap_rays] ray indices
+  int* tail_count;      // [2] rays queued by the launch in flight; used alternately (tail_parity), each launch's
+                        // tail kernel zeroes the counter of the next one
+  int tail_parity;
   // scatter strategy (lt_scatter.hip): state of the render in flight -- per SCENE, so that a ray set is read-only
   // during a render and one ray set (one sensor model) serves any number of scenes and streams at once
   unsigned long long* sc_cell;  // [sc_cap_cells] packed (t, face) z-min per ray; all-ones = empty, re-armed by k_sc_resolve
@@ -102,6 +113,8 @@ struct lt_tsdf {
 #define LT_BOUNDS_BLOCKS 256
 #define LT_DBG_WAVES 16384   // wave start/end clocks kept by a LT_TRACE_COUNT launch (debug)
 #define LT_FLAG_BAD_INDEX 1u
+#define LT_TRACE_DEBUG_STEPS 0x4000u  // internal trace flag: `tri` receives the node steps of each ray (k_trace4)
+#define LT_TRACE_DEBUG_TIMES 0x8000u  // internal trace flag: per-wave wall-clock stamps into the counters area
 
 int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats);
 int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_rays, int height,

@@ -212,8 +212,21 @@ __global__ __launch_bounds__(256) void k_trace(
 //   * leaf step: lane j runs Moller-Trumbore on triangle j of the leaf (<= 4), then a quad min over
 //     (t, face index).
 // The per-ray stack is shared by the quad: LDS [depth][16 rays], spill to HBM beyond LT_STACK4_LDS.
-// Results do not depend on the traversal order (min over (t, face)), so this kernel is bit-identical to
-// k_trace and to the brute-force oracle.
+//
+// What bounds the kernel is the LONGEST walk, not the sum of the walks: a step is a dependent chain of ~0.9 us
+// (node line from L2 / Infinity Cache + ~100 dependent VALU / DPP / LDS instructions), the mean ray needs 30 steps
+// and the worst one 148 -- per-wave wall-clock stamps (tools/wave_times.py --quad) showed 99 % of the waves gone
+// after 71 us of a 123 us launch, the chip 25 % busy over the span.  Two measures (C2: 125 -> 68 + 19 us):
+//   * ONE loop whose trips are node OR leaf steps, so that a wave needs max-over-quads trips (the nested form made
+//     a quad at a leaf wait for every other quad's run of node steps: 110 trips for the slowest wave although no
+//     quad took more than 48 steps);
+//   * hand-over: a ray that is not done after `step_cap` steps (LT_TRACE4_STEP_CAP = 40: 6 % of the rays on C2) parks
+//     its state -- its stack plus the reference it was about to visit, best (t, face) -- in a queue, compacted
+//     across the wave with one ballot-counted atomic per wave, and k_trace4_tail walks each such ray with a WHOLE
+//     WAVE: the 16 quads pop 16 stack entries at a time and share best (t, face) through an LDS atomic, so the
+//     remaining ~100 dependent steps of the worst ray become ~10.
+// Results do not depend on the traversal order (min over (t, face), children are culled only when their entry
+// distance exceeds the best t), so both kernels are bit-identical to k_trace and to the brute-force oracle.
 // =====================================================================================================
 #define LT_Q_BCAST(k) ((k) | ((k) << 2) | ((k) << 4) | ((k) << 6))
 #define LT_Q_XOR1 0xB1  // quad_perm [1,0,3,2]
@@ -231,16 +244,111 @@ __device__ __forceinline__ float qperm_f(float v) {
 #define LT_TILE4_H 2
 #define LT_TILE4_W 8
 
+// hit write-back of one ray (RayTracer.cpp:73-90); misses are written only with LT_TRACE_WRITE_MISSES
+__device__ __forceinline__ void trace_writeback(size_t ray, float best_t, int best_face, float ox, float oy, float oz,
+                                                float dx, float dy, float dz, const int* __restrict__ faces,
+                                                const int* __restrict__ colors, const float* __restrict__ rem,
+                                                float* __restrict__ endpoints, int* __restrict__ endcolors,
+                                                float* __restrict__ range, float* __restrict__ endrem,
+                                                int* __restrict__ tri_out, unsigned flags) {
+  if (best_face != 0x7fffffff) {
+    const int i0 = faces[3 * (size_t)best_face], i1 = faces[3 * (size_t)best_face + 1],
+              i2 = faces[3 * (size_t)best_face + 2];
+    if (endpoints) {
+      endpoints[3 * ray] = ox + dx * best_t;
+      endpoints[3 * ray + 1] = oy + dy * best_t;
+      endpoints[3 * ray + 2] = oz + dz * best_t;
+    }
+    if (endcolors) {
+      if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
+        endcolors[ray] = (int)(float)colors[3 * (size_t)i0 + 2];
+      } else {
+        endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
+        endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
+        endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
+      }
+    }
+    if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
+    if (range) range[ray] = best_t;
+    if (tri_out) tri_out[ray] = best_face;
+  } else if (flags & LT_TRACE_WRITE_MISSES) {
+    if (endpoints) { endpoints[3 * ray] = 0.f; endpoints[3 * ray + 1] = 0.f; endpoints[3 * ray + 2] = 0.f; }
+    if (endcolors) {
+      if (flags & LT_TRACE_LABEL_IMAGE) endcolors[ray] = 0;
+      else { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
+    }
+    if (endrem) endrem[ray] = 0.f;
+    if (range) range[ray] = 0.f;
+    if (tri_out) tri_out[ray] = -1;
+  }
+}
+
+// Moller-Trumbore with the reference's operation order (Triangle.h:27-50) on a sorted triangle record; returns t
+// (INFINITY = no hit) and the face index
+__device__ __forceinline__ float trace_tri(const float4* __restrict__ T, float ox, float oy, float oz, float dx, float dy,
+                                           float dz, int& face) {
+  const float eps = 0.000001f;
+  const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+  const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+  const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
+  const float aa = (e1x * hx + e1y * hy) + e1z * hz;
+  face = 0x7fffffff;
+  if (aa < eps && aa > -eps) return INFINITY;
+  const float inv_a = lt_rcp_ieee(aa);  // = 1.0f / aa, bit for bit (lt_internal.h)
+  const float sx = ox - t0.x, sy = oy - t0.y, sz = oz - t0.z;
+  const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
+  if (u < 0 || u > 1) return INFINITY;
+  const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+  const float v = ((dx * qx + dy * qy) + dz * qz) * inv_a;
+  if (v < 0 || u + v > 1) return INFINITY;
+  const float tt = ((e2x * qx + e2y * qy) + e2z * qz) * inv_a;
+  if (tt < eps || !(tt == tt)) return INFINITY;  // NaN t is never recorded by the reference either (BVH.cpp:59)
+  face = __float_as_int(t2.y);
+  return tt;
+}
+
+// slab test of child j of a 4-wide node against the ray; hit iff the child exists and tn <= min(tfar, best_t)
+__device__ __forceinline__ int trace_slab(const float4 a, const float4 b, float ox, float oy, float oz, float ix,
+                                          float iy, float iz, float best_t, float& tn, int& ref) {
+  const float l1x = (a.x - ox) * ix, l2x = (a.w - ox) * ix;
+  const float l1y = (a.y - oy) * iy, l2y = (b.x - oy) * iy;
+  const float l1z = (a.z - oz) * iz, l2z = (b.y - oz) * iz;
+  tn = fmaxf(fmaxf(fminf(l1x, l2x), fminf(l1y, l2y)), fmaxf(fminf(l1z, l2z), 0.0f));
+  const float tf = fminf(fminf(fmaxf(l1x, l2x), fmaxf(l1y, l2y)), fminf(fmaxf(l1z, l2z), best_t));
+  ref = __float_as_int(b.z);
+  // an unused child slot (box +inf, ref 0x7fffffff) fails the slab test of every finite ray, but fminf /
+  // fmaxf drop NaN operands, so a ray or origin with a NaN would "hit" it: exclude it explicitly
+  return (tn <= tf && ref != 0x7fffffff) ? 1 : 0;
+}
+
+// ray of cell (h, w): direction normalised like Vector3.h:73-89
+__device__ __forceinline__ void trace_ray_dir(const float* __restrict__ rays, size_t ray, unsigned flags, float& dx,
+                                              float& dy, float& dz) {
+  const float rx = rays[3 * ray], ry = rays[3 * ray + 1], rz = rays[3 * ray + 2];
+  const float D = (rx * rx + ry * ry) + rz * rz;
+  const float r0 = lt_rsqrt_seed(D, flags);
+  const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
+  dx = rx * r; dy = ry * r; dz = rz * r;
+}
+
+struct tail_args {  // hand-over area of a launch (lt_internal.h: lt_scene::tail_*)
+  int* stack; float4* meta; int* queue;
+  int* count;       // rays parked by this launch (starts at 0)
+  int* count_next;  // the counter of the scene's NEXT launch: k_trace4_tail zeroes it (no memset between launches)
+};
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace4(
     const float4* __restrict__ nodes4, const float4* __restrict__ tris, const float* __restrict__ rays, float ox,
     float oy, float oz, int H, int W, int n_faces, const int* __restrict__ faces, const int* __restrict__ colors,
     const float* __restrict__ rem, float* __restrict__ endpoints, int* __restrict__ endcolors,
     float* __restrict__ range, float* __restrict__ endrem, int* __restrict__ tri_out, unsigned flags,
-    int* __restrict__ overflow, unsigned long long* __restrict__ counters) {
+    int* __restrict__ overflow, unsigned long long* __restrict__ counters, int step_cap, tail_args tail) {
   __shared__ int stack[4][LT_STACK4_LDS][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 3, q = lane >> 2;
+  const bool dbg_times = COUNT || (flags & LT_TRACE_DEBUG_TIMES);
+  const unsigned long long t_start = dbg_times ? (unsigned long long)wall_clock64() : 0ull;  // 100 MHz
   const int nb = gridDim.x;
   const int lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);  // XCD x owns the x-th azimuth sector
   const int tiles_h = (H + LT_TILE4_H - 1) / LT_TILE4_H, tiles_w = (W + LT_TILE4_W - 1) / LT_TILE4_W;
@@ -251,13 +359,7 @@ __global__ __launch_bounds__(256) void k_trace4(
   const size_t ray = (size_t)h * W + w;
 
   float dx = 0.f, dy = 0.f, dz = 1.f;
-  if (active) {
-    const float rx = rays[3 * ray], ry = rays[3 * ray + 1], rz = rays[3 * ray + 2];
-    const float D = (rx * rx + ry * ry) + rz * rz;  // normalize, Vector3.h:73-89
-    const float r0 = lt_rsqrt_seed(D, flags);
-    const float r = (1.5f * r0) + (((D * -0.5f) * r0) * (r0 * r0));
-    dx = rx * r; dy = ry * r; dz = rz * r;
-  }
+  if (active) trace_ray_dir(rays, ray, flags, dx, dy, dz);
   const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
 
   float best_t = 999999999.f;
@@ -268,24 +370,24 @@ __global__ __launch_bounds__(256) void k_trace4(
   const bool finite_ray = (dx == dx) && (dy == dy) && (dz == dz) && (ox == ox) && (oy == oy) && (oz == oz);
   int cur = (active && n_faces > 0 && finite_ray) ? 0 : LT_DONE;
   unsigned n_nodes = 0, n_tris = 0, n_ovf = 0;
-  const float eps = 0.000001f;
+  int n_steps = 0;          // node + leaf steps of this quad's ray
+  bool handed_over = false;  // the ray goes on in k_trace4_tail
   int* spill = overflow + ray * (LT_STACK4_MAX - LT_STACK4_LDS);
 
-  while (true) {
-    // ---- descend through 4-wide nodes (cur, sp, best_* are uniform within a quad) -----------------------
-    while (cur >= 0) {
+  // ONE loop whose trips are steps of either kind ("if-if" traversal): a wave needs max-over-its-quads trips.  The
+  // nested form (inner loop over nodes, leaf step outside) makes a quad that has reached a leaf wait for every other
+  // quad's run of node steps and the other way round: measured 110 trips for the slowest wave although no quad took
+  // more than 48 steps.  (cur, sp, best_*, n_steps are uniform within a quad.)
+  while (cur != LT_DONE && n_steps < step_cap) {
+    ++n_steps;
+    if (cur >= 0) {
+      // ---- node step: lane j tests child j ---------------------------------------------------------------
       const float4* N = nodes4 + 8 * (size_t)cur + 2 * j;
       const float4 a = N[0], b = N[1];
       if (COUNT && j == 0) ++n_nodes;
-      const float l1x = (a.x - ox) * ix, l2x = (a.w - ox) * ix;
-      const float l1y = (a.y - oy) * iy, l2y = (b.x - oy) * iy;
-      const float l1z = (a.z - oz) * iz, l2z = (b.y - oz) * iz;
-      const float tn = fmaxf(fmaxf(fminf(l1x, l2x), fminf(l1y, l2y)), fmaxf(fminf(l1z, l2z), 0.0f));
-      const float tf = fminf(fminf(fmaxf(l1x, l2x), fmaxf(l1y, l2y)), fminf(fmaxf(l1z, l2z), best_t));
-      const int ref = __float_as_int(b.z);
-      // an unused child slot (box +inf, ref 0x7fffffff) fails the slab test of every finite ray, but fminf /
-      // fmaxf drop NaN operands, so a ray or origin with a NaN would "hit" it: exclude it explicitly
-      const int hit = (tn <= tf && ref != 0x7fffffff) ? 1 : 0;
+      float tn;
+      int ref;
+      const int hit = trace_slab(a, b, ox, oy, oz, ix, iy, iz, best_t, tn, ref);
       // rank of this child among the hit children of the quad (by tn, then lane)
       const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
       const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);
@@ -318,37 +420,15 @@ __global__ __launch_bounds__(256) void k_trace4(
         sp += nh - 1;
         cur = nxt;
       }
-    }
-    if (cur == LT_DONE) break;
-    // ---- leaf: one triangle per lane (Triangle.h:27-50 operation order) ---------------------------------
-    {
+    } else {
+      // ---- leaf step: one triangle per lane (Triangle.h:27-50 operation order) ----------------------------------
       const int lref = ~cur;
       const int start = lref & 0x0fffffff, cnt = (lref >> 28) + 1;
       float t = INFINITY;
       int f = 0x7fffffff;
       if (j < cnt) {
-        const float4* T = tris + 3 * (size_t)(start + j);
-        const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+        t = trace_tri(tris + 3 * (size_t)(start + j), ox, oy, oz, dx, dy, dz, f);
         if (COUNT) ++n_tris;
-        const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
-        const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
-        const float aa = (e1x * hx + e1y * hy) + e1z * hz;
-        if (!(aa < eps && aa > -eps)) {
-          const float inv_a = lt_rcp_ieee(aa);  // = 1.0f / aa, bit for bit (lt_internal.h)
-          const float sx = ox - t0.x, sy = oy - t0.y, sz = oz - t0.z;
-          const float u = ((sx * hx + sy * hy) + sz * hz) * inv_a;
-          if (!(u < 0 || u > 1)) {
-            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
-            const float v = ((dx * qx + dy * qy) + dz * qz) * inv_a;
-            if (!(v < 0 || u + v > 1)) {
-              const float tt = ((e2x * qx + e2y * qy) + e2z * qz) * inv_a;
-              if (!(tt < eps) && tt == tt) {  // NaN t is never recorded by the reference either (BVH.cpp:59)
-                t = tt;
-                f = __float_as_int(t2.y);
-              }
-            }
-          }
-        }
       }
       // quad min over (t, face)
       {
@@ -365,48 +445,43 @@ __global__ __launch_bounds__(256) void k_trace4(
         best_t = t;
         best_face = f;
       }
+      if (sp > 0) {
+        --sp;
+        cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
+      } else {
+        cur = LT_DONE;
+      }
     }
-    if (sp > 0) {
-      --sp;
-      cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
-    } else {
-      cur = LT_DONE;
+  }
+  handed_over = cur != LT_DONE;  // left by the step cap: cur is the node / leaf reference still to be visited
+
+  // ---- hand-over of the rays that hit the step cap: compaction across the wave (one atomic per wave) ---------
+  {
+    const unsigned long long m = __ballot(handed_over && j == 0);
+    if (m) {  // wave-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(tail.count, __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (handed_over) {
+        const int slot = base + __popcll(m & ((1ull << (lane & ~3)) - 1ull));  // rank of this quad among the parked ones
+        int* dst = tail.stack + (size_t)slot * LT_TAIL_SAVE;
+        for (int i = j; i < sp; i += 4) dst[i] = i < LT_STACK4_LDS ? stack[wave][i][q] : spill[i - LT_STACK4_LDS];
+        if (j == 0) {
+          dst[sp] = cur;  // the reference it was about to visit goes on top
+          tail.meta[slot] = make_float4(best_t, __int_as_float(best_face), __int_as_float(sp + 1), 0.f);
+          tail.queue[slot] = (int)ray;
+        }
+      }
     }
   }
 
   // ---- write-back by lane 0 of the quad (RayTracer.cpp:73-90) ----------------------------------------------
   const bool hit = best_face != 0x7fffffff;
-  if (active && j == 0) {
-    if (hit) {
-      const int i0 = faces[3 * (size_t)best_face], i1 = faces[3 * (size_t)best_face + 1],
-                i2 = faces[3 * (size_t)best_face + 2];
-      if (endpoints) {
-        endpoints[3 * ray] = ox + dx * best_t;
-        endpoints[3 * ray + 1] = oy + dy * best_t;
-        endpoints[3 * ray + 2] = oz + dz * best_t;
-      }
-      if (endcolors) {
-        if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
-          endcolors[ray] = (int)(float)colors[3 * (size_t)i0 + 2];
-        } else {
-          endcolors[3 * ray] = (int)(float)colors[3 * (size_t)i0];
-          endcolors[3 * ray + 1] = (int)(float)colors[3 * (size_t)i0 + 1];
-          endcolors[3 * ray + 2] = (int)(float)colors[3 * (size_t)i0 + 2];
-        }
-      }
-      if (endrem) endrem[ray] = ((rem[i0] + rem[i1]) + rem[i2]) / 3.0f;
-      if (range) range[ray] = best_t;
-      if (tri_out) tri_out[ray] = best_face;
-    } else if (flags & LT_TRACE_WRITE_MISSES) {
-      if (endpoints) { endpoints[3 * ray] = 0.f; endpoints[3 * ray + 1] = 0.f; endpoints[3 * ray + 2] = 0.f; }
-      if (endcolors) {
-        if (flags & LT_TRACE_LABEL_IMAGE) endcolors[ray] = 0;
-        else { endcolors[3 * ray] = 0; endcolors[3 * ray + 1] = 0; endcolors[3 * ray + 2] = 0; }
-      }
-      if (endrem) endrem[ray] = 0.f;
-      if (range) range[ray] = 0.f;
-      if (tri_out) tri_out[ray] = -1;
-    }
+  if ((flags & LT_TRACE_DEBUG_STEPS) && tri_out) {  // debug: steps per ray instead of the face (cap off)
+    if (active && j == 0) tri_out[ray] = n_steps;
+  } else if (active && j == 0 && !handed_over) {
+    trace_writeback(ray, best_t, best_face, ox, oy, oz, dx, dy, dz, faces, colors, rem, endpoints, endcolors, range,
+                    endrem, tri_out, flags);
   }
   if (COUNT) {
     unsigned long long vn = n_nodes, vt = n_tris, vh = (active && hit && j == 0) ? 1u : 0u, vo = n_ovf;
@@ -423,6 +498,94 @@ __global__ __launch_bounds__(256) void k_trace4(
       atomicAdd(&counters[2], vh);
       atomicAdd(&counters[3], vo);
     }
+  }
+  if (dbg_times && lane == 0) {  // debug (tools/wave_times.py --quad): start / duration at 100 MHz, steps of quad 0
+    const int wg = blockIdx.x * 4 + wave;
+    if (wg < LT_DBG_WAVES) {
+      counters[8 + 2 * wg] = t_start;
+      counters[8 + 2 * wg + 1] = ((unsigned long long)wall_clock64() - t_start) | ((unsigned long long)n_steps << 32);
+    }
+  }
+}
+
+// One WAVE per handed-over ray: the 16 quads pop up to 16 entries of the ray's stack at a time (LT_TAIL_DFS: one at a
+// time while the stack is very full), every quad visits its node (lane j tests child j against the shared best t) or
+// its leaf (lane j tests triangle j; quad minimum into the shared best (t, face) with one 64-bit LDS atomic), the hit
+// children of all quads are pushed with a wave prefix sum.  Workgroup = one wave, so __syncthreads() is a wave barrier.
+__global__ __launch_bounds__(64) void k_trace4_tail(
+    const float4* __restrict__ nodes4, const float4* __restrict__ tris, const float* __restrict__ rays, float ox,
+    float oy, float oz, const int* __restrict__ faces, const int* __restrict__ colors, const float* __restrict__ rem,
+    float* __restrict__ endpoints, int* __restrict__ endcolors, float* __restrict__ range, float* __restrict__ endrem,
+    int* __restrict__ tri_out, unsigned flags, tail_args tail) {
+  __shared__ int stk[LT_TAIL_STACK];
+  __shared__ unsigned long long best;  // (t bits) << 32 | face: for t > 0 the integer order is the order of (t, face)
+  const int lane = threadIdx.x, j = lane & 3, q = lane >> 2;
+  const int n_tail = *tail.count;
+  if (blockIdx.x == 0 && lane == 0) *tail.count_next = 0;
+  for (int it = blockIdx.x; it < n_tail; it += gridDim.x) {
+    const size_t ray = (size_t)tail.queue[it];
+    const float4 meta = tail.meta[it];
+    int sp = __float_as_int(meta.z);
+    const int* src = tail.stack + (size_t)it * LT_TAIL_SAVE;
+    for (int i = lane; i < sp; i += 64) stk[i] = src[i];
+    if (lane == 0) best = ((unsigned long long)__float_as_uint(meta.x) << 32) | (unsigned)__float_as_int(meta.y);
+    float dx, dy, dz;
+    trace_ray_dir(rays, ray, flags, dx, dy, dz);
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    __syncthreads();
+    while (sp > 0) {  // sp is wave-uniform
+      const int take = sp > LT_TAIL_DFS ? 1 : min(sp, 16);
+      const int ref_in = q < take ? stk[sp - 1 - q] : LT_DONE;  // quad 0 takes the top = the nearest deferred child
+      const float best_t = __uint_as_float((unsigned)(best >> 32));
+      __syncthreads();  // every quad has read its entry and the best t before anything is pushed / improved
+      sp -= take;
+      int hit = 0, ref = 0;
+      float tn = 0.f;
+      if (ref_in >= 0) {  // node: lane j tests child j
+        const float4* N = nodes4 + 8 * (size_t)ref_in + 2 * j;
+        hit = trace_slab(N[0], N[1], ox, oy, oz, ix, iy, iz, best_t, tn, ref);
+      } else if (ref_in != LT_DONE) {  // leaf: lane j tests triangle j
+        const int lref = ~ref_in;
+        const int start = lref & 0x0fffffff, cnt = (lref >> 28) + 1;
+        float t = INFINITY;
+        int f = 0x7fffffff;
+        if (j < cnt) t = trace_tri(tris + 3 * (size_t)(start + j), ox, oy, oz, dx, dy, dz, f);
+        {
+          const float ot = qperm_f<LT_Q_XOR1>(t);
+          const int of = qperm_i<LT_Q_XOR1>(f);
+          if (ot < t || (ot == t && of < f)) { t = ot; f = of; }
+        }
+        {
+          const float ot = qperm_f<LT_Q_XOR2>(t);
+          const int of = qperm_i<LT_Q_XOR2>(f);
+          if (ot < t || (ot == t && of < f)) { t = ot; f = of; }
+        }
+        if (j == 0 && f != 0x7fffffff && t < 999999999.f)
+          atomicMin(&best, ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)f);
+      }
+      // push the hit children of all quads: far ones first inside a quad (the nearer child is popped first); the
+      // quads are stacked in reverse order so that quad 0's children -- the subtree of the old top -- end on top
+      const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
+      const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);
+      const int h0 = qperm_i<LT_Q_BCAST(0)>(hit), h1 = qperm_i<LT_Q_BCAST(1)>(hit);
+      const int h2 = qperm_i<LT_Q_BCAST(2)>(hit), h3 = qperm_i<LT_Q_BCAST(3)>(hit);
+      const int nh = h0 + h1 + h2 + h3;
+      const int rank = (h0 & ((t0 < tn) | ((t0 == tn) & (0 < j)))) + (h1 & ((t1 < tn) | ((t1 == tn) & (1 < j)))) +
+                       (h2 & ((t2 < tn) | ((t2 == tn) & (2 < j)))) + (h3 & ((t3 < tn) | ((t3 == tn) & (3 < j))));
+      // exclusive prefix of nh over the quads ABOVE this one (quads q+1 .. 15), via the hit ballot
+      const unsigned long long hm = __ballot(hit != 0);
+      const int above = q == 15 ? 0 : __popcll(hm >> ((q + 1) * 4));
+      const int total = __popcll(hm);
+      if (hit) stk[sp + above + (nh - 1 - rank)] = ref;
+      sp += total;
+      __syncthreads();
+    }
+    if (lane == 0) {
+      const unsigned long long k = best;
+      trace_writeback(ray, __uint_as_float((unsigned)(k >> 32)), (int)(unsigned)(k & 0xFFFFFFFFull), ox, oy, oz, dx, dy,
+                      dz, faces, colors, rem, endpoints, endcolors, range, endrem, tri_out, flags);
+    }
+    __syncthreads();
   }
 }
 
@@ -472,15 +635,30 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
       const int tiles = ((H + LT_TILE4_H - 1) / LT_TILE4_H) * ((W + LT_TILE4_W - 1) / LT_TILE4_W);
       int nblocks = (tiles + 3) / 4;
       nblocks = (nblocks + 7) & ~7;
-      if (count)
+      // two hand-over counters used alternately: the tail kernel of a launch re-arms the other one
+      const bool with_tail = !count && !(flags & LT_TRACE_DEBUG_STEPS);
+      const tail_args tail = {s->tail_stack, s->tail_meta, s->tail_queue, s->tail_count + (s->tail_parity & 1),
+                              s->tail_count + ((s->tail_parity & 1) ^ 1)};
+      if (with_tail) s->tail_parity ^= 1;
+      static const int env_cap = []() {
+        const char* e = getenv("LIDARHIP_STEP_CAP");
+        return e ? atoi(e) : LT_TRACE4_STEP_CAP;
+      }();
+      // counting and the per-ray step image measure the undisturbed walk: no hand-over there
+      const int step_cap = (!with_tail || env_cap <= 0) ? 0x7fffffff : env_cap;
+      if (count) {
         hipLaunchKernelGGL(k_trace4<true>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays, origin[0],
                            origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem, endpoints,
-                           endcolors, range, endrem, tri, flags, s->overflow, s->counters);
-      else {
+                           endcolors, range, endrem, tri, flags, s->overflow, s->counters, step_cap, tail);
+      } else {
         if (s->probe[0]) LT_HIP(hipEventRecord(s->probe[0], stream));
         hipLaunchKernelGGL(k_trace4<false>, dim3(nblocks), dim3(256), 0, stream, s->nodes4, s->tris, rays,
                            origin[0], origin[1], origin[2], H, W, s->n_faces, s->faces, s->colors, s->rem,
-                           endpoints, endcolors, range, endrem, tri, flags, s->overflow, s->counters);
+                           endpoints, endcolors, range, endrem, tri, flags, s->overflow, s->counters, step_cap, tail);
+        // (launched even when the cap is off: it re-arms the counter and finds an empty queue)
+        hipLaunchKernelGGL(k_trace4_tail, dim3(4096), dim3(64), 0, stream, s->nodes4, s->tris, rays, origin[0],
+                             origin[1], origin[2], s->faces, s->colors, s->rem, endpoints, endcolors, range, endrem,
+                             tri, flags, tail);
         if (s->probe[1]) LT_HIP(hipEventRecord(s->probe[1], stream));
         s->probe[0] = s->probe[1] = nullptr;
       }

@@ -29,3 +29,39 @@ print("duration: mean %d p50 %d p90 %d p99 %d max %d" % (dur.mean(), np.percenti
 print("end: p50 %d p90 %d p99 %d max %d" % (np.percentile(end, 50), np.percentile(end, 90), np.percentile(end, 99), end.max()))
 order = np.argsort(-dur)[:8]
 print("slowest waves (wave id, start, dur):", [(int(i), int(start[i]), int(dur[i])) for i in order])
+
+# ---- quad traversal: production kernel with the internal timing flag (wall clock at 100 MHz per wave)
+if "--quad" in sys.argv:
+    nw = 8192
+    org = (C.c_float * 3)(0, 0, 0)
+    R = wl["H"] * wl["W"]
+
+    def run(flags):
+        assert lib.lt_scene_trace_dev(sc._h, rays.data_ptr(), org, R, wl["H"], out["endpoints"].data_ptr(),
+                                      out["endcolors"].data_ptr(), out["range"].data_ptr(), out["endrem"].data_ptr(),
+                                      out["tri"].data_ptr(), flags, None, None) == 0
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        run(1 | 0x8000)
+    buf = np.zeros(2 * nw, np.uint64)
+    assert lib.lt_debug_wave_times(sc._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
+    t = buf.reshape(nw, 2)
+    start = (t[:, 0] - t[:, 0].min()).astype(np.int64) / 100.0            # us
+    dur = (t[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64) / 100.0        # us
+    end = start + dur
+    print("k_trace4 (step cap %s): waves %d, span of the main kernel %.1f us" % (os.environ.get("LIDARHIP_STEP_CAP", "default"), nw, end.max()))
+    for name, a in (("start", start), ("duration", dur), ("end", end)):
+        print("  %-16s mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f max %8.1f" % (name, a.mean(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max()))
+    print("  busy fraction of the chip over the span: %.3f" % (dur.sum() / (nw * end.max())))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(20):
+        e0.record(); run(1); e1.record(); torch.cuda.synchronize(); ms.append(e0.elapsed_time(e1))
+    print("  trace (main + tail kernel), events around the call: median %.1f us" % (np.median(ms) * 1e3))
+    # steps per ray (internal flag 0x4000, no cap): where do the long walks live?
+    run(1 | 0x4000)
+    steps = out["tri"].cpu().numpy().reshape(wl["H"], wl["W"])
+    print("  steps per ray (node + leaf): mean %.1f p50 %d p90 %d p98 %d p99 %d p99.9 %d max %d" % (steps.mean(), *[np.percentile(steps, p) for p in (50, 90, 98, 99, 99.9)], steps.max()))
+    for cap in (32, 40, 48, 64):
+        print("    rays beyond %d steps: %.2f %%" % (cap, 100.0 * (steps > cap).mean()))
