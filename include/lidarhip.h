@@ -271,6 +271,8 @@ typedef struct lt_tsdf lt_tsdf; /* opaque: four float32 volumes [dim_x][dim_y][d
  * tsdf = 1, weight = colour = remission = 0. */
 int lt_tsdf_create(lt_tsdf** vol, const double* vol_bnds, double voxel_size, double fov_up, double fov_down,
                    int device);
+/* Back to the initial state (the reference builds a new TSDFVolume per output scan, laserscan.py:886-887); only the
+ * voxel columns written since the last reset are re-initialised. */
 int lt_tsdf_reset(lt_tsdf* vol, void* stream);
 /* Integrate one spherical observation: color_im = labels folded into one float per pixel as
  * fusion_lidar.py:262-264, depth_im, rem_im -- DEVICE pointers [im_h * im_w] f32.  Replaces the pycuda kernel
@@ -280,6 +282,9 @@ int lt_tsdf_integrate_dev(lt_tsdf* vol, const float* color_im, const float* dept
 /* Device pointers of the volumes (TSDFVolume.get_volume, fusion_lidar.py:395-400, without the copies). */
 int lt_tsdf_volumes(lt_tsdf* vol, int* dims, float* origin, float** tsdf, float** weight, float** color,
                     float** rem);
+/* Tell the volume that its fields were modified through the pointers above (the library tracks which (x, y) columns
+ * its own integrate calls wrote, so that reset and marching cubes skip the untouched ones). */
+int lt_tsdf_touch(lt_tsdf* vol);
 int lt_tsdf_destroy(lt_tsdf* vol);
 
 /* ---- between fusion and render: marching cubes on the device, the mesh is born in HBM -------------------------- */

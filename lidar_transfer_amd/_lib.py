@@ -27,7 +27,7 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection", "lt_rayset_create_dev",
            "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_render_batch_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
            "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
-           "lt_tsdf_volumes", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
+           "lt_tsdf_volumes", "lt_tsdf_touch", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
            "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free"]
 
@@ -114,7 +114,9 @@ def load():
     lib.lt_tsdf_integrate_dev.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint, vp]
     lib.lt_tsdf_volumes.argtypes = [vp, ip, fp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.lt_tsdf_destroy.argtypes = [vp]
-    for name in ("lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev", "lt_tsdf_volumes", "lt_tsdf_destroy"):
+    lib.lt_tsdf_touch.argtypes = [vp]
+    for name in ("lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev", "lt_tsdf_volumes", "lt_tsdf_destroy",
+                 "lt_tsdf_touch"):
         getattr(lib, name).restype = C.c_int
     lib.lt_mesh_create.argtypes = [C.POINTER(vp), C.c_int]
     lib.lt_mesh_destroy.argtypes = [vp]

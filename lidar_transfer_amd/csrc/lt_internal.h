@@ -108,6 +108,15 @@ struct lt_tsdf {
   double fov_up_deg, fov_down_deg;
   size_t n;
   float *tsdf, *weight, *color, *rem;
+  // sparse bookkeeping (lt_tsdf.hip): an (x, y) COLUMN of dim_z voxels is "dirty" when an integrate since the last
+  // reset wrote into it -- col_epoch[c] == epoch.  Reset re-initialises dirty columns only and then bumps `epoch`
+  // (nothing is cleared); marching cubes skips clean columns (their tsdf is the initial 1 everywhere).
+  unsigned* col_epoch;  // [dim_x * dim_y]
+  unsigned epoch;
+  int all_dirty;        // an integrate without stamps ran (LIDARHIP_TSDF=dense): every column counts as written
+  int* colinfo;         // [dim_x * dim_y] per integrate call: image column px of the voxel column, or -1 = dead
+  float* colmax;        // [cap_w] per integrate call: largest depth of every image column
+  int cap_w;
 };
 
 #define LT_BOUNDS_BLOCKS 256

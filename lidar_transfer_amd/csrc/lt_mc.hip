@@ -14,7 +14,7 @@
 //   k_mc_words    one thread per 64-voxel word: crossing-edge masks ex / ey / ez of the edges its voxels own
 //                 (m ^ neighbour word, shifted for z), active-cell mask (the 8 corner words are not all equal), number
 //                 of vertices (popcounts) and triangles (case table, only on the set bits); per-workgroup totals
-//   k_mc_scan     exclusive scan of the workgroup totals (one workgroup) -> V, F
+//   k_mc_scan1/2  exclusive scan of the workgroup totals in two levels -> V, F
 //   k_mc_compact  word -> compact index of the active words (the ~2 % that own a vertex or a triangle); per active
 //                 word a record {word, vertex base, triangle base, ex, ey, ez}
 //   k_mc_emit     one WAVE per active word, one lane per voxel: the lane's up to three vertices (position by
@@ -60,27 +60,41 @@ struct lt_mesh {
 };
 
 // ---- k_mc_signs ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mc_signs(const float* __restrict__ tsdf, mc_dims D, u64* __restrict__ bits) {
+// col_epoch / epoch (may be NULL): stamps of the (x, y) columns written since the volume's last reset (lt_tsdf.hip) --
+// a clean column still holds the initial tsdf = 1 everywhere, its sign bits are 0 without reading it.  A wave takes 64
+// rows (= columns of the volume) at a time: lane r zeroes the words of row r when that row is clean; the dirty rows
+// are then walked one by one, z along the lanes, four words (loads) in flight.
+__global__ __launch_bounds__(256) void k_mc_signs(const float* __restrict__ tsdf, mc_dims D, u64* __restrict__ bits,
+                                                  const unsigned* __restrict__ col_epoch, unsigned epoch) {
   const int lane = threadIdx.x & 63;
-  const int n_waves = gridDim.x * 4;
-  // four words per wave and iteration: four independent loads in flight (a pure HBM stream)
-  for (int w0 = blockIdx.x * 4 + (threadIdx.x >> 6); w0 < D.n_words; w0 += 4 * n_waves) {
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = w0 + k * n_waves;
-      v[k] = 1.0f;
-      if (w < D.n_words) {
-        const int row = w / D.wz, wz = w - row * D.wz;
-        const int z = wz * 64 + lane;
-        if (z < D.nz) v[k] = tsdf[(size_t)row * D.nz + z];
-      }
+  const int n_rows = D.nx * D.ny;
+  const int n_chunks = (n_rows + 63) / 64;
+  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    const int row = chunk * 64 + lane;
+    bool dirty = false;
+    if (row < n_rows) {
+      dirty = !col_epoch || col_epoch[row] == epoch;
+      if (!dirty)
+        for (int k = 0; k < D.wz; ++k) bits[(size_t)row * D.wz + k] = 0ull;
     }
+    u64 m = __ballot(dirty);
+    while (m) {
+      const int r = chunk * 64 + (__ffsll((long long)m) - 1);
+      m &= m - 1;
+      const float* src = tsdf + (size_t)r * D.nz;
+      for (int k0 = 0; k0 < D.wz; k0 += 4) {
+        float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = w0 + k * n_waves;
-      const u64 m = __ballot(v[k] < 0.0f);  // level 0; NaN is "not inside"
-      if (lane == 0 && w < D.n_words) bits[w] = m;
+        for (int k = 0; k < 4; ++k) {
+          const int z = (k0 + k) * 64 + lane;
+          v[k] = z < D.nz ? src[z] : 1.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u64 w = __ballot(v[k] < 0.0f);  // level 0; NaN is "not inside"
+          if (lane == 0 && k0 + k < D.wz) bits[(size_t)r * D.wz + k0 + k] = w;
+        }
+      }
     }
   }
 }
@@ -174,18 +188,42 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
   }
 }
 
-// ---- k_mc_scan: exclusive scan of the per-workgroup totals, in place; totals[0..2] = grand totals --------------------
-__global__ __launch_bounds__(1024) void k_mc_scan(int* __restrict__ blk, int n_blocks, int* __restrict__ totals) {
+// ---- k_mc_scan1 / k_mc_scan2: exclusive scan of the per-workgroup totals in two levels -------------------------------
+// level 1: workgroup g scans its segment of 256 totals in place (coalesced) and leaves the segment's sums in seg[3g..];
+// level 2: one workgroup scans the (<= 1024) segment sums in place and writes the grand totals.  k_mc_compact adds
+// seg[3 * (block / 256) + k] to the block's in-segment prefix.  (A single workgroup walking all 62 500 totals of the
+// default volume took 143 us: one CU's L2 bandwidth.)
+__global__ __launch_bounds__(256) void k_mc_scan1(int* __restrict__ blk, int n_blocks, int* __restrict__ seg) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  unsigned a = 0, v = 0, t = 0;
+  if (b < n_blocks) { a = (unsigned)blk[3 * b]; v = (unsigned)blk[3 * b + 1]; t = (unsigned)blk[3 * b + 2]; }
+  // (the 20-bit packing of pack3 would overflow here -- 256 x 81 920 triangles: three 64-bit scans)
+  u64 p[3] = {a, v, t}, inc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) inc[k] = wave_incl_scan(p[k]);
+  __shared__ u64 ws[3][4];
+  if ((threadIdx.x & 63) == 63)
+    for (int k = 0; k < 3; ++k) ws[k][threadIdx.x >> 6] = inc[k];
+  __syncthreads();
+  u64 off[3] = {0, 0, 0}, tot[3];
+  for (int k = 0; k < 3; ++k) {
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off[k] += ws[k][w];
+    tot[k] = (ws[k][0] + ws[k][1]) + (ws[k][2] + ws[k][3]);
+  }
+  if (b < n_blocks)
+    for (int k = 0; k < 3; ++k) blk[3 * b + k] = (int)min(off[k] + inc[k] - p[k], (u64)2147483647);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; ++k) seg[3 * blockIdx.x + k] = (int)min(tot[k], (u64)2147483647);
+}
+
+__global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_seg, int* __restrict__ totals) {
   __shared__ long long part[3][1024];
   const int t = threadIdx.x;
-  const int per = (n_blocks + 1023) / 1024;
-  const int b0 = min(t * per, n_blocks), b1 = min(b0 + per, n_blocks);
   long long s[3] = {0, 0, 0};
-  for (int b = b0; b < b1; ++b)
-    for (int k = 0; k < 3; ++k) s[k] += blk[3 * b + k];
+  if (t < n_seg)
+    for (int k = 0; k < 3; ++k) s[k] = seg[3 * t + k];
   for (int k = 0; k < 3; ++k) part[k][t] = s[k];
   __syncthreads();
-  // Hillis-Steele over the 1024 partial sums
   for (int o = 1; o < 1024; o <<= 1) {
     long long v[3];
     for (int k = 0; k < 3; ++k) v[k] = t >= o ? part[k][t - o] : 0;
@@ -193,14 +231,8 @@ __global__ __launch_bounds__(1024) void k_mc_scan(int* __restrict__ blk, int n_b
     for (int k = 0; k < 3; ++k) part[k][t] += v[k];
     __syncthreads();
   }
-  long long run[3];
-  for (int k = 0; k < 3; ++k) run[k] = part[k][t] - s[k];  // exclusive prefix of this thread's chunk
-  for (int b = b0; b < b1; ++b)
-    for (int k = 0; k < 3; ++k) {
-      const int c = blk[3 * b + k];
-      blk[3 * b + k] = (int)min(run[k], 2147483647ll);
-      run[k] += c;
-    }
+  if (t < n_seg)
+    for (int k = 0; k < 3; ++k) seg[3 * t + k] = (int)min(part[k][t] - s[k], 2147483647ll);
   if (t == 1023)
     for (int k = 0; k < 3; ++k) totals[k] = (int)min(part[k][1023], 2147483647ll);
 }
@@ -208,7 +240,8 @@ __global__ __launch_bounds__(1024) void k_mc_scan(int* __restrict__ blk, int n_b
 // ---- k_mc_compact ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits, mc_dims D,
                                                     const unsigned* __restrict__ cnt, const int* __restrict__ blk,
-                                                    int* __restrict__ cmap, mc_rec* __restrict__ rec, int cap_rec) {
+                                                    const int* __restrict__ seg, int* __restrict__ cmap,
+                                                    mc_rec* __restrict__ rec, int cap_rec) {
   __shared__ u64 wsum[4];
   const int w = blockIdx.x * 256 + threadIdx.x;
   const unsigned c = w < D.n_words ? cnt[w] : 0u;
@@ -223,15 +256,16 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
   if (w >= D.n_words) return;
   int ci = -1;
   if (c) {
-    ci = blk[3 * blockIdx.x] + (int)(ex & 0xFFFFF);
+    const int* sg = seg + 3 * (blockIdx.x >> 8);
+    ci = sg[0] + blk[3 * blockIdx.x] + (int)(ex & 0xFFFFF);
     if (ci < cap_rec) {
       const int row = w / D.wz, wz = w - row * D.wz;
       const int x = row / D.ny, y = row - x * D.ny;
       const mc_masks M = mc_load(bits, D, x, y, wz);
       mc_rec r;
       r.w = w;
-      r.vbase = blk[3 * blockIdx.x + 1] + (int)((ex >> 20) & 0xFFFFF);
-      r.tbase = blk[3 * blockIdx.x + 2] + (int)((ex >> 40) & 0xFFFFF);
+      r.vbase = sg[1] + blk[3 * blockIdx.x + 1] + (int)((ex >> 20) & 0xFFFFF);
+      r.tbase = sg[2] + blk[3 * blockIdx.x + 2] + (int)((ex >> 40) & 0xFFFFF);
       r.pad = 0;
       r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
       rec[ci] = r;
@@ -424,9 +458,9 @@ static int mc_grow(T** p, size_t* cap, size_t need) {
   return LT_OK;
 }
 
-extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
-                                     int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
-                                     float* ms) {
+static int mc_extract(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny, int nz,
+                      float voxel_size, const float* origin, lt_mesh* m, void* stream_, float* ms,
+                      const unsigned* col_epoch, unsigned epoch) {
   if (!tsdf || !color_vol || !rem_vol || !origin || !m || nx <= 0 || ny <= 0 || nz <= 0) {
     lt_set_error("lt_marching_cubes_dev: invalid argument");
     return LT_ERR_INVALID_ARG;
@@ -459,14 +493,21 @@ extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, 
     LT_HIP(hipMalloc((void**)&m->cmap, n_words * sizeof(int)));
     m->cap_words = n_words;
   }
-  LT_CHECK(mc_grow(&m->blk, &m->cap_blocks, (size_t)3 * n_blocks + 4));
-  int* totals_dev = m->blk + 3 * (size_t)n_blocks;
+  const int n_seg = (n_blocks + 255) / 256;
+  if (n_seg > 1024) {
+    lt_set_error("lt_marching_cubes_dev: volume too large (%d words)", D.n_words);
+    return LT_ERR_TOO_LARGE;
+  }
+  LT_CHECK(mc_grow(&m->blk, &m->cap_blocks, (size_t)3 * n_blocks + 3 * (size_t)n_seg + 4));
+  int* seg_dev = m->blk + 3 * (size_t)n_blocks;
+  int* totals_dev = seg_dev + 3 * (size_t)n_seg;
   if (ms) LT_HIP(hipEventRecord(m->ev[0], stream));
-  hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)65536, (n_words + 3) / 4)), dim3(256), 0, stream, tsdf, D,
-                     m->bits);
+  hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
+                     tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
   hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk);
-  hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, stream, m->blk, n_blocks, totals_dev);
+  hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
+  hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
   LT_HIP(hipStreamSynchronize(stream));  // the one synchronisation: the sizes of the mesh
   const int n_active = m->totals_host[0], nv = m->totals_host[1], nf = m->totals_host[2];
@@ -501,7 +542,7 @@ extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, 
     LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }
-  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk, m->cmap, m->rec,
+  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647));
   if (n_active > 0)
     hipLaunchKernelGGL(k_mc_emit, dim3((n_active + 3) / 4), dim3(256), 0, stream, tsdf, color_vol, rem_vol, m->bits, D,
@@ -531,8 +572,15 @@ extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, fl
     lt_set_error("lt_tsdf_extract_mesh_dev: volume on device %d, mesh on device %d", t->device, m->device);
     return LT_ERR_INVALID_ARG;
   }
-  return lt_marching_cubes_dev(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m,
-                               stream, ms);
+  // the volume knows which columns were written since its last reset: the others are not read
+  return mc_extract(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m, stream, ms,
+                    t->all_dirty ? nullptr : t->col_epoch, t->epoch);
+}
+
+extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
+                                     int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
+                                     float* ms) {
+  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u);
 }
 
 extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {

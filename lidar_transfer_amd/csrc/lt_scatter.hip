@@ -314,7 +314,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   const float tol = 1e-6f * rho_max2 + 1e-12f;
   const float cmin = fminf(c0, fminf(c1, c2)), cmax = fmaxf(c0, fmaxf(c1, c2));
   const bool outside = cmin < -tol && cmax > tol;
-  const bool edge_on = cmin >= -tol && cmax <= tol;
+  bool edge_on = cmin >= -tol && cmax <= tol;
   // rho_edges2 = a lower bound of the squared distance from the axis to the triangle's edges.  The closest point
   // of an edge is at most half the edge away from one of its end points, at a right angle when it is interior:
   // d^2 >= min(q) - L^2 / 4 with L the longest edge.  For a triangle small against its distance from the axis
@@ -332,6 +332,11 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   }
   const float rho_edges = f_sqrt(rho_edges2);
   const float rho_tiny = 1e-4f * rho_max + 1e-6f;
+  // A triangle whose edges are all further from the axis than twice its longest edge cannot contain the axis, whatever
+  // the sub-areas say: for a TINY triangle far away (marching cubes emits 40-micrometre triangles where the field is
+  // ~0 at a grid point) they are all of the order of `tol`, neither clearly mixed nor clearly zero -- such triangles
+  // were taken for pierced (every azimuth: 70 000 candidate bins each).  They take the three-azimuth path instead.
+  if (!outside && rho_edges2 > 4.0f * lmax2) edge_on = true;
   const bool pierced = !(outside || (edge_on && rho_edges > rho_tiny));
   const float rho_min = pierced ? 0.f : rho_edges;
   // angular padding: float rounding of atan2 and of the ray bins, plus the positional slop (<= ~1e-4 m) with
@@ -690,6 +695,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   const float ox = J.ox, oy = J.oy, oz = J.oz;
   const rs_params P = J.P;
   const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
+  if (COUNT && rb == 0 && threadIdx.x == 0) J.counters[3] = (unsigned long long)n_large | ((unsigned long long)n_slices << 32);
   unsigned n_tests = 0, n_cand = 0;
   for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
     const int2 sl = J.slices[q];
@@ -1009,7 +1015,11 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
   if (B.n == 0) return LT_OK;
   B.tris_blocks = tb;
   B.resolve_blocks = rb;
-  B.cap = n_items > 1 ? LT_SC_CAP_BATCH : LT_SC_CAP_SINGLE;
+  static const int env_cap = []() {
+    const char* e = getenv("LIDARHIP_SC_CAP");
+    return e ? atoi(e) : 0;
+  }();
+  B.cap = env_cap > 0 ? env_cap : (n_items > 1 ? LT_SC_CAP_BATCH : LT_SC_CAP_SINGLE);
   const dim3 b(256);
 #define SC_LAUNCH(KERNEL, GRID) \
   do { \
@@ -1115,4 +1125,24 @@ extern "C" int lt_scene_render_batch_dev(int n_scans, lt_scene* const* scenes, l
   }
   LT_HIP(hipSetDevice(scenes[0]->device));
   return sc_launch_batch(it, n_scans, flags, stream, false, probe ? probe : scenes[0]);
+}
+
+// debug helpers (not part of the documented ABI): queue lengths of the last LT_TRACE_COUNT render (big triangles,
+// slices), and the face indices of its big-triangle queue
+extern "C" int lt_debug_scatter_queues(lt_scene* s, int* out2) {
+  if (!s || !out2) return LT_ERR_INVALID_ARG;
+  LT_HIP(hipSetDevice(s->device));
+  LT_HIP(hipDeviceSynchronize());
+  unsigned long long c = 0;
+  LT_HIP(hipMemcpy(&c, s->counters + 3, sizeof(c), hipMemcpyDeviceToHost));
+  out2[0] = (int)(c & 0xFFFFFFFFull);
+  out2[1] = (int)(c >> 32);
+  return LT_OK;
+}
+extern "C" int lt_debug_scatter_large(lt_scene* s, int* out, int n) {
+  if (!s || !out || n < 0 || n > s->sc_cap_queue) return LT_ERR_INVALID_ARG;
+  LT_HIP(hipSetDevice(s->device));
+  LT_HIP(hipDeviceSynchronize());
+  LT_HIP(hipMemcpy(out, s->sc_large, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  return LT_OK;
 }

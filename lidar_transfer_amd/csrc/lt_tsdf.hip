@@ -13,8 +13,24 @@
 // nvcc contracts them by default (-fmad=true).  CUDA's norm3df / atan2f / asinf are not available bit for bit
 // on any other platform: voxels whose projection falls within an ulp of a pixel or field-of-view boundary
 // may land differently -- tests bound that fraction.
+//
+// The kernel is the reference's arithmetic, voxel by voxel; what is NOT the reference's is the amount of work spent
+// on voxels that cannot change -- 800 M voxels at the default volume, of which one observation updates a few per cent:
+//   * the image column px of a voxel depends on its (x, y) only: k_tsdf_columns computes it once per COLUMN of
+//     dim_z voxels with the very expressions of the kernel (atan2f and the double-precision proj_x: the costly part),
+//     and marks a column DEAD when even its nearest possible depth sqrt(x^2 + y^2) lies more than the truncation
+//     margin behind the largest depth of that image column -- every voxel of it takes the kernel's
+//     `depth_diff < -trunc_margin` exit (float subtraction, fma and sqrt are monotonic, so the implication is exact);
+//   * a conservative sine test (|margin| 1e-5, far above asinf's error) drops voxels clearly outside the vertical
+//     field of view before asinf; the band around the limits takes the exact path;
+//   * columns written since the last reset are stamped with the volume's epoch: reset re-initialises those only, and
+//     marching cubes (lt_mc.hip) does not read the clean ones.
+// LIDARHIP_TSDF=dense selects the one-thread-per-voxel kernel without any of this (A/B: bit-identical volumes,
+// tests/test_tsdf_gpu.py).
 #include "lt_internal.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #define LT_PI_D 3.14159265358979323846
 
@@ -25,6 +41,48 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
     weight[i] = 0.0f;
     color[i] = 0.0f;
     rem[i] = 0.0f;
+  }
+}
+
+// the update of one voxel (fusion_lidar.py:178-228), shared by the dense and the column-aware kernel
+template <bool MERGE>
+__device__ __forceinline__ void tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
+                                            float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
+                                            float dist, float obs_weight, float new_color, float new_rem) {
+  if (!MERGE) {
+    const float w_old = weight_vol[voxel_idx];
+    const float w_new = w_old + obs_weight;
+    weight_vol[voxel_idx] = w_new;
+    tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+    const float old_color = color_vol[voxel_idx];
+    const float old_b = floorf(old_color / (256 * 256));
+    const float old_g = floorf((old_color - old_b * 256 * 256) / 256);
+    const float old_r = old_color - old_b * 256 * 256 - old_g * 256;
+    float new_b = floorf(new_color / (256 * 256));
+    float new_g = floorf((new_color - new_b * 256 * 256) / 256);
+    float new_r = new_color - new_b * 256 * 256 - new_g * 256;
+    new_b = fminf(roundf(__fmaf_rn(old_b, w_old, new_b) / w_new), 255.0f);
+    new_g = fminf(roundf(__fmaf_rn(old_g, w_old, new_g) / w_new), 255.0f);
+    new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
+    color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
+    rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+  } else {
+    const float dist_old = weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
+    const float old_color = color_vol[voxel_idx];
+    if (old_color == new_color) {  // same class: integrate
+      const float w_old = weight_vol[voxel_idx];
+      const float w_new = w_old + obs_weight;
+      weight_vol[voxel_idx] = w_new;
+      tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+      rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+    } else if (dist < dist_old) {  // other class: the closer observation wins
+      tsdf_vol[voxel_idx] = dist;
+      const float new_b = floorf(new_color / (256 * 256));
+      const float new_g = floorf((new_color - new_b * 256 * 256) / 256);
+      const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
+      color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
+      rem_vol[voxel_idx] = new_rem;
+    }
   }
 }
 
@@ -68,41 +126,161 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(float* __restrict__ tsdf
   const float depth_diff = depth_value - depth;
   if (depth_diff < -trunc_margin) return;
   const float dist = fminf(1.0f, depth_diff / trunc_margin);
-  if (!MERGE) {
-    const float w_old = weight_vol[voxel_idx];
-    const float w_new = w_old + obs_weight;
-    weight_vol[voxel_idx] = w_new;
-    tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
-    const float old_color = color_vol[voxel_idx];
-    const float old_b = floorf(old_color / (256 * 256));
-    const float old_g = floorf((old_color - old_b * 256 * 256) / 256);
-    const float old_r = old_color - old_b * 256 * 256 - old_g * 256;
-    const float new_color = color_im[py * im_w + px];
-    float new_b = floorf(new_color / (256 * 256));
-    float new_g = floorf((new_color - new_b * 256 * 256) / 256);
-    float new_r = new_color - new_b * 256 * 256 - new_g * 256;
-    new_b = fminf(roundf(__fmaf_rn(old_b, w_old, new_b) / w_new), 255.0f);
-    new_g = fminf(roundf(__fmaf_rn(old_g, w_old, new_g) / w_new), 255.0f);
-    new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
-    color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
-    rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, rem_im[py * im_w + px]) / w_new;
-  } else {
-    const float dist_old = weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
-    const float old_color = color_vol[voxel_idx];
-    const float new_color = color_im[py * im_w + px];
-    if (old_color == new_color) {  // same class: integrate
-      const float w_old = weight_vol[voxel_idx];
-      const float w_new = w_old + obs_weight;
-      weight_vol[voxel_idx] = w_new;
-      tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
-      rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, rem_im[py * im_w + px]) / w_new;
-    } else if (dist < dist_old) {  // other class: the closer observation wins
-      tsdf_vol[voxel_idx] = dist;
-      const float new_b = floorf(new_color / (256 * 256));
-      const float new_g = floorf((new_color - new_b * 256 * 256) / 256);
-      const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
-      color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
-      rem_vol[voxel_idx] = rem_im[py * im_w + px];
+  tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight, color_im[py * im_w + px],
+                     rem_im[py * im_w + px]);
+}
+
+// largest depth of every image column (W threads)
+__global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ depth_im, int im_h, int im_w,
+                                                     float* __restrict__ colmax) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= im_w) return;
+  float m = 0.f;
+  for (int y = 0; y < im_h; ++y) m = fmaxf(m, depth_im[y * im_w + x]);
+  colmax[x] = m;
+}
+
+// per voxel column (x, y): its image column px -- the kernel's own expressions on voxel_x = x, voxel_y = y -- or -1
+// when no voxel of the column can pass the truncation test
+__global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim_y, float ox, float oy, float voxel_size,
+                                                      int im_w, float trunc_margin, const float* __restrict__ colmax,
+                                                      int* __restrict__ colinfo) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= vol_dim_x * vol_dim_y) return;
+  const int x = c / vol_dim_y, y = c - x * vol_dim_y;
+  const float pt_x = __fmaf_rn((float)x, voxel_size, ox);
+  const float pt_y = __fmaf_rn((float)y, voxel_size, oy);
+  const float yaw = -atan2f(pt_y, pt_x);
+  float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
+  proj_x *= (float)im_w;
+  int px = (int)floorf(proj_x);
+  px = min(im_w - 1, px);
+  px = max(0, px);
+  // every voxel of the column has depth = sqrtf(fma(z, z, fma(y, y, x * x))) >= rho (fma and sqrtf are monotonic), so
+  // depth_value - depth <= colmax - rho: if that is already < -trunc_margin the column is dead.  A column of zeros
+  // (colmax == 0) leaves at `depth_value == 0`.
+  const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
+  const float cm = colmax[px];
+  const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
+  colinfo[c] = dead ? -1 : px;
+}
+
+template <bool MERGE>
+__device__ __forceinline__ void tsdf_voxel(
+    int voxel_idx, float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
+    const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
+    unsigned epoch) {
+  // voxel grid coordinates -- float division exactly as the reference (:95-98); beyond 2^24 voxels (float)voxel_idx
+  // is rounded, which moves a few voxels next to an x boundary to (x + 1, -1, z): those are not a column of the table
+  const float voxel_x = floorf(((float)voxel_idx) / ((float)(vol_dim_y * vol_dim_z)));
+  const float voxel_y = floorf(((float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z)) / ((float)vol_dim_z));
+  const float voxel_z = (float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z - ((int)voxel_y) * vol_dim_z);
+  const int ix = (int)voxel_x, iy = (int)voxel_y;
+  const bool in_table = ix >= 0 && ix < vol_dim_x && iy >= 0 && iy < vol_dim_y;
+  int px = -2;
+  if (in_table) {
+    px = colinfo[ix * vol_dim_y + iy];
+    if (px == -1) return;
+  }
+  const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
+  const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
+  const float pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
+  const float fov = fabsf(fov_up) + fabsf(fov_down);
+  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, __fmaf_rn(pt_y, pt_y, pt_x * pt_x)));  // norm3df
+  const float s = pt_z / depth;
+  if (s > sin_up_hi || s < sin_down_lo) return;  // clearly outside the vertical field of view (NaN passes on)
+  const float pitch = asinf(s);
+  if (pitch > fov_up || pitch < fov_down) return;
+  if (px < 0) {
+    const float yaw = -atan2f(pt_y, pt_x);
+    float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
+    proj_x *= (float)im_w;
+    px = (int)floorf(proj_x);
+    px = min(im_w - 1, px);
+    px = max(0, px);
+  }
+  float proj_y = (float)(1.0 - (double)((pitch + fabsf(fov_down)) / fov));
+  proj_y *= (float)im_h;
+  int py = (int)floorf(proj_y);
+  py = min(im_h - 1, py);
+  py = max(0, py);
+  const float depth_value = depth_im[py * im_w + px];
+  if (depth_value == 0.f) return;
+  const float depth_diff = depth_value - depth;
+  if (depth_diff < -trunc_margin) return;
+  const float dist = fminf(1.0f, depth_diff / trunc_margin);
+  // the column this voxel's MEMORY belongs to becomes dirty (in_table: (ix, iy, z) is the true decomposition)
+  col_epoch[in_table ? ix * vol_dim_y + iy : voxel_idx / vol_dim_z] = epoch;
+  tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight, color_im[py * im_w + px],
+                     rem_im[py * im_w + px]);
+}
+
+// A wave looks at the table entries of 64 voxel columns at once and then walks only the columns that are not dead,
+// dim_z voxels each with z along the lanes (the memory order: coalesced).  Columns with y = dim_y - 1 are always
+// walked: they are where the reference's float voxel index can misplace a voxel into the (x + 1, -1) column, which the
+// table does not describe -- tsdf_voxel() handles every voxel by the reference's own decomposition.
+template <bool MERGE>
+__global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
+    const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
+    unsigned epoch, float tan_up, float tan_down, int tan_ok) {
+  const int lane = threadIdx.x & 63;
+  const int n_cols = vol_dim_x * vol_dim_y;
+  const int n_chunks = (n_cols + 63) / 64;
+  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    const int c = chunk * 64 + lane;
+    bool live = false;
+    if (c < n_cols) live = colinfo[c] != -1 || (c % vol_dim_y) == vol_dim_y - 1;
+    unsigned long long m = __ballot(live);
+    while (m) {
+      const int cc = chunk * 64 + (__ffsll((long long)m) - 1);
+      m &= m - 1;
+      // z range of the column that can lie inside the vertical field of view (wave-uniform, conservative: the voxels
+      // left out would take tsdf_voxel's sine exit): pt_z in [rho tan(fov_down) - pad, rho tan(fov_up) + pad].  Not
+      // for the y = dim_y - 1 columns, whose voxels may belong to another (x, y) by the reference's float index.
+      int z0 = 0, z1 = vol_dim_z;
+      const int cx = cc / vol_dim_y, cy = cc - cx * vol_dim_y;
+      if (cy != vol_dim_y - 1 && tan_ok) {
+        const float pt_x = __fmaf_rn((float)cx, voxel_size, ox), pt_y = __fmaf_rn((float)cy, voxel_size, oy);
+        const float rho = sqrtf(pt_x * pt_x + pt_y * pt_y);
+        const float pad = 2.0f * voxel_size + 1e-3f * rho;
+        const float zl = (rho * tan_down - pad - oz) / voxel_size, zh = (rho * tan_up + pad - oz) / voxel_size;
+        z0 = max(0, (int)floorf(fminf(fmaxf(zl, -1.0f), (float)vol_dim_z)));
+        z1 = min(vol_dim_z, (int)ceilf(fminf(fmaxf(zh, -1.0f), (float)vol_dim_z)) + 1);
+      }
+      for (int z = z0 + lane; z < z1; z += 64)
+        tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y, vol_dim_z, ox,
+                          oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down, sin_up_hi,
+                          sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch);
+    }
+  }
+}
+
+// re-initialise the dirty columns: a wave reads 64 stamps at once and walks the dirty columns
+__global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
+                                                         float* __restrict__ color, float* __restrict__ rem,
+                                                         int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
+                                                         unsigned epoch) {
+  const int lane = threadIdx.x & 63;
+  const int n_chunks = (n_cols + 63) / 64;
+  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    const int c = chunk * 64 + lane;
+    unsigned long long m = __ballot(c < n_cols && col_epoch[c] == epoch);
+    while (m) {
+      const size_t base = (size_t)(chunk * 64 + (__ffsll((long long)m) - 1)) * dim_z;
+      m &= m - 1;
+      for (int z = lane; z < dim_z; z += 64) {
+        tsdf[base + z] = 1.0f;
+        weight[base + z] = 0.0f;
+        color[base + z] = 0.0f;
+        rem[base + z] = 0.0f;
+      }
     }
   }
 }
@@ -111,22 +289,36 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  float* ps[] = {t->tsdf, t->weight, t->color, t->rem};
-  for (float* p : ps)
+  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax};
+  for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
   return LT_OK;
 }
 
+static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
+  hipLaunchKernelGGL(k_tsdf_fill, dim3(4096), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem, t->n);
+  LT_HIP(hipMemsetAsync(t->col_epoch, 0, (size_t)t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
+  LT_HIP(hipGetLastError());
+  t->epoch = 1;
+  t->all_dirty = 0;
+  return LT_OK;
+}
+
+// Back to the initial volume (tsdf = 1, weight = colour = remission = 0): the reference builds a NEW TSDFVolume per
+// output scan (laserscan.py:886-887, :968-969).  Only the columns written since the last reset are touched.
 extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   if (!t) {
     lt_set_error("lt_tsdf_reset: NULL volume");
     return LT_ERR_INVALID_ARG;
   }
   LT_HIP(hipSetDevice(t->device));
-  hipLaunchKernelGGL(k_tsdf_fill, dim3(4096), dim3(256), 0, (hipStream_t)stream, t->tsdf, t->weight, t->color, t->rem,
-                     t->n);
+  if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
+  const int n_cols = t->dim[0] * t->dim[1];
+  hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch);
   LT_HIP(hipGetLastError());
+  t->epoch += 1;  // every stamp is stale now: nothing to clear
   return LT_OK;
 }
 
@@ -171,7 +363,14 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
       return LT_ERR_NO_MEMORY;
     }
   }
-  const int rc = lt_tsdf_reset(t, nullptr);
+  const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
+  if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
+      hipMalloc((void**)&t->colinfo, n_cols * sizeof(int)) != hipSuccess) {
+    lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
+    lt_tsdf_destroy(t);
+    return LT_ERR_NO_MEMORY;
+  }
+  const int rc = tsdf_full_reset(t, nullptr);
   if (rc != LT_OK) {
     lt_tsdf_destroy(t);
     return rc;
@@ -182,26 +381,76 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
 }
 
 extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im,
-                                     int im_h, int im_w, float obs_weight, unsigned flags, void* stream) {
+                                     int im_h, int im_w, float obs_weight, unsigned flags, void* stream_) {
   if (!t || !color_im || !depth_im || !rem_im || im_h <= 0 || im_w <= 0) {
     lt_set_error("lt_tsdf_integrate_dev: invalid argument");
     return LT_ERR_INVALID_ARG;
   }
+  hipStream_t stream = (hipStream_t)stream_;
   LT_HIP(hipSetDevice(t->device));
   // other_params[6] * PI / 180.0 in double, stored to float (fusion_lidar.py:124-125); the launch passes the
   // degrees as float32 (:278-280)
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
   const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
   const unsigned nb = (unsigned)((t->n + 255) / 256);
+  static const bool dense = []() {
+    const char* e = getenv("LIDARHIP_TSDF");
+    return e && strcmp(e, "dense") == 0;
+  }();
+  if (dense) {
+    t->all_dirty = 1;  // no column stamps from this kernel: the next reset / extraction treats every column as written
+    if (flags & LT_TSDF_MERGE)
+      hipLaunchKernelGGL(k_tsdf_integrate<true>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
+                         t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h,
+                         im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
+    else
+      hipLaunchKernelGGL(k_tsdf_integrate<false>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
+                         t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h,
+                         im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
+    LT_HIP(hipGetLastError());
+    return LT_OK;
+  }
+  if (im_w > t->cap_w) {
+    if (t->colmax) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(t->colmax);
+      t->colmax = nullptr;
+    }
+    LT_HIP(hipMalloc((void**)&t->colmax, (size_t)im_w * sizeof(float)));
+    t->cap_w = im_w;
+  }
+  const int n_cols = t->dim[0] * t->dim[1];
+  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 255) / 256), dim3(256), 0, stream, depth_im, im_h, im_w, t->colmax);
+  hipLaunchKernelGGL(k_tsdf_columns, dim3((n_cols + 255) / 256), dim3(256), 0, stream, t->dim[0], t->dim[1], t->origin[0],
+                     t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo);
+  // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
+  const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
+  // slopes of the per-column z range (same 1e-5 margin on the angles); off for fields of view beyond +-80 degrees
+  const int tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
+  const float tu = tan_ok ? (float)tan((double)fu + 1e-5) : 0.f, td = tan_ok ? (float)tan((double)fd - 1e-5) : 0.f;
+  const unsigned nbc = (unsigned)min((n_cols + 255) / 256, 16384);  // 64 columns per wave and trip
   if (flags & LT_TSDF_MERGE)
-    hipLaunchKernelGGL(k_tsdf_integrate<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t->tsdf, t->weight,
-                       t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
-                       t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
+    hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
+                       t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
+                       t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
+                       t->epoch, tu, td, tan_ok);
   else
-    hipLaunchKernelGGL(k_tsdf_integrate<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, t->tsdf, t->weight,
-                       t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
-                       t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
+    hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
+                       t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
+                       t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
+                       t->epoch, tu, td, tan_ok);
   LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
+// The caller wrote into the volumes through the pointers of lt_tsdf_volumes: every column counts as written from
+// now on (until the next reset) -- reset and marching cubes must not skip anything.
+extern "C" int lt_tsdf_touch(lt_tsdf* t) {
+  if (!t) {
+    lt_set_error("lt_tsdf_touch: NULL volume");
+    return LT_ERR_INVALID_ARG;
+  }
+  t->all_dirty = 1;
   return LT_OK;
 }
 

@@ -145,6 +145,16 @@ class TSDFVolume:
                                                            C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_dev")
         st.synchronize()  # the temporaries above must outlive the kernel
 
+    def reset(self):
+        """Back to the initial volume (what ``TSDFVolume(...)`` of the reference starts from); only the voxel columns
+        written since the last reset are re-initialised."""
+        st = self._torch.cuda.current_stream(self.device)
+        self._libmod.check(self._lib.lt_tsdf_reset(self._h, self._C.c_void_p(st.cuda_stream)), "lt_tsdf_reset")
+
+    def touch(self):
+        """Call after writing into the tensors of :meth:`get_volume_tensors` directly."""
+        self._libmod.check(self._lib.lt_tsdf_touch(self._h), "lt_tsdf_touch")
+
     def get_volume(self):
         """``(tsdf, color, rem)`` as float32 numpy arrays ``[dx,dy,dz]`` (fusion_lidar.py:395-400)."""
         t, w, c, r = self.get_volume_tensors()

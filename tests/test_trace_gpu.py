@@ -873,3 +873,34 @@ def test_five_instruction_reciprocal_is_the_ieee_division_for_every_float():
     assert lib.lt_debug_verify_rcp(C.byref(bad), C.byref(fast)) == 0
     assert bad.value == 0, f"{bad.value} of 2^32 floats differ"
     assert fast.value == 2 * 128 * (1 << 23) + 2   # 128 binades of each sign, plus +-2^64
+
+
+def test_tiny_far_triangles_are_not_taken_for_pierced(oracle):
+    """Marching cubes emits micrometre-sized triangles where the field is ~0 at a grid point.  Far from the sensor
+    their three sub-areas are all of the order of the rounding tolerance -- neither clearly of mixed sign nor clearly
+    zero -- and the angular bounds used to fall back to "every azimuth" (70 000 candidate bins per triangle).
+    Parity with the brute-force oracle, and the candidate count stays that of a small triangle."""
+    rng = np.random.default_rng(21)
+    n = 3000
+    rho = rng.uniform(5.0, 60.0, (n, 1))
+    phi = rng.uniform(-np.pi, np.pi, (n, 1))
+    cen = np.concatenate([rho * np.cos(phi), rho * np.sin(phi), rng.uniform(-2.0, 0.5, (n, 1))], 1)
+    size = 10.0 ** rng.uniform(-5.5, -3.0, (n, 1, 1))           # 3 um .. 1 mm
+    tri = cen[:, None, :] + rng.normal(size=(n, 3, 3)) * size
+    tri[: n // 3] = cen[: n // 3, None, :] + np.eye(3)[None] * size[: n // 3]   # the axis-aligned corner triangles of MC
+    big = synth_scene(2, 4000)                                    # plus an ordinary scene behind them
+    v = np.ascontiguousarray(np.concatenate([tri.reshape(-1, 3).astype(np.float32), big[0]]))
+    f = np.ascontiguousarray(np.concatenate([np.arange(3 * n, dtype=np.int32).reshape(-1, 3), big[1] + 3 * n]))
+    c = np.ascontiguousarray(np.concatenate([rng.integers(0, 256, (3 * n, 3)).astype(np.int32), big[2]]))
+    r = np.ascontiguousarray(np.concatenate([rng.uniform(0, 1, 3 * n).astype(np.float32), big[3]]))
+    H, W = 64, 2048
+    rays = create_rays(3.0, -25.0, H, W)
+    a, b = _both_strategies(v, f, c, r, rays, (0.0, 0.0, 0.0), H)
+    ref = oracle.oracle_trace(rays, np.zeros(3, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE, norm=oracle.NORM_SSE_TABLE)
+    for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+        _assert_bits(a[k], ref[k], "scatter " + k)
+        _assert_bits(b[k], ref[k], "lbvh " + k)
+    # the tiny triangles alone: a handful of candidate bins each (it was the whole circle: ~70 000)
+    nt = 3 * n
+    a2, _ = _both_strategies(v[:nt], f[:n], c[:nt], r[:nt], rays, (0.0, 0.0, 0.0), H)
+    assert a2["stats"]["nodes_visited"] < 8 * n, a2["stats"]["nodes_visited"] / n

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Driver for rocprofv3: the fusion chain (reset -> integrate -> marching cubes -> render) on the default volume, N times."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from lidar_transfer_amd import _lib
+from lidar_transfer_amd.fusion import DeviceMesh, TSDFVolume
+from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.raytracer import RaySet, Scene
+from lidar_transfer_amd.synth import WORKLOADS, synth_scene
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+wl = WORKLOADS["C2"]; H, W = wl["H"], wl["W"]; dev = torch.device("cuda", 0)
+lib = _lib.load()
+mesh0 = [torch.from_numpy(x).to(dev) for x in synth_scene(0, wl["tris"])]
+rays = torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev)
+sc = Scene(0); rs = RaySet(rays, H); sc.set_mesh(*mesh0)
+o = sc.render(rs, (0, 0, 0)); torch.cuda.synchronize()
+folded = (o["endcolors"][:, 2].reshape(H, W).float() * 65536.0).contiguous()
+depth = o["range"].reshape(H, W).contiguous(); remi = o["endrem"].reshape(H, W).contiguous()
+vol = TSDFVolume(np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]]), 0.05, wl["fov_up"], wl["fov_down"])
+mesh = DeviceMesh(0)
+sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream); org = (C.c_float * 3)(0, 0, 0)
+for i in range(n):
+    assert lib.lt_tsdf_reset(vol._h, sp) == 0
+    assert lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), depth.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
+    assert lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None) == 0
+    assert lib.lt_scene_set_mesh(sc._h, mesh._h) == 0
+    assert lib.lt_scene_render_dev(sc._h, rs._h, org, o["endpoints"].data_ptr(), o["endcolors"].data_ptr(), o["range"].data_ptr(),
+                                   o["endrem"].data_ptr(), o["tri"].data_ptr(), 1, sp, None) == 0
+torch.cuda.synchronize()
+dirty = None
+print("verts", mesh.n_verts, "faces", mesh.n_faces)
+if "--count" in sys.argv:
+    sc.set_device_mesh(mesh)
+    st = sc.render(rs, (0, 0, 0), count=True)["stats"]
+    print("MC mesh render: candidate bins %d (%.2f per triangle), MT tests %d (%.2f per ray), hits %d" % (
+        st["nodes_visited"], st["nodes_visited"] / mesh.n_faces, st["tris_tested"], st["tris_tested"] / (H * W), st["n_hits"]))
+    qs = (C.c_int * 2)()
+    lib.lt_debug_scatter_queues.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert lib.lt_debug_scatter_queues(sc._h, qs) == 0
+    print("queued big triangles %d, queued slices %d" % (qs[0], qs[1]))
+    v, f, c, r = mesh.tensors()
+    tri = v[f.long()]                      # [F, 3, 3]
+    d = tri.norm(dim=2).min(dim=1).values
+    rho = tri[:, :, :2].norm(dim=2).min(dim=1).values
+    print("triangles: nearest vertex distance  min %.3f  p1 %.3f  p50 %.2f ; min horizontal distance  min %.4f  p0.1 %.4f" % (
+        d.min(), d.kthvalue(max(1, int(0.01 * d.numel()))).values, d.median(), rho.min(), rho.kthvalue(max(1, int(0.001 * rho.numel()))).values))
+    print("triangles within 1 m of the sensor: %d, within 0.3 m of the vertical axis: %d" % (int((d < 1.0).sum()), int((rho < 0.3).sum())))
+    area = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=1) * 0.5
+    print("degenerate (area < 1e-9 m^2): %d of %d" % (int((area < 1e-9).sum()), area.numel()))
+    nl = qs[0]
+    ids = np.zeros(nl, np.int32)
+    lib.lt_debug_scatter_large.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert lib.lt_debug_scatter_large(sc._h, ids.ctypes.data_as(C.c_void_p), nl) == 0
+    T = tri[torch.from_numpy(ids).long().to(dev)].cpu().numpy().astype(np.float64)
+    np.set_printoptions(precision=5, suppress=True, linewidth=200)
+    for k in range(min(6, nl)):
+        a = T[k]
+        az = np.degrees(np.arctan2(a[:, 1], a[:, 0])); el = np.degrees(np.arctan2(a[:, 2], np.hypot(a[:, 0], a[:, 1])))
+        print("big face", ids[k], "verts", a.reshape(-1), "az", az, "el", el)
+    az_all = np.degrees(np.arctan2(T[:, :, 1], T[:, :, 0]))
+    print("big triangles: |azimuth| of their vertices min %.3f ; all near the +-180 seam: %s" % (np.abs(az_all).min(), bool((np.abs(az_all) > 179).all())))
