@@ -114,6 +114,8 @@ struct lt_tsdf {
   unsigned* col_epoch;  // [dim_x * dim_y]
   unsigned epoch;
   int all_dirty;        // an integrate without stamps ran (LIDARHIP_TSDF=dense): every column counts as written
+  unsigned long long* bits;  // [dim_x * dim_y][ceil(dim_z / 64)] sign bit of every voxel's tsdf (the layout of lt_mc.hip),
+                             // kept up to date by the column-aware integrate and by reset; invalid while all_dirty
   int* colinfo;         // [dim_x * dim_y] per integrate call: image column px of the voxel column, or -1 = dead
   float* colmax;        // [cap_w] per integrate call: largest depth of every image column
   int cap_w;

@@ -460,7 +460,7 @@ static int mc_grow(T** p, size_t* cap, size_t need) {
 
 static int mc_extract(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny, int nz,
                       float voxel_size, const float* origin, lt_mesh* m, void* stream_, float* ms,
-                      const unsigned* col_epoch, unsigned epoch) {
+                      const unsigned* col_epoch, unsigned epoch, const u64* ext_bits) {
   if (!tsdf || !color_vol || !rem_vol || !origin || !m || nx <= 0 || ny <= 0 || nz <= 0) {
     lt_set_error("lt_marching_cubes_dev: invalid argument");
     return LT_ERR_INVALID_ARG;
@@ -502,10 +502,13 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   int* seg_dev = m->blk + 3 * (size_t)n_blocks;
   int* totals_dev = seg_dev + 3 * (size_t)n_seg;
   if (ms) LT_HIP(hipEventRecord(m->ev[0], stream));
-  hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
-                     tsdf, D, m->bits, col_epoch, epoch);
+  // sign bits: the volume's own (kept current by integrate / reset, lt_tsdf.hip) or one pass over the float field
+  const u64* bits = ext_bits ? ext_bits : m->bits;
+  if (!ext_bits)
+    hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
+                       tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
-  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk);
+  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -542,10 +545,10 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }
-  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, m->bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
+  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647));
   if (n_active > 0)
-    hipLaunchKernelGGL(k_mc_emit, dim3((n_active + 3) / 4), dim3(256), 0, stream, tsdf, color_vol, rem_vol, m->bits, D,
+    hipLaunchKernelGGL(k_mc_emit, dim3((n_active + 3) / 4), dim3(256), 0, stream, tsdf, color_vol, rem_vol, bits, D,
                        m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], m->verts, m->faces,
                        m->colors, m->rem, m->cap_v, m->cap_f);
   LT_HIP(hipGetLastError());
@@ -574,13 +577,13 @@ extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, fl
   }
   // the volume knows which columns were written since its last reset: the others are not read
   return mc_extract(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m, stream, ms,
-                    t->all_dirty ? nullptr : t->col_epoch, t->epoch);
+                    t->all_dirty ? nullptr : t->col_epoch, t->epoch, t->all_dirty ? nullptr : t->bits);
 }
 
 extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
                                      int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
                                      float* ms) {
-  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u);
+  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u, nullptr);
 }
 
 extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {

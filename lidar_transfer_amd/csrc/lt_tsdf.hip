@@ -44,16 +44,19 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
   }
 }
 
-// the update of one voxel (fusion_lidar.py:178-228), shared by the dense and the column-aware kernel
+// the update of one voxel (fusion_lidar.py:178-228), shared by the dense and the column-aware kernel; returns what
+// happened to the voxel's tsdf: 0 untouched, 1 written (not negative), 2 written negative (the sign bit marching cubes
+// needs, lt_mc.hip)
 template <bool MERGE>
-__device__ __forceinline__ void tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
+__device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
                                             float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
                                             float dist, float obs_weight, float new_color, float new_rem) {
   if (!MERGE) {
     const float w_old = weight_vol[voxel_idx];
     const float w_new = w_old + obs_weight;
     weight_vol[voxel_idx] = w_new;
-    tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+    const float tv = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+    tsdf_vol[voxel_idx] = tv;
     const float old_color = color_vol[voxel_idx];
     const float old_b = floorf(old_color / (256 * 256));
     const float old_g = floorf((old_color - old_b * 256 * 256) / 256);
@@ -66,6 +69,7 @@ __device__ __forceinline__ void tsdf_update(float* __restrict__ tsdf_vol, float*
     new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
     color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
     rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+    return tv < 0.0f ? 2 : 1;
   } else {
     const float dist_old = weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
     const float old_color = color_vol[voxel_idx];
@@ -73,8 +77,10 @@ __device__ __forceinline__ void tsdf_update(float* __restrict__ tsdf_vol, float*
       const float w_old = weight_vol[voxel_idx];
       const float w_new = w_old + obs_weight;
       weight_vol[voxel_idx] = w_new;
-      tsdf_vol[voxel_idx] = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+      const float tv = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+      tsdf_vol[voxel_idx] = tv;
       rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+      return tv < 0.0f ? 2 : 1;
     } else if (dist < dist_old) {  // other class: the closer observation wins
       tsdf_vol[voxel_idx] = dist;
       const float new_b = floorf(new_color / (256 * 256));
@@ -82,7 +88,9 @@ __device__ __forceinline__ void tsdf_update(float* __restrict__ tsdf_vol, float*
       const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
       color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
       rem_vol[voxel_idx] = new_rem;
+      return dist < 0.0f ? 2 : 1;
     }
+    return 0;
   }
 }
 
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
 }
 
 template <bool MERGE>
-__device__ __forceinline__ void tsdf_voxel(
+__device__ __forceinline__ int tsdf_voxel(
     int voxel_idx, float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
     float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
@@ -183,7 +191,7 @@ __device__ __forceinline__ void tsdf_voxel(
   int px = -2;
   if (in_table) {
     px = colinfo[ix * vol_dim_y + iy];
-    if (px == -1) return;
+    if (px == -1) return 0;
   }
   const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
   const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
@@ -191,9 +199,9 @@ __device__ __forceinline__ void tsdf_voxel(
   const float fov = fabsf(fov_up) + fabsf(fov_down);
   const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, __fmaf_rn(pt_y, pt_y, pt_x * pt_x)));  // norm3df
   const float s = pt_z / depth;
-  if (s > sin_up_hi || s < sin_down_lo) return;  // clearly outside the vertical field of view (NaN passes on)
+  if (s > sin_up_hi || s < sin_down_lo) return 0;  // clearly outside the vertical field of view (NaN passes on)
   const float pitch = asinf(s);
-  if (pitch > fov_up || pitch < fov_down) return;
+  if (pitch > fov_up || pitch < fov_down) return 0;
   if (px < 0) {
     const float yaw = -atan2f(pt_y, pt_x);
     float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
@@ -208,14 +216,14 @@ __device__ __forceinline__ void tsdf_voxel(
   py = min(im_h - 1, py);
   py = max(0, py);
   const float depth_value = depth_im[py * im_w + px];
-  if (depth_value == 0.f) return;
+  if (depth_value == 0.f) return 0;
   const float depth_diff = depth_value - depth;
-  if (depth_diff < -trunc_margin) return;
+  if (depth_diff < -trunc_margin) return 0;
   const float dist = fminf(1.0f, depth_diff / trunc_margin);
   // the column this voxel's MEMORY belongs to becomes dirty (in_table: (ix, iy, z) is the true decomposition)
   col_epoch[in_table ? ix * vol_dim_y + iy : voxel_idx / vol_dim_z] = epoch;
-  tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight, color_im[py * im_w + px],
-                     rem_im[py * im_w + px]);
+  return tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight,
+                            color_im[py * im_w + px], rem_im[py * im_w + px]);
 }
 
 // A wave looks at the table entries of 64 voxel columns at once and then walks only the columns that are not dead,
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch, float tan_up, float tan_down, int tan_ok) {
+    unsigned epoch, float tan_up, float tan_down, int tan_ok, unsigned long long* __restrict__ sign_bits, int words_z) {
   const int lane = threadIdx.x & 63;
   const int n_cols = vol_dim_x * vol_dim_y;
   const int n_chunks = (n_cols + 63) / 64;
@@ -254,10 +262,22 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
         z0 = max(0, (int)floorf(fminf(fmaxf(zl, -1.0f), (float)vol_dim_z)));
         z1 = min(vol_dim_z, (int)ceilf(fminf(fmaxf(zh, -1.0f), (float)vol_dim_z)) + 1);
       }
-      for (int z = z0 + lane; z < z1; z += 64)
-        tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y, vol_dim_z, ox,
-                          oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down, sin_up_hi,
-                          sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch);
+      // z in word-aligned chunks of 64 (the lanes): the signs of the values written update ONE word of the column's
+      // sign bits, which marching cubes reads instead of the float field (bit b of word k = voxel z = 64 k + b is
+      // negative); only this wave works on this column, so the read-modify-write needs no atomic
+      for (int zc = z0 & ~63; zc < z1; zc += 64) {
+        const int z = zc + lane;
+        int code = 0;
+        if (z >= z0 && z < z1)
+          code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
+                                   vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
+                                   fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch);
+        const unsigned long long wrote = __ballot(code != 0), neg = __ballot(code == 2);
+        if (wrote && lane == 0) {
+          unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
+          *w = (*w & ~wrote) | neg;
+        }
+      }
     }
   }
 }
@@ -266,15 +286,18 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
 __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
                                                          float* __restrict__ color, float* __restrict__ rem,
                                                          int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
-                                                         unsigned epoch) {
+                                                         unsigned epoch, unsigned long long* __restrict__ sign_bits) {
   const int lane = threadIdx.x & 63;
   const int n_chunks = (n_cols + 63) / 64;
+  const int words_z = (dim_z + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
     const int c = chunk * 64 + lane;
     unsigned long long m = __ballot(c < n_cols && col_epoch[c] == epoch);
     while (m) {
-      const size_t base = (size_t)(chunk * 64 + (__ffsll((long long)m) - 1)) * dim_z;
+      const int cc = chunk * 64 + (__ffsll((long long)m) - 1);
+      const size_t base = (size_t)cc * dim_z;
       m &= m - 1;
+      if (lane < words_z) sign_bits[(size_t)cc * words_z + lane] = 0ull;
       for (int z = lane; z < dim_z; z += 64) {
         tsdf[base + z] = 1.0f;
         weight[base + z] = 0.0f;
@@ -289,7 +312,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax};
+  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -299,6 +322,8 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
 static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
   hipLaunchKernelGGL(k_tsdf_fill, dim3(4096), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem, t->n);
   LT_HIP(hipMemsetAsync(t->col_epoch, 0, (size_t)t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
+  LT_HIP(hipMemsetAsync(t->bits, 0, (size_t)t->dim[0] * t->dim[1] * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long),
+                        stream));
   LT_HIP(hipGetLastError());
   t->epoch = 1;
   t->all_dirty = 0;
@@ -316,7 +341,7 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
   const int n_cols = t->dim[0] * t->dim[1];
   hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch);
+                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits);
   LT_HIP(hipGetLastError());
   t->epoch += 1;  // every stamp is stale now: nothing to clear
   return LT_OK;
@@ -365,7 +390,8 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   }
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
-      hipMalloc((void**)&t->colinfo, n_cols * sizeof(int)) != hipSuccess) {
+      hipMalloc((void**)&t->colinfo, n_cols * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
     lt_tsdf_destroy(t);
     return LT_ERR_NO_MEMORY;
@@ -433,12 +459,12 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, tu, td, tan_ok);
+                       t->epoch, tu, td, tan_ok, t->bits, (t->dim[2] + 63) / 64);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, tu, td, tan_ok);
+                       t->epoch, tu, td, tan_ok, t->bits, (t->dim[2] + 63) / 64);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }

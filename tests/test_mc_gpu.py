@@ -160,3 +160,37 @@ def test_default_sized_volume_extraction_is_sparse_work():
     print(f"default volume: {v.shape[0]} verts, {f.shape[0]} faces, sign pass {ms_signs:.3f} ms, rest {ms_rest:.3f} ms")
     assert ms_signs < 5.0 and ms_rest < 5.0
     vol.close()
+
+
+def test_mesh_after_reset_and_reintegration_equals_oracle(oracle):
+    """The volume keeps the sign bit of every voxel current while it integrates and clears them for the columns a reset
+    re-initialises; marching cubes reads those bits instead of the float field.  After reset + one more observation the
+    mesh must again be the oracle's mesh of the downloaded volume (and differ from the mesh before the reset), also
+    after the fields were modified behind the library's back (`touch`)."""
+    import torch
+    vol, (H, W, fu, fd) = _fused_volume(n_obs=2)
+    before = [a.cpu().numpy() for a in vol.extract_mesh().tensors()]
+    vol.reset()
+    t, w, c, r = vol.get_volume_tensors()
+    assert float(t.min()) == 1.0 and float(w.max()) == 0.0 and float(c.max()) == 0.0
+    assert vol.extract_mesh().n_faces == 0
+    dev = t.device
+    yaw = torch.linspace(-np.pi, np.pi, W, device=dev)
+    depth = (7.0 + 2.0 * torch.sin(2 * yaw))[None, :].repeat(H, 1).contiguous()
+    lab = torch.full((H, W), 50.0, device=dev)
+    label3 = torch.stack([lab, torch.zeros_like(lab), torch.zeros_like(lab)], 2)
+    vol.integrate(label3, depth, torch.full((H, W), 0.25, device=dev), np.eye(4))
+    tsdf, weight, color, rem = [a.cpu().numpy() for a in vol.get_volume_tensors()]
+    want = oracle.marching_cubes(tsdf, color, rem, np.float32(0.1), vol._vol_origin)
+    got = [a.cpu().numpy() for a in vol.extract_mesh().tensors()]
+    _assert_same_mesh(got, want)
+    assert got[1].shape[0] > 5000 and got[1].shape != before[1].shape
+    # a caller writes into the field directly: the library must be told, then everything is re-read
+    t, w, c, r = vol.get_volume_tensors()
+    t[100:110, 100:110, 20:30] = -0.5
+    vol.touch()
+    tsdf = t.cpu().numpy()
+    want = oracle.marching_cubes(tsdf, color, rem, np.float32(0.1), vol._vol_origin)
+    got = [a.cpu().numpy() for a in vol.extract_mesh().tensors()]
+    _assert_same_mesh(got, want)
+    vol.close()
