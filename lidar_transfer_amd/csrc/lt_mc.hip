@@ -287,107 +287,128 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
   return (float)((double)c + w2 / (w1 + w2));
 }
 
-__global__ __launch_bounds__(256) void k_mc_emit(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
-                                                 const float* __restrict__ rem_vol, const u64* __restrict__ bits,
-                                                 mc_dims D, const int* __restrict__ cmap,
-                                                 const mc_rec* __restrict__ rec, int n_active, float voxel_size,
-                                                 float ox, float oy, float oz, float* __restrict__ verts,
-                                                 int* __restrict__ faces, int* __restrict__ colors,
-                                                 float* __restrict__ rem, int cap_v, int cap_f) {
-  __shared__ mc_nb nb[4][8];
-  const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
-  const int ci = blockIdx.x * 4 + wave;
-  const bool live = ci < n_active;
-  mc_rec R;
-  R.w = 0; R.vbase = 0; R.tbase = 0; R.ex = R.ey = R.ez = 0;
-  if (live) R = rec[ci];
+__global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
+                                                const float* __restrict__ rem_vol, const u64* __restrict__ bits,
+                                                mc_dims D, const int* __restrict__ cmap,
+                                                const mc_rec* __restrict__ rec, int n_active, float voxel_size,
+                                                float ox, float oy, float oz, float* __restrict__ verts,
+                                                int* __restrict__ faces, int* __restrict__ colors,
+                                                float* __restrict__ rem, int cap_v, int cap_f) {
+  // One wave per workgroup (the barrier below is a wave barrier); the kernel is a chain of dependent memory round
+  // trips per wave, so the loads that depend on the record only -- sign words, neighbour indices, field values -- are
+  // all issued before the first of them is needed: record -> {bits, cmap, tsdf} -> {neighbour records, attributes} ->
+  // stores (it was six levels deep: 335 us on the default volume).
+  __shared__ mc_nb nb[8];
+  const int b = threadIdx.x;
+  const int ci = blockIdx.x;
+  if (ci >= n_active) return;
+  const mc_rec R = rec[ci];
   const int row = R.w / D.wz, wz = R.w - row * D.wz;
   const int x = row / D.ny, y = row - x * D.ny;
-  // the records of the (up to) 8 words a triangle of this word's cells can reference: slot = dx | dy << 1 | dwz << 2
+  const int z = wz * 64 + b;
+  const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
+  const size_t i = (size_t)x * sx + (size_t)y * sy + z;
+  // (a) sign words of the cell corners
+  const mc_masks M = mc_load(bits, D, x, y, wz);
+  // (b) compact index of the (up to) 8 words a triangle of this word's cells can reference: slot = dx | dy << 1 | dwz << 2
+  int c2 = -1;
+  if (b < 8) {
+    const int dx = b & 1, dy = (b >> 1) & 1, dw = b >> 2;
+    if (x + dx < D.nx && y + dy < D.ny && wz + dw < D.wz)
+      c2 = b == 0 ? ci : cmap[((x + dx) * D.ny + (y + dy)) * D.wz + wz + dw];
+  }
+  // (c) field values at the two ends of the edges this lane's voxel owns
+  const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull), fz = (int)((R.ez >> b) & 1ull);
+  float v0 = 0.f, v1[3] = {0.f, 0.f, 0.f};
+  if (fx | fy | fz) v0 = tsdf[i];
+  if (fx) v1[0] = tsdf[i + sx];
+  if (fy) v1[1] = tsdf[i + sy];
+  if (fz) v1[2] = tsdf[i + 1];
+  // (d) the neighbour records
   if (b < 8) {
     mc_nb e;
     e.ex = e.ey = e.ez = 0; e.vbase = 0; e.have = 0;
-    const int dx = b & 1, dy = (b >> 1) & 1, dw = b >> 2;
-    if (live && x + dx < D.nx && y + dy < D.ny && wz + dw < D.wz) {
-      const int w2 = ((x + dx) * D.ny + (y + dy)) * D.wz + wz + dw;
-      const int c2 = b == 0 ? ci : cmap[w2];
-      if (c2 >= 0) {
-        const mc_rec r2 = rec[c2];
-        e.ex = r2.ex; e.ey = r2.ey; e.ez = r2.ez; e.vbase = r2.vbase; e.have = 1;
-      }
+    if (c2 >= 0) {
+      const mc_rec r2 = rec[c2];
+      e.ex = r2.ex; e.ey = r2.ey; e.ez = r2.ez; e.vbase = r2.vbase; e.have = 1;
     }
-    nb[wave][b] = e;
+    nb[b] = e;
   }
-  __syncthreads();
-  if (!live) return;
-  const int z = wz * 64 + b;
   const u64 lm = (1ull << b) - 1ull;
   // ---- vertices of the edges this lane's voxel owns
-  const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull), fz = (int)((R.ez >> b) & 1ull);
   if (fx | fy | fz) {
-    const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
-    const size_t i = (size_t)x * sx + (size_t)y * sy + z;
-    const float v0 = tsdf[i];
     int vid = R.vbase + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
+    size_t jj[3] = {0, 0, 0};
+    float pp[3][3];
+    float rgbv[3] = {0.f, 0.f, 0.f}, remv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int f = a == 0 ? fx : (a == 1 ? fy : fz);
+      pp[a][0] = (float)x; pp[a][1] = (float)y; pp[a][2] = (float)z;
+      if (!f) continue;
+      pp[a][a] = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1[a]);
+      // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
+      // (clamped: a NaN field value must not become a wild address; numpy would raise there)
+      const int i0 = min(max((int)rintf(pp[a][0]), 0), D.nx - 1), i1 = min(max((int)rintf(pp[a][1]), 0), D.ny - 1),
+                i2 = min(max((int)rintf(pp[a][2]), 0), D.nz - 1);
+      jj[a] = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
+      rgbv[a] = color_vol[jj[a]];
+      remv[a] = rem_vol[jj[a]];
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int f = a == 0 ? fx : (a == 1 ? fy : fz);
       if (!f) continue;
       if (vid < cap_v) {
-        const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : 1))];
-        float p[3] = {(float)x, (float)y, (float)z};
-        p[a] = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
-        // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
-        // (clamped: a NaN field value must not become a wild address; numpy would raise there)
-        const int i0 = min(max((int)rintf(p[0]), 0), D.nx - 1), i1 = min(max((int)rintf(p[1]), 0), D.ny - 1),
-                  i2 = min(max((int)rintf(p[2]), 0), D.nz - 1);
-        const size_t j = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
         // verts * voxel_size + vol_origin in float32 (:412)
-        verts[3 * (size_t)vid] = p[0] * voxel_size + ox;
-        verts[3 * (size_t)vid + 1] = p[1] * voxel_size + oy;
-        verts[3 * (size_t)vid + 2] = p[2] * voxel_size + oz;
+        verts[3 * (size_t)vid] = pp[a][0] * voxel_size + ox;
+        verts[3 * (size_t)vid + 1] = pp[a][1] * voxel_size + oy;
+        verts[3 * (size_t)vid + 2] = pp[a][2] * voxel_size + oz;
         // colour unfolding (:419-423) in float32, .astype(np.uint8) = truncation to 8 bits
-        const float rgb = color_vol[j];
+        const float rgb = rgbv[a];
         const float cb = floorf(rgb / (float)(256 * 256));
         const float cg = floorf((rgb - cb * 256.0f * 256.0f) / 256.0f);
         const float cr = rgb - cb * 256.0f * 256.0f - cg * 256.0f;
         colors[3 * (size_t)vid] = (int)floorf(cr) & 255;
         colors[3 * (size_t)vid + 1] = (int)floorf(cg) & 255;
         colors[3 * (size_t)vid + 2] = (int)floorf(cb) & 255;
-        rem[vid] = rem_vol[j];
+        rem[vid] = remv[a];
       }
       ++vid;
     }
   }
-  // ---- triangles of this lane's cell (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz: nb[][3] / [4] are there)
-  int cs = 0, nt = 0;
-  {
-    const mc_masks M = mc_load(bits, D, x, y, wz);
-    if ((M.ac >> b) & 1ull) {
-      cs = mc_case(M, b);
-      nt = LT_MC_NTRIS[cs];
-    }
+  __syncthreads();  // nb[] is complete (one wave: a wave barrier)
+  // ---- triangles of this lane's cell (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz: nb[3] / [4] are there)
+  // the lane's whole cell in one 128-bit load: triangle count + 15 five-bit edge codes (LT_MC_PACKED)
+  u64 pk0 = 0, pk1 = 0;
+  if ((M.ac >> b) & 1ull) {
+    const ulonglong2 pk = ((const ulonglong2*)LT_MC_PACKED)[mc_case(M, b)];
+    pk0 = pk.x; pk1 = pk.y;
   }
+  const int nt = (int)(pk0 & 7ull);
   int inc = nt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int q = __shfl_up(inc, o, 64);
     if (b >= o) inc += q;
   }
-  int tid = R.tbase + inc - nt;
-  for (int t = LT_MC_FIRST[cs], te = t + 3 * nt; t < te; t += 3, ++tid) {
-    if (tid >= cap_f) break;
+  const int tid0 = R.tbase + inc - nt;
+#pragma unroll
+  for (int t = 0; t < LT_MC_MAX_TRIS; ++t) {
+    if (t >= nt || tid0 + t >= cap_f) break;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int code = LT_MC_TRIS[t + k], c0 = code & 7, a = code >> 3;
+      const int sh = 8 + 5 * (3 * t + k);  // compile-time constant after unrolling
+      const int code = (int)((sh < 64 ? (sh + 5 <= 64 ? (pk0 >> sh) : ((pk0 >> sh) | (pk1 << (64 - sh)))) : (pk1 >> (sh - 64))) & 31ull);
+      const int c0 = code & 7, a = code >> 3;
       int b2 = b + ((c0 >> 2) & 1), slot = c0 & 3;
       if (b2 == 64) { b2 = 0; slot |= 4; }
-      const mc_nb& e = nb[wave][slot];
+      const mc_nb& e = nb[slot];
       const u64 l2 = (1ull << b2) - 1ull;
       int id = e.vbase + __popcll(e.ex & l2) + __popcll(e.ey & l2) + __popcll(e.ez & l2);
       if (a > 0) id += (int)((e.ex >> b2) & 1ull);
       if (a > 1) id += (int)((e.ey >> b2) & 1ull);
-      faces[3 * (size_t)tid + k] = id;
+      faces[3 * (size_t)(tid0 + t) + k] = id;
     }
   }
 }
@@ -548,7 +569,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647));
   if (n_active > 0)
-    hipLaunchKernelGGL(k_mc_emit, dim3((n_active + 3) / 4), dim3(256), 0, stream, tsdf, color_vol, rem_vol, bits, D,
+    hipLaunchKernelGGL(k_mc_emit, dim3(n_active), dim3(64), 0, stream, tsdf, color_vol, rem_vol, bits, D,
                        m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], m->verts, m->faces,
                        m->colors, m->rem, m->cap_v, m->cap_f);
   LT_HIP(hipGetLastError());

@@ -47,17 +47,20 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
 // the update of one voxel (fusion_lidar.py:178-228), shared by the dense and the column-aware kernel; returns what
 // happened to the voxel's tsdf: 0 untouched, 1 written (not negative), 2 written negative (the sign bit marching cubes
 // needs, lt_mc.hip)
+// `fresh`: the voxel's column has not been written since the last reset, so the old values are the initial ones
+// (tsdf 1, weight 0, colour 0, remission 0) and need not be loaded
 template <bool MERGE>
 __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
                                             float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
-                                            float dist, float obs_weight, float new_color, float new_rem) {
+                                            float dist, float obs_weight, float new_color, float new_rem,
+                                            bool fresh = false) {
   if (!MERGE) {
-    const float w_old = weight_vol[voxel_idx];
+    const float w_old = fresh ? 0.0f : weight_vol[voxel_idx];
     const float w_new = w_old + obs_weight;
     weight_vol[voxel_idx] = w_new;
-    const float tv = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+    const float tv = __fmaf_rn(fresh ? 1.0f : tsdf_vol[voxel_idx], w_old, dist) / w_new;
     tsdf_vol[voxel_idx] = tv;
-    const float old_color = color_vol[voxel_idx];
+    const float old_color = fresh ? 0.0f : color_vol[voxel_idx];
     const float old_b = floorf(old_color / (256 * 256));
     const float old_g = floorf((old_color - old_b * 256 * 256) / 256);
     const float old_r = old_color - old_b * 256 * 256 - old_g * 256;
@@ -68,18 +71,18 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
     new_g = fminf(roundf(__fmaf_rn(old_g, w_old, new_g) / w_new), 255.0f);
     new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
     color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
-    rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+    rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
     return tv < 0.0f ? 2 : 1;
   } else {
-    const float dist_old = weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
-    const float old_color = color_vol[voxel_idx];
+    const float dist_old = fresh ? 0.0f : weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
+    const float old_color = fresh ? 0.0f : color_vol[voxel_idx];
     if (old_color == new_color) {  // same class: integrate
-      const float w_old = weight_vol[voxel_idx];
+      const float w_old = fresh ? 0.0f : weight_vol[voxel_idx];
       const float w_new = w_old + obs_weight;
       weight_vol[voxel_idx] = w_new;
-      const float tv = __fmaf_rn(tsdf_vol[voxel_idx], w_old, dist) / w_new;
+      const float tv = __fmaf_rn(fresh ? 1.0f : tsdf_vol[voxel_idx], w_old, dist) / w_new;
       tsdf_vol[voxel_idx] = tv;
-      rem_vol[voxel_idx] = __fmaf_rn(rem_vol[voxel_idx], w_old, new_rem) / w_new;
+      rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
       return tv < 0.0f ? 2 : 1;
     } else if (dist < dist_old) {  // other class: the closer observation wins
       tsdf_vol[voxel_idx] = dist;
@@ -180,7 +183,7 @@ __device__ __forceinline__ int tsdf_voxel(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch) {
+    unsigned epoch, bool fresh) {
   // voxel grid coordinates -- float division exactly as the reference (:95-98); beyond 2^24 voxels (float)voxel_idx
   // is rounded, which moves a few voxels next to an x boundary to (x + 1, -1, z): those are not a column of the table
   const float voxel_x = floorf(((float)voxel_idx) / ((float)(vol_dim_y * vol_dim_z)));
@@ -223,13 +226,46 @@ __device__ __forceinline__ int tsdf_voxel(
   // the column this voxel's MEMORY belongs to becomes dirty (in_table: (ix, iy, z) is the true decomposition)
   col_epoch[in_table ? ix * vol_dim_y + iy : voxel_idx / vol_dim_z] = epoch;
   return tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight,
-                            color_im[py * im_w + px], rem_im[py * im_w + px]);
+                            color_im[py * im_w + px], rem_im[py * im_w + px], fresh);
 }
 
-// A wave looks at the table entries of 64 voxel columns at once and then walks only the columns that are not dead,
-// dim_z voxels each with z along the lanes (the memory order: coalesced).  Columns with y = dim_y - 1 are always
-// walked: they are where the reference's float voxel index can misplace a voxel into the (x + 1, -1) column, which the
-// table does not describe -- tsdf_voxel() handles every voxel by the reference's own decomposition.
+// z range [z0, z1) of the voxel column (cx, cy) that can lie inside the vertical field of view -- conservative: the
+// voxels left out would take tsdf_voxel's sine exit -- pt_z in [rho tan(fov_down) - pad, rho tan(fov_up) + pad].  The
+// whole column for y = dim_y - 1 (its voxels may belong to another (x, y) by the reference's float index) and when the
+// field of view is too steep for tangents.
+struct col_geom {
+  int dim_y, dim_z;
+  float ox, oy, oz, voxel_size, tan_up, tan_down;
+  int tan_ok;
+};
+__device__ __forceinline__ void col_zrange(const col_geom& G, int cx, int cy, int& z0, int& z1) {
+  z0 = 0;
+  z1 = G.dim_z;
+  if (cy != G.dim_y - 1 && G.tan_ok) {
+    const float pt_x = __fmaf_rn((float)cx, G.voxel_size, G.ox), pt_y = __fmaf_rn((float)cy, G.voxel_size, G.oy);
+    const float rho = sqrtf(pt_x * pt_x + pt_y * pt_y);
+    const float pad = 2.0f * G.voxel_size + 1e-3f * rho;
+    const float zl = (rho * G.tan_down - pad - G.oz) / G.voxel_size, zh = (rho * G.tan_up + pad - G.oz) / G.voxel_size;
+    z0 = max(0, (int)floorf(fminf(fmaxf(zl, -1.0f), (float)G.dim_z)));
+    z1 = min(G.dim_z, (int)ceilf(fminf(fmaxf(zh, -1.0f), (float)G.dim_z)) + 1);
+  }
+}
+
+// the n-th (0-based) set bit of m, or -1
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
+  for (int k = 0; k < n; ++k) m &= m - 1;
+  return m ? __ffsll((long long)m) - 1 : -1;
+}
+
+// A wave looks at the table entries of 64 voxel columns at once and then walks only the columns that are not dead:
+// FOUR columns at a time, 16 lanes each with z along the lanes (a column's walk is a chain of dependent loads -- table
+// entry, depth pixel, the voxel's fields -- and only the z range inside the field of view, 20 - 60 voxels, has work:
+// one column per wave iteration left the kernel latency-bound at 0.66 ms for the default volume).  Columns with
+// y = dim_y - 1 are always walked, whole: they are where the reference's float voxel index can misplace a voxel into
+// the (x + 1, -1) column, which the table does not describe -- tsdf_voxel() handles every voxel by the reference's own
+// decomposition.  The signs of the values written update the column's sign bits (bit b of word k = voxel z = 64 k + b
+// is negative), which marching cubes reads instead of the float field; a 16-aligned chunk of z lies inside one word and
+// only this quarter wave works on this column, so the read-modify-write needs no atomic.
 template <bool MERGE>
 __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
@@ -237,68 +273,74 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch, float tan_up, float tan_down, int tan_ok, unsigned long long* __restrict__ sign_bits, int words_z) {
-  const int lane = threadIdx.x & 63;
+    unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_cols = vol_dim_x * vol_dim_y;
   const int n_chunks = (n_cols + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
     const int c = chunk * 64 + lane;
-    bool live = false;
-    if (c < n_cols) live = colinfo[c] != -1 || (c % vol_dim_y) == vol_dim_y - 1;
+    bool live = false, written = false;
+    if (c < n_cols) {
+      live = colinfo[c] != -1 || (c % vol_dim_y) == vol_dim_y - 1;
+      written = col_epoch[c] == epoch;  // before this launch: its voxels hold something else than the initial values
+    }
     unsigned long long m = __ballot(live);
+    const unsigned long long wm = __ballot(written);
     while (m) {
-      const int cc = chunk * 64 + (__ffsll((long long)m) - 1);
-      m &= m - 1;
-      // z range of the column that can lie inside the vertical field of view (wave-uniform, conservative: the voxels
-      // left out would take tsdf_voxel's sine exit): pt_z in [rho tan(fov_down) - pad, rho tan(fov_up) + pad].  Not
-      // for the y = dim_y - 1 columns, whose voxels may belong to another (x, y) by the reference's float index.
-      int z0 = 0, z1 = vol_dim_z;
-      const int cx = cc / vol_dim_y, cy = cc - cx * vol_dim_y;
-      if (cy != vol_dim_y - 1 && tan_ok) {
-        const float pt_x = __fmaf_rn((float)cx, voxel_size, ox), pt_y = __fmaf_rn((float)cy, voxel_size, oy);
-        const float rho = sqrtf(pt_x * pt_x + pt_y * pt_y);
-        const float pad = 2.0f * voxel_size + 1e-3f * rho;
-        const float zl = (rho * tan_down - pad - oz) / voxel_size, zh = (rho * tan_up + pad - oz) / voxel_size;
-        z0 = max(0, (int)floorf(fminf(fmaxf(zl, -1.0f), (float)vol_dim_z)));
-        z1 = min(vol_dim_z, (int)ceilf(fminf(fmaxf(zh, -1.0f), (float)vol_dim_z)) + 1);
+      const int bit = nth_set_bit(m, grp);  // this quarter wave's column of the next four
+      m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
+      int z0 = 0, z1 = 0, cc = 0;
+      const bool fresh = bit >= 0 && !((wm >> bit) & 1ull);
+      if (bit >= 0) {
+        cc = chunk * 64 + bit;
+        const int cx = cc / vol_dim_y;
+        col_zrange(G, cx, cc - cx * vol_dim_y, z0, z1);
       }
-      // z in word-aligned chunks of 64 (the lanes): the signs of the values written update ONE word of the column's
-      // sign bits, which marching cubes reads instead of the float field (bit b of word k = voxel z = 64 k + b is
-      // negative); only this wave works on this column, so the read-modify-write needs no atomic
-      for (int zc = z0 & ~63; zc < z1; zc += 64) {
-        const int z = zc + lane;
+      // (uniform trip count over the wave: the ballots below need every lane)
+      int trips = (z1 - (z0 & ~15) + 15) >> 4;
+      trips = max(trips, __shfl_xor(trips, 16, 64));
+      trips = max(trips, __shfl_xor(trips, 32, 64));
+      for (int k = 0; k < trips; ++k) {
+        const int zc = (z0 & ~15) + 16 * k, z = zc + gl;
         int code = 0;
         if (z >= z0 && z < z1)
           code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
                                    vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
-                                   fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch);
-        const unsigned long long wrote = __ballot(code != 0), neg = __ballot(code == 2);
-        if (wrote && lane == 0) {
+                                   fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch,
+                                   fresh);
+        const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2);
+        const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
+        if (wrote && gl == 0) {
           unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
-          *w = (*w & ~wrote) | neg;
+          const int sh = zc & 63;
+          *w = (*w & ~(wrote << sh)) | (neg << sh);
         }
       }
     }
   }
 }
 
-// re-initialise the dirty columns: a wave reads 64 stamps at once and walks the dirty columns
+// re-initialise the dirty columns -- the z range integrate can have written -- and their sign words: a wave reads 64
+// stamps at once and walks the dirty columns
 __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
                                                          float* __restrict__ color, float* __restrict__ rem,
-                                                         int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
+                                                         int n_cols, col_geom G, const unsigned* __restrict__ col_epoch,
                                                          unsigned epoch, unsigned long long* __restrict__ sign_bits) {
   const int lane = threadIdx.x & 63;
   const int n_chunks = (n_cols + 63) / 64;
-  const int words_z = (dim_z + 63) / 64;
+  const int words_z = (G.dim_z + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
     const int c = chunk * 64 + lane;
     unsigned long long m = __ballot(c < n_cols && col_epoch[c] == epoch);
     while (m) {
       const int cc = chunk * 64 + (__ffsll((long long)m) - 1);
-      const size_t base = (size_t)cc * dim_z;
+      const size_t base = (size_t)cc * G.dim_z;
       m &= m - 1;
       if (lane < words_z) sign_bits[(size_t)cc * words_z + lane] = 0ull;
-      for (int z = lane; z < dim_z; z += 64) {
+      int z0, z1;
+      const int cx = cc / G.dim_y;
+      col_zrange(G, cx, cc - cx * G.dim_y, z0, z1);
+      for (int z = z0 + lane; z < z1; z += 64) {
         tsdf[base + z] = 1.0f;
         weight[base + z] = 0.0f;
         color[base + z] = 0.0f;
@@ -317,6 +359,21 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
     if (p) (void)hipFree(p);
   free(t);
   return LT_OK;
+}
+
+// geometry of the per-column z range: slopes of the field of view with the 1e-5 margin of the sine test on the angles;
+// off for fields of view beyond +-80 degrees
+static col_geom tsdf_geom(const lt_tsdf* t) {
+  const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
+  const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
+  col_geom G;
+  G.dim_y = t->dim[1]; G.dim_z = t->dim[2];
+  G.ox = t->origin[0]; G.oy = t->origin[1]; G.oz = t->origin[2];
+  G.voxel_size = t->voxel_size;
+  G.tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
+  G.tan_up = G.tan_ok ? (float)tan((double)fu + 1e-5) : 0.f;
+  G.tan_down = G.tan_ok ? (float)tan((double)fd - 1e-5) : 0.f;
+  return G;
 }
 
 static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
@@ -341,7 +398,7 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
   const int n_cols = t->dim[0] * t->dim[1];
   hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits);
+                     t->tsdf, t->weight, t->color, t->rem, n_cols, tsdf_geom(t), t->col_epoch, t->epoch, t->bits);
   LT_HIP(hipGetLastError());
   t->epoch += 1;  // every stamp is stale now: nothing to clear
   return LT_OK;
@@ -451,20 +508,18 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
                      t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo);
   // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
-  // slopes of the per-column z range (same 1e-5 margin on the angles); off for fields of view beyond +-80 degrees
-  const int tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
-  const float tu = tan_ok ? (float)tan((double)fu + 1e-5) : 0.f, td = tan_ok ? (float)tan((double)fd - 1e-5) : 0.f;
+  const col_geom G = tsdf_geom(t);
   const unsigned nbc = (unsigned)min((n_cols + 255) / 256, 16384);  // 64 columns per wave and trip
   if (flags & LT_TSDF_MERGE)
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, tu, td, tan_ok, t->bits, (t->dim[2] + 63) / 64);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, tu, td, tan_ok, t->bits, (t->dim[2] + 63) / 64);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }

@@ -230,6 +230,18 @@ def render():
     for r0 in range(0, len(flat), 24):
         lines.append(" ".join(f"{x}," for x in flat[r0:r0 + 24]))
     lines.append("};")
+    lines.append("/* the same, one 128-bit word per case: bits 0..2 = number of triangles, bits 8 + 5 i .. 12 + 5 i = edge code i")
+    lines.append(" * (i = 3 * triangle + corner): one load hands a lane its whole cell */")
+    lines.append("LT_TABLE_ATTR static const unsigned long long LT_MC_PACKED[512] = {")
+    for c0 in range(0, 256, 2):
+        parts = []
+        for c in (c0, c0 + 1):
+            v = len(rows[c])
+            for i, code in enumerate(x for t in rows[c] for x in t):
+                v |= code << (8 + 5 * i)
+            parts.append("0x%016xull, 0x%016xull," % (v & ((1 << 64) - 1), v >> 64))
+        lines.append(" ".join(parts))
+    lines.append("};")
     lines.append("#endif")
     return "\n".join(lines) + "\n"
 
