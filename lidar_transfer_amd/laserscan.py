@@ -185,14 +185,21 @@ class SemLaserScan(LaserScan):
         o = self._last
         mask = self.proj_idx >= 0
         self.proj_label = np.where(mask, o["labi"], 0).astype(np.int32)
-        self.proj_color = np.where(mask[:, :, None], self._color_of(o), 0.0)
+        self.proj_color = np.where(mask[:, :, None], self._color_of(o, mask), 0.0)
 
     def do_label_projection_new(self):
         """laserscan.py:672-676."""
         o = self._last
         mask = self.index >= 0
         self.proj_label = np.where(mask, o["labi"], 0).astype(np.int32)
-        self.proj_color = np.where(mask[:, :, None], self._color_of(o), 0.0)
+        self.proj_color = np.where(mask[:, :, None], self._color_of(o, mask), 0.0)
 
-    def _color_of(self, o):
-        return self.color_lut[np.clip(o["labi"], 0, self.color_lut.shape[0] - 1)].astype(np.float64)
+    def _color_of(self, o, mask):
+        """``color_lut[label[...]]`` of the occupied cells; like the reference's fancy indexing (laserscan.py:649, :676)
+        a label beyond the look-up table raises IndexError instead of being mapped to some other class."""
+        lab = np.asarray(o["labi"])
+        n = self.color_lut.shape[0]
+        bad = mask & ((lab < 0) | (lab >= n))
+        if bad.any():
+            raise IndexError(f"index {int(lab[bad].reshape(-1)[0])} is out of bounds for axis 0 with size {n}")
+        return self.color_lut[np.where(mask, lab, 0)].astype(np.float64)

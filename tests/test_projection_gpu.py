@@ -204,3 +204,22 @@ def test_projection_fuzz_vs_cpu_restatement(seed):
         if scan.points.shape[0] == o["kept"].shape[0]:
             bad = (got_index != o["index"]) | (np.asarray(got_range).view(np.int32) != o["range"].view(np.int32))
             assert int(bad.sum()) <= 6, f"{int(bad.sum())} cells differ"
+
+
+def test_label_beyond_the_colour_table_raises_like_the_reference():
+    """`proj_color[mask] = color_lut[label[idx[mask]]]` (laserscan.py:649, :676) raises IndexError for a label the
+    look-up table does not hold; the mirror must not map it to some other class."""
+    from lidar_transfer_amd.laserscan import SemLaserScan
+    from lidar_transfer_amd.synth import synth_cloud
+    pts, rem, lab = synth_cloud(3, 5000, dtype=np.float32)
+    scan = SemLaserScan(16, 128, 300, COLOR_DICT, None, None)
+    scan.points, scan.remissions, scan.label = pts, rem, lab.copy()
+    scan.do_range_projection(3.0, -25.0, remove=True)
+    scan.do_label_projection()                           # fine: every label is inside the table (size 80 + 1 + 100)
+    assert scan.proj_color.shape == (16, 128, 3)
+    bad = SemLaserScan(16, 128, 300, COLOR_DICT, None, None)
+    bad.points, bad.remissions, bad.label = pts.copy(), rem.copy(), lab.copy()
+    bad.label[::7] = 100000
+    bad.do_range_projection(3.0, -25.0, remove=True)
+    with pytest.raises(IndexError):
+        bad.do_label_projection()
