@@ -371,6 +371,10 @@ __device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, i
   return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
 }
 
+// Box of the sorted leaves [a, b]: the standard bottom-up walk over the heap-ordered segment tree.  (Issuing the loads
+// of several levels together -- which nodes the walk takes depends on a and b only -- was measured: four levels per
+// batch cut the mean wave life from 31 to 24 us but cost 86 VGPRs and a third round of workgroups, 122 us instead of
+// 110; two levels per batch, 56 VGPRs, changed nothing.)
 __device__ __forceinline__ void range_box(const float4* __restrict__ seg, int np, int a, int b, float4& lo,
                                           float4& hi) {
   lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
@@ -476,8 +480,17 @@ __device__ __forceinline__ void put_entry(float4* __restrict__ O, int k, const f
 }
 
 __global__ __launch_bounds__(256) void k_hierarchy4(const uint32_t* __restrict__ keys, int n, int np,
-                                                    const float4* __restrict__ seg, float4* __restrict__ nodes4) {
+                                                    const float4* __restrict__ seg, float4* __restrict__ nodes4,
+                                                    unsigned long long* __restrict__ dbg) {
   __shared__ uint32_t wkeys[256 + 2 * LT_HWIN];
+  const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;
+  struct dbg_stamp {  // debug (LIDARHIP_DEBUG_HIER=1): start / duration of every wave at 100 MHz
+    unsigned long long* d; unsigned long long t0;
+    __device__ ~dbg_stamp() {
+      const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+      if (d && (threadIdx.x & 63) == 0 && wg < LT_DBG_WAVES) { d[8 + 2 * wg] = t0; d[8 + 2 * wg + 1] = (unsigned long long)wall_clock64() - t0; }
+    }
+  } stamp{dbg, t_dbg};
   const int i0 = blockIdx.x * 256;
   key_window kw;
   kw.lds = wkeys; kw.keys = keys; kw.n = n;
@@ -591,8 +604,9 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
       hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n, np,
                          s->seg, s->nodes);
     } else {
+      static const bool dbg_hier = getenv("LIDARHIP_DEBUG_HIER") != nullptr;
       hipLaunchKernelGGL(k_hierarchy4, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n,
-                         np, s->seg, s->nodes4);
+                         np, s->seg, s->nodes4, dbg_hier ? s->counters : nullptr);
     }
     LT_MARK();  // 6
     LT_HIP(hipGetLastError());

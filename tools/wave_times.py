@@ -65,3 +65,20 @@ if "--quad" in sys.argv:
     print("  steps per ray (node + leaf): mean %.1f p50 %d p90 %d p98 %d p99 %d p99.9 %d max %d" % (steps.mean(), *[np.percentile(steps, p) for p in (50, 90, 98, 99, 99.9)], steps.max()))
     for cap in (32, 40, 48, 64):
         print("    rays beyond %d steps: %.2f %%" % (cap, 100.0 * (steps > cap).mean()))
+
+# ---- k_hierarchy4 (LIDARHIP_DEBUG_HIER=1): wall-clock stamps per wave (first 16384 waves = 1 M nodes)
+if "--hier" in sys.argv:
+    sc.set_mesh(*mesh); sc.build(); torch.cuda.synchronize()
+    nw = 15624
+    buf = np.zeros(2 * nw, np.uint64)
+    assert lib.lt_debug_wave_times(sc._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
+    t = buf.reshape(nw, 2)
+    start = (t[:, 0] - t[:, 0].min()).astype(np.int64) / 100.0
+    dur = t[:, 1].astype(np.int64) / 100.0
+    end = start + dur
+    print("k_hierarchy4: waves %d, span %.1f us" % (nw, end.max()))
+    for name, a in (("start", start), ("duration", dur), ("end", end)):
+        print("  %-10s mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f p99.9 %8.1f max %8.1f" % (name, a.mean(), *[np.percentile(a, p) for p in (50, 90, 99, 99.9)], a.max()))
+    order = np.argsort(-dur)[:10]
+    print("  slowest waves (wave, start, duration us):", [(int(i), round(float(start[i]), 1), round(float(dur[i]), 1)) for i in order])
+    print("  busy fraction over the span: %.3f" % (dur.sum() / 8192 / end.max()))
