@@ -713,7 +713,8 @@ def main():
                         "measured_wire_GBs": PCIE_WIRE_GBS, "frac_of_wire": round(h2d / t / 1e9 / PCIE_WIRE_GBS, 4),
                         "note": "upload bytes per scan / time per scan; the link is full duplex and the downloads "
                                 "run under the uploads"}, "hits": m["hits"],
-               "uploader_thread_ms_per_scan": m.get("worker_upload_ms")}
+               "uploader_thread_ms_per_scan": m.get("worker_upload_ms"),
+               "single_call_ms_in_this_process": m.get("single_call_ms")}
         if res.get("in_torch_process"):
             out["in_torch_process"] = {"ms_per_scan": res["in_torch_process"]["ms_per_scan"],
                                        "GBs": res["in_torch_process"]["GBs"],

@@ -162,12 +162,25 @@ __device__ __forceinline__ u64 wave_incl_scan(u64 p) {
 }
 
 // ---- k_mc_words -----------------------------------------------------------------------------------------------------
+// a word can only own a crossing edge or an active cell if its row (x, y) or one of the rows (x, y + 1), (x + 1, y),
+// (x + 1, y + 1) was written since the volume's last reset; the stamps are 4 B per row against 8 sign words per thread
+__device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_epoch, unsigned epoch, const mc_dims& D,
+                                              int row) {
+  if (!col_epoch) return true;
+  const int last = D.nx * D.ny - 1;
+  return col_epoch[row] == epoch || col_epoch[min(row + 1, last)] == epoch || col_epoch[min(row + D.ny, last)] == epoch ||
+         col_epoch[min(row + D.ny + 1, last)] == epoch;
+}
+
 __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
-                                                  int* __restrict__ blk) {
+                                                  int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
+                                                  unsigned epoch) {
   __shared__ u64 wsum[4];
   const int w = blockIdx.x * 256 + threadIdx.x;
   unsigned nv = 0, nt = 0;
-  if (w < D.n_words) {
+  if (w < D.n_words && !mc_rows_dirty(col_epoch, epoch, D, w / D.wz)) {
+    cnt[w] = 0u;
+  } else if (w < D.n_words) {
     const int row = w / D.wz, wz = w - row * D.wz;
     const int x = row / D.ny, y = row - x * D.ny;
     const mc_masks M = mc_load(bits, D, x, y, wz);
@@ -529,7 +542,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
                        tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
-  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk);
+  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
+                     epoch);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));

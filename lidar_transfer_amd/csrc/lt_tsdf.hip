@@ -223,8 +223,6 @@ __device__ __forceinline__ int tsdf_voxel(
   const float depth_diff = depth_value - depth;
   if (depth_diff < -trunc_margin) return 0;
   const float dist = fminf(1.0f, depth_diff / trunc_margin);
-  // the column this voxel's MEMORY belongs to becomes dirty (in_table: (ix, iy, z) is the true decomposition)
-  col_epoch[in_table ? ix * vol_dim_y + iy : voxel_idx / vol_dim_z] = epoch;
   return tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight,
                             color_im[py * im_w + px], rem_im[py * im_w + px], fresh);
 }
@@ -273,7 +271,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z) {
+    unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
+    unsigned* __restrict__ col_zw) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_cols = vol_dim_x * vol_dim_y;
   const int n_chunks = (n_cols + 63) / 64;
@@ -296,6 +295,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
         const int cx = cc / vol_dim_y;
         col_zrange(G, cx, cc - cx * vol_dim_y, z0, z1);
       }
+      int wz_lo = 0x7fff, wz_hi = -1;  // z range this launch writes in the column (any field; uniform over the group)
       // (uniform trip count over the wave: the ballots below need every lane)
       int trips = (z1 - (z0 & ~15) + 15) >> 4;
       trips = max(trips, __shfl_xor(trips, 16, 64));
@@ -310,37 +310,57 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
                                    fresh);
         const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2);
         const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
-        if (wrote && gl == 0) {
-          unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
-          const int sh = zc & 63;
-          *w = (*w & ~(wrote << sh)) | (neg << sh);
+        if (wrote) {
+          wz_lo = min(wz_lo, zc + (__ffsll((long long)wrote) - 1));
+          wz_hi = max(wz_hi, zc + 63 - __clzll((long long)wrote));
+          if (gl == 0) {
+            unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
+            const int sh = zc & 63;
+            *w = (*w & ~(wrote << sh)) | (neg << sh);
+          }
         }
+      }
+      // the column becomes dirty only if something was written: stamp it and widen its written z range (what the next
+      // reset has to re-initialise); this quarter wave owns the column, no atomics
+      if (bit >= 0 && wz_hi >= 0 && gl == 0) {
+        if (!fresh) {
+          const unsigned old = col_zw[cc];
+          wz_lo = min(wz_lo, (int)(old & 0xFFFFu));
+          wz_hi = max(wz_hi, (int)(old >> 16));
+        }
+        col_zw[cc] = (unsigned)wz_lo | ((unsigned)wz_hi << 16);
+        col_epoch[cc] = epoch;
       }
     }
   }
 }
 
-// re-initialise the dirty columns -- the z range integrate can have written -- and their sign words: a wave reads 64
-// stamps at once and walks the dirty columns
+// re-initialise the dirty columns -- the z range that was actually written (col_zw, kept by integrate) -- and their sign
+// words: a wave reads 64 stamps at once and walks the dirty columns, four at a time (16 lanes each: a written range is
+// typically the truncation band, ~10 voxels)
 __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
                                                          float* __restrict__ color, float* __restrict__ rem,
-                                                         int n_cols, col_geom G, const unsigned* __restrict__ col_epoch,
-                                                         unsigned epoch, unsigned long long* __restrict__ sign_bits) {
-  const int lane = threadIdx.x & 63;
+                                                         int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
+                                                         unsigned epoch, unsigned long long* __restrict__ sign_bits,
+                                                         const unsigned* __restrict__ col_zw) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_chunks = (n_cols + 63) / 64;
-  const int words_z = (G.dim_z + 63) / 64;
+  const int words_z = (dim_z + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
     const int c = chunk * 64 + lane;
-    unsigned long long m = __ballot(c < n_cols && col_epoch[c] == epoch);
+    const bool dirty = c < n_cols && col_epoch[c] == epoch;
+    const unsigned zw = dirty ? col_zw[c] : 0u;
+    if (dirty)
+      for (int k = 0; k < words_z; ++k) sign_bits[(size_t)c * words_z + k] = 0ull;
+    unsigned long long m = __ballot(dirty);
     while (m) {
-      const int cc = chunk * 64 + (__ffsll((long long)m) - 1);
-      const size_t base = (size_t)cc * G.dim_z;
-      m &= m - 1;
-      if (lane < words_z) sign_bits[(size_t)cc * words_z + lane] = 0ull;
-      int z0, z1;
-      const int cx = cc / G.dim_y;
-      col_zrange(G, cx, cc - cx * G.dim_y, z0, z1);
-      for (int z = z0 + lane; z < z1; z += 64) {
+      const int bit = nth_set_bit(m, grp);
+      m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
+      const unsigned r = __shfl(zw, max(bit, 0), 64);  // (every lane takes part: the source lane must be active)
+      if (bit < 0) continue;
+      const int z0 = (int)(r & 0xFFFFu), z1 = min((int)(r >> 16), dim_z - 1);
+      const size_t base = (size_t)(chunk * 64 + bit) * dim_z;
+      for (int z = z0 + gl; z <= z1; z += 16) {
         tsdf[base + z] = 1.0f;
         weight[base + z] = 0.0f;
         color[base + z] = 0.0f;
@@ -354,7 +374,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits};
+  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -398,7 +418,7 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
   const int n_cols = t->dim[0] * t->dim[1];
   hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     t->tsdf, t->weight, t->color, t->rem, n_cols, tsdf_geom(t), t->col_epoch, t->epoch, t->bits);
+                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits, t->col_zw);
   LT_HIP(hipGetLastError());
   t->epoch += 1;  // every stamp is stale now: nothing to clear
   return LT_OK;
@@ -448,6 +468,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->colinfo, n_cols * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&t->col_zw, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
     lt_tsdf_destroy(t);
@@ -514,12 +535,12 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }

@@ -43,10 +43,22 @@ with HostScanPipeline(rays, H, depth=depth) as pipe:
     base = tr[rows[0], 0]
     for rI in rows:
         sys.stderr.write("ticket%%256=%3d submit %7.3f | issue %7.3f upload_end %7.3f issue_end %7.3f | collect %7.3f .. %7.3f\n" % ((rI,) + tuple((tr[rI] - base) * 1e3)))
+# the single drop-in call in the same process (for comparison: same runtime, same arrays, int32 colours as ctrace takes them)
+from lidar_transfer_amd.raytracer import C_Trace
+v, f, c8, r = host[0]
+c32 = np.ascontiguousarray(c8.astype(np.int32)).reshape(-1)
+R = H * W
+ts = []
+for i in range(14):
+    ep = np.zeros(3 * R, np.float32); ec = np.zeros(3 * R, np.int32); rg = np.zeros(R, np.float32); rm = np.zeros(R, np.float32)
+    t0s = time.perf_counter()
+    C_Trace(rays.reshape(-1), org, v.reshape(-1), f.reshape(-1), c32, r, ep, ec, rg, rm, H, W)
+    ts.append(time.perf_counter() - t0s)
+single_ms = float(np.median(ts[2:])) * 1e3
 h2d = sum(a.nbytes for a in host[0])
 d2h = sum(a.nbytes for a in outs[0].values())
 hits = int((outs[(n - 1) % len(outs)]["range"] > 0).sum())
-print(json.dumps({"h2d_bytes": h2d, "d2h_bytes": d2h, "hits": hits, "n_scans": n, "torch_in_process": "torch" in sys.modules,
+print(json.dumps({"single_call_ms": round(single_ms, 4), "h2d_bytes": h2d, "d2h_bytes": d2h, "hits": hits, "n_scans": n, "torch_in_process": "torch" in sys.modules,
                   "depth": depth, "meshes": n_meshes, "outputs": "range" if few_out else "all", "ms_per_scan": round(dt * 1e3, 4), "h2d_MB": round(h2d / 1e6, 2), "GBs": round(h2d / dt / 1e9, 2),
                   "worker_issue_ms": round((t1d[1] - t0d[1]) / n * 1e3, 4), "worker_upload_ms": round((t1d[2] - t0d[2]) / n * 1e3, 4),
                   "caller_collect_ms": round((t1d[3] - t0d[3]) / n * 1e3, 4)}))
