@@ -733,7 +733,8 @@ def main():
                  "roofline": roofline(oname, serial_probe_ms(oname, n=12), okern)}
 
     iso_ms = isolated_kernel_ms(args.strategy)
-    e2e = e2e_host_call() if (rank == 0 and not args.no_e2e) else None
+    # the PCIe-inclusive clocks and the fusion chain are single-GPU records (like cpu_baseline): rank 0 at N = 1 only
+    e2e = e2e_host_call() if (rank == 0 and world == 1 and not args.no_e2e) else None
     if e2e:
         e2e = {"single_call": e2e, "pipelined": e2e_pipelined()}
     chain = fusion_chain() if (rank == 0 and not args.no_chain and world == 1) else None
