@@ -105,7 +105,7 @@ extern "C" int lt_scene_create(lt_scene** out, int device) {
   int rc = dev_alloc(&s->partial, 6 * LT_BOUNDS_BLOCKS);
   if (rc == LT_OK) rc = dev_alloc(&s->params, 8);
   if (rc == LT_OK) rc = dev_alloc(&s->flags, 4);
-  if (rc == LT_OK) rc = dev_alloc(&s->counters, 8 + 2 * LT_DBG_WAVES);
+  if (rc == LT_OK) rc = dev_alloc(&s->counters, 8 + 4 * LT_DBG_WAVES);
   if (rc == LT_OK && hipMemset(s->flags, 0, 4 * sizeof(unsigned)) != hipSuccess) rc = LT_ERR_HIP;
   for (int k = 0; rc == LT_OK && k < 10; ++k) {
     if (hipEventCreate(&s->ev[k]) != hipSuccess) {
@@ -238,7 +238,7 @@ extern "C" int lt_scene_trace_dev(lt_scene* s, const float* rays, const float* o
 
 // debug helper (not part of the documented ABI): wave start/end clocks of the last LT_TRACE_COUNT launch
 extern "C" int lt_debug_wave_times(lt_scene* s, unsigned long long* out, int n_waves) {
-  if (!s || !out || n_waves < 0 || n_waves > LT_DBG_WAVES) return LT_ERR_INVALID_ARG;
+  if (!s || !out || n_waves < 0 || n_waves > 2 * LT_DBG_WAVES) return LT_ERR_INVALID_ARG;
   LT_HIP(hipSetDevice(s->device));
   LT_HIP(hipDeviceSynchronize());
   LT_HIP(hipMemcpy(out, s->counters + 8, (size_t)n_waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

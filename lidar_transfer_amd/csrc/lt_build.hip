@@ -443,103 +443,370 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint32_t* __restrict__ 
 // Node i finds its own key range and split as k_hierarchy does; because the ranges of its two children
 // are then known, their splits need no range search -- one binary search each -- and the up to four
 // grandchild ranges become the entries of the 128-B node.  The sorted keys around the workgroup are
-// staged in LDS: most searches never leave that window, which removes the dependent L2 round trips that
-// dominated the binary kernel.
-#define LT_HWIN 512  // keys staged on each side of the workgroup's 256 nodes
+// staged in LDS and every search of k_hierarchy4 stays inside that window.
+#define LT_HWIN 512  // keys staged on each side of the workgroup's nodes (>= 2 LT_HBIG)
 
 struct key_window {
-  const uint32_t* lds;   // window copy
-  const uint32_t* keys;  // global sorted keys
-  int lo, hi, n;         // window = [lo, hi)
+  const uint32_t* lds;  // window copy
+  int lo, hi, n;        // window = [lo, hi) of the n sorted keys
 };
-
-__device__ __forceinline__ uint32_t kw_key(const key_window& kw, int j) {
-  return (j >= kw.lo && j < kw.hi) ? kw.lds[j - kw.lo] : kw.keys[j];
-}
-__device__ __forceinline__ int kw_delta(const key_window& kw, int i, uint32_t ki, int j) {
-  if (j < 0 || j >= kw.n) return -1;
-  const uint32_t kj = kw_key(kw, j);
-  return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
-}
-// split of the key range [a, b] (b > a): largest g in [a, b) with delta(a, g) > delta(a, b) ... Karras 2012
-__device__ __forceinline__ int kw_split(const key_window& kw, int a, int b) {
-  const uint32_t ka = kw_key(kw, a);
-  const int dn = kw_delta(kw, a, ka, b);
-  const int l = b - a;
-  int s = 0;
-  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-    if (s + t < l && kw_delta(kw, a, ka, a + s + t) > dn) s += t;
-    if (t == 1) break;
-  }
-  return a + s;
-}
 
 __device__ __forceinline__ void put_entry(float4* __restrict__ O, int k, const float4 lo, const float4 hi, int ref) {
   O[2 * k] = make_float4(lo.x, lo.y, lo.z, hi.x);
   O[2 * k + 1] = make_float4(hi.y, hi.z, __int_as_float(ref), 0.f);
 }
 
-__global__ __launch_bounds__(256) void k_hierarchy4(const uint32_t* __restrict__ keys, int n, int np,
-                                                    const float4* __restrict__ seg, float4* __restrict__ nodes4,
-                                                    unsigned long long* __restrict__ dbg) {
-  __shared__ uint32_t wkeys[256 + 2 * LT_HWIN];
-  const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;
-  struct dbg_stamp {  // debug (LIDARHIP_DEBUG_HIER=1): start / duration of every wave at 100 MHz
-    unsigned long long* d; unsigned long long t0;
-    __device__ ~dbg_stamp() {
-      const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
-      if (d && (threadIdx.x & 63) == 0 && wg < LT_DBG_WAVES) { d[8 + 2 * wg] = t0; d[8 + 2 * wg + 1] = (unsigned long long)wall_clock64() - t0; }
+// What bounds this kernel is the LONGEST chain in a wave, not the work: splits are binary searches and range boxes are
+// level-by-level walks, both ~log2(range) steps, and every 64 consecutive Karras nodes hold ranges of all sizes.  The
+// one-thread-per-node kernel (round 1) ran 15 624 waves of ~30 us in two rounds, the slowest 90 us, 110 us in all
+// (per-wave wall-clock stamps: LIDARHIP_DEBUG_HIER=1 python tools/wave_times.py --hier).  Now, on the 1 M-triangle mesh:
+//   * a workgroup takes LT_HNODES consecutive nodes.  Phase 1a (3 probes a node) finds the survivors: three quarters of
+//     all Karras nodes span <= LT_LEAF_MAX leaves, are swallowed by a leaf of an ancestor and end there.  Phase 1b finds
+//     the survivors' key ranges with every lane busy; nodes spanning more than LT_HBIG leaves are QUEUED for
+//     k_hierarchy4_big -- one device-scope atomic per WORKGROUP (one per wave and pass, 12 000 on one hot word served at
+//     ~130 per us, was a quarter of the kernel).  Phase 2 -- splits, grandchild ranges, range boxes -- walks the four
+//     boxes of a node TOGETHER (range_box4): 128 VGPRs, which is exactly what keeps all 977 workgroups resident at once.
+//     Stamps: phase 1 ends at 14 us, the splits at 22 us, the boxes (<= 8 levels x ~1.5 us of memory-side latency: the
+//     64 MB segment tree is cold) at 34 us mean / 49 us max: 49 us.
+//   * k_hierarchy4_big gives each of the ~8 k queued nodes a whole wave: 64-ary range and split searches (64 keys per
+//     round trip, both children's splits side by side in the two half-waves) and range boxes whose 2 x 32 levels are
+//     loaded at once (level l of the walk is closed-form: left ceil(l0 / 2^l), right floor(r0 / 2^l)) and reduced with
+//     shuffles: range 2.7 us, splits 2.2 us, boxes 6.8 us per node, 18 us in all.
+// Measured and rejected: LDS copies of the window's segment-tree levels (occupancy: a second round of workgroups);
+// warming the XCD's L2 with the window's tree lines during phase 1 (85 us instead of 78); LT_HNODES = 256 with four
+// times the workgroups.
+#define LT_HNODES 1024
+#define LT_HBIG 256
+__device__ __forceinline__ int lw_delta(const key_window& kw, int i, uint32_t ki, int j) {
+  if (j < 0 || j >= kw.n) return -1;
+  const uint32_t kj = kw.lds[j - kw.lo];
+  return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
+}
+__device__ __forceinline__ int lw_split(const key_window& kw, int a, int b) {
+  const uint32_t ka = kw.lds[a - kw.lo];
+  const int dn = lw_delta(kw, a, ka, b);
+  const int l = b - a;
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (s + t < l && lw_delta(kw, a, ka, a + s + t) > dn) s += t;
+    if (t == 1) break;
+  }
+  return a + s;
+}
+struct lt_f3 { float x, y, z; };
+// The boxes of up to four sorted-leaf ranges, walked level by level TOGETHER: which heap nodes a walk takes depends on
+// its end points only, so the (up to 8) loads of a level are independent and in flight at once -- the chain is the
+// deepest walk, not the sum of the four.
+__device__ __forceinline__ void range_box4(const float4* __restrict__ seg, int np, const int* a, const int* b,
+                                           float4* lo, float4* hi) {
+  int l[4], r[4];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lo[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+    hi[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    l[k] = a[k] + np;  // (an empty slot has b = a - 1: l == r, no step)
+    r[k] = b[k] + np + 1;
+    any |= l[k] < r[k];
+  }
+  while (any) {
+    lt_f3 tl[8], th[8];  // (12-byte loads: the w lanes of the tree's float4s carry nothing)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool live = l[k] < r[k];
+      const bool tk_l = live && (l[k] & 1), tk_r = live && (r[k] & 1);
+      tl[2 * k] = lt_f3{INFINITY, INFINITY, INFINITY}; th[2 * k] = lt_f3{-INFINITY, -INFINITY, -INFINITY};
+      tl[2 * k + 1] = tl[2 * k]; th[2 * k + 1] = th[2 * k];
+      if (tk_l) { tl[2 * k] = *(const lt_f3*)&seg[2 * (size_t)l[k]]; th[2 * k] = *(const lt_f3*)&seg[2 * (size_t)l[k] + 1]; }
+      if (tk_r) { tl[2 * k + 1] = *(const lt_f3*)&seg[2 * (size_t)(r[k] - 1)]; th[2 * k + 1] = *(const lt_f3*)&seg[2 * (size_t)(r[k] - 1) + 1]; }
+      l[k] = (l[k] + (tk_l ? 1 : 0)) >> 1;
+      r[k] = (r[k] - (tk_r ? 1 : 0)) >> 1;
     }
-  } stamp{dbg, t_dbg};
-  const int i0 = blockIdx.x * 256;
-  key_window kw;
-  kw.lds = wkeys; kw.keys = keys; kw.n = n;
-  kw.lo = max(i0 - LT_HWIN, 0);
-  kw.hi = min(i0 + 256 + LT_HWIN, n);
-  for (int k = threadIdx.x; k < kw.hi - kw.lo; k += 256) wkeys[k] = keys[kw.lo + k];
-  __syncthreads();
-  const int i = i0 + threadIdx.x;
+    any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        lo[k].x = fminf(lo[k].x, tl[2 * k + f].x); lo[k].y = fminf(lo[k].y, tl[2 * k + f].y); lo[k].z = fminf(lo[k].z, tl[2 * k + f].z);
+        hi[k].x = fmaxf(hi[k].x, th[2 * k + f].x); hi[k].y = fmaxf(hi[k].y, th[2 * k + f].y); hi[k].z = fmaxf(hi[k].z, th[2 * k + f].z);
+      }
+      any |= l[k] < r[k];
+    }
+  }
+}
+
+__device__ __forceinline__ void hier_emit(const key_window& kw, const float4* __restrict__ seg, int np,
+                                          float4* __restrict__ nodes4, int i, int first, int last, bool stamp,
+                                          unsigned long long& t_split) {
   const float inf = INFINITY;
   const float4 e_lo = make_float4(inf, inf, inf, 0.f), e_hi = make_float4(inf, inf, inf, 0.f);  // mn = mx = +inf
+  const int g = lw_split(kw, first, last);
+  float4* O = nodes4 + 8 * (size_t)i;
+  // slots 0, 1 belong to the left child, 2, 3 to the right one; a child that is a leaf uses its first slot only (the
+  // other stays an empty range, which the walk skips); entries are written compacted, in slot order
+  int ra[4], rb[4], ref[4];
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const int a = side == 0 ? first : g + 1, b = side == 0 ? g : last;
+    if (b - a + 1 <= LT_LEAF_MAX) {
+      ra[2 * side] = a; rb[2 * side] = b; ref[2 * side] = leaf_ref(a, b - a + 1);
+      ra[2 * side + 1] = 0; rb[2 * side + 1] = -1; ref[2 * side + 1] = 0;
+    } else {
+      const int gc = lw_split(kw, a, b);
+      const int lc = gc - a + 1, rc = b - gc;
+      ra[2 * side] = a; rb[2 * side] = gc; ref[2 * side] = lc <= LT_LEAF_MAX ? leaf_ref(a, lc) : gc;
+      ra[2 * side + 1] = gc + 1; rb[2 * side + 1] = b; ref[2 * side + 1] = rc <= LT_LEAF_MAX ? leaf_ref(gc + 1, rc) : gc + 1;
+    }
+  }
+  if (stamp) t_split = (unsigned long long)wall_clock64();
+  float4 lo[4], hi[4];
+  range_box4(seg, np, ra, rb, lo, hi);
+  int ne = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (rb[k] >= ra[k]) put_entry(O, ne++, lo[k], hi[k], ref[k]);
+  for (; ne < 4; ++ne) put_entry(O, ne, e_lo, e_hi, 0x7fffffff);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_hierarchy4(const uint32_t* __restrict__ keys, int n, int np,
+                                                    const float4* __restrict__ seg, float4* __restrict__ nodes4,
+                                                    int* __restrict__ big_queue, int big_cap, unsigned* __restrict__ big_count,
+                                                    unsigned long long* __restrict__ dbg) {
+  __shared__ uint32_t wkeys[LT_HNODES + 2 * LT_HWIN];
+  __shared__ int sv_i[LT_HNODES], sv_first[LT_HNODES], sv_last[LT_HNODES];
+  __shared__ int n_surv, n_big, n_big_out, big_base;
+  const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;
+  const int i0 = blockIdx.x * LT_HNODES;
+  key_window kw;
+  kw.lds = wkeys; kw.n = n;
+  kw.lo = max(i0 - LT_HWIN, 0);
+  kw.hi = min(i0 + LT_HNODES + LT_HWIN, n);
+  for (int k = threadIdx.x; k < kw.hi - kw.lo; k += 256) wkeys[k] = keys[kw.lo + k];
+  if (threadIdx.x == 0) { n_surv = 0; n_big = 0; n_big_out = 0; }
+  __syncthreads();
   if (n == 1) {
-    if (i == 0) {
+    if (i0 == 0 && threadIdx.x == 0) {
+      const float inf = INFINITY;
+      const float4 e_lo = make_float4(inf, inf, inf, 0.f), e_hi = make_float4(inf, inf, inf, 0.f);
       put_entry(nodes4, 0, seg[2 * (size_t)np], seg[2 * (size_t)np + 1], leaf_ref(0, 1));
       for (int k = 1; k < 4; ++k) put_entry(nodes4, k, e_lo, e_hi, 0x7fffffff);
     }
     return;
   }
-  if (i >= n - 1) return;
-  const uint32_t ki = wkeys[i - kw.lo];
-  const int d = (kw_delta(kw, i, ki, i + 1) - kw_delta(kw, i, ki, i - 1)) >= 0 ? 1 : -1;
-  const int dmin = kw_delta(kw, i, ki, i - d);
-  int lmax = 2;
-  while (kw_delta(kw, i, ki, i + lmax * d) > dmin) lmax <<= 1;
-  int l = 0;
-  for (int t = lmax >> 1; t >= 1; t >>= 1)
-    if (kw_delta(kw, i, ki, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int first = min(i, j), last = max(i, j);
-  if (last - first + 1 <= LT_LEAF_MAX && i != 0) return;  // swallowed by a leaf of an ancestor: never referenced
-  const int g = kw_split(kw, first, last);
-  float4* O = nodes4 + 8 * (size_t)i;
-  int ne = 0;
-  float4 lo, hi;
-#pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    const int a = side == 0 ? first : g + 1, b = side == 0 ? g : last;
-    if (b - a + 1 <= LT_LEAF_MAX) {
-      range_box(seg, np, a, b, lo, hi);
-      put_entry(O, ne++, lo, hi, leaf_ref(a, b - a + 1));
-    } else {
-      const int gc = kw_split(kw, a, b);
-      const int lc = gc - a + 1, rc = b - gc;
-      range_box(seg, np, a, gc, lo, hi);
-      put_entry(O, ne++, lo, hi, lc <= LT_LEAF_MAX ? leaf_ref(a, lc) : gc);
-      range_box(seg, np, gc + 1, b, lo, hi);
-      put_entry(O, ne++, lo, hi, rc <= LT_LEAF_MAX ? leaf_ref(gc + 1, rc) : gc + 1);
+  // ---- phase 1a: which nodes survive?  Node i spans more than LT_LEAF_MAX leaves exactly when delta(i, i + LT_LEAF_MAX d)
+  // > dmin (delta is monotone along d) -- three probes; the other three quarters of the nodes are swallowed by a leaf of
+  // an ancestor, never referenced, and end here.  Survivors (i, d, dmin) are compacted in LDS.
+  for (int k = 0; k < LT_HNODES / 256; ++k) {
+    const int i = i0 + k * 256 + threadIdx.x;
+    bool keep = false;
+    int d = 0, dmin = 0;
+    if (i < n - 1) {
+      const uint32_t ki = wkeys[i - kw.lo];
+      const int dp = lw_delta(kw, i, ki, i + 1), dm = lw_delta(kw, i, ki, i - 1);
+      d = dp - dm >= 0 ? 1 : -1;
+      dmin = d > 0 ? dm : dp;  // = delta(i, i - d)
+      keep = i == 0 || lw_delta(kw, i, ki, i + LT_LEAF_MAX * d) > dmin;
+    }
+    const unsigned long long ms = __ballot(keep);
+    int base_s = 0;
+    if ((threadIdx.x & 63) == 0 && ms) base_s = atomicAdd(&n_surv, __popcll(ms));
+    base_s = __shfl(base_s, 0, 64);
+    if (keep) {
+      const int slot = base_s + __popcll(ms & ((1ull << (threadIdx.x & 63)) - 1ull));
+      sv_i[slot] = i; sv_first[slot] = d; sv_last[slot] = dmin;
     }
   }
-  for (; ne < 4; ++ne) put_entry(O, ne, e_lo, e_hi, 0x7fffffff);
+  __syncthreads();
+  // ---- phase 1b: the survivors' key ranges, every lane busy.  The doubling search stops at LT_HBIG: up to there every
+  // probe is inside the LDS key window; a node whose range reaches further is handed to k_hierarchy4_big with (d, dmin)
+  // -- ITS range search is the long chain of dependent global loads that every wave used to wait for.
+  for (int sidx = threadIdx.x; sidx < n_surv; sidx += 256) {
+    const int i = sv_i[sidx], d = sv_first[sidx], dmin = sv_last[sidx];
+    const uint32_t ki = wkeys[i - kw.lo];
+    // (known: delta(i, i + d) > dmin by the choice of d, and delta(i, i + LT_LEAF_MAX d) > dmin for every survivor but a
+    // root with fewer leaves)
+    int lmax = i == 0 ? 2 : 2 * LT_LEAF_MAX;
+    while (lmax <= LT_HBIG && lw_delta(kw, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+    if (lmax > LT_HBIG) {
+      atomicAdd(&n_big, 1);
+      sv_i[sidx] = ~i;  // queued below with (d, dmin), which stay in the slot; not for phase 2
+    } else {
+      int l = lmax >> 1;  // the last probe that held
+      for (int t = lmax >> 2; t >= 1; t >>= 1)
+        if (lw_delta(kw, i, ki, i + (l + t) * d) > dmin) l += t;
+      const int j = i + l * d;
+      sv_first[sidx] = min(i, j);
+      sv_last[sidx] = max(i, j);
+    }
+  }
+  __syncthreads();
+  // the workgroup's big nodes go to the global queue with ONE device-scope atomic (see above).  The queue cannot
+  // overflow: the ranges of one tree level are disjoint, so a level holds fewer than n / LT_HBIG big nodes, and the tree
+  // is at most 30 key bits + 28 index bits deep -- under n / 4 in all, the queue holds n / 3.
+  if (threadIdx.x == 0 && n_big > 0) big_base = (int)atomicAdd(big_count, (unsigned)n_big);
+  __syncthreads();
+  if (n_big > 0)
+    for (int sidx = threadIdx.x; sidx < n_surv; sidx += 256)
+      if (sv_i[sidx] < 0) {
+        const int slot = big_base + atomicAdd(&n_big_out, 1);
+        if (slot < big_cap) { big_queue[3 * slot] = ~sv_i[sidx]; big_queue[3 * slot + 1] = sv_first[sidx]; big_queue[3 * slot + 2] = sv_last[sidx]; }
+      }
+  // ---- phase 2: the small surviving nodes, one per thread
+  unsigned long long t_p1 = dbg ? (unsigned long long)wall_clock64() : 0ull, t_split = 0ull;
+  for (int sidx = threadIdx.x; sidx < n_surv; sidx += 256)
+    if (sv_i[sidx] >= 0) hier_emit(kw, seg, np, nodes4, sv_i[sidx], sv_first[sidx], sv_last[sidx], dbg != nullptr, t_split);
+  if (dbg && (threadIdx.x & 63) == 0) {
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg < LT_DBG_WAVES) { dbg[8 + 2 * wg] = t_dbg; dbg[8 + 2 * wg + 1] = (unsigned long long)wall_clock64() - t_dbg; }
+    if (wg < LT_DBG_WAVES) { dbg[8 + 2 * LT_DBG_WAVES + 2 * wg] = t_p1 - t_dbg; dbg[8 + 2 * LT_DBG_WAVES + 2 * wg + 1] = t_split ? t_split - t_dbg : 0ull; }
+  }
+}
+
+// ---- one WAVE per big node ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int g_delta(const uint32_t* __restrict__ keys, int i, uint32_t ki, int j) {  // 0 <= j < n
+  const uint32_t kj = keys[j];
+  return ki != kj ? __clz((int)(ki ^ kj)) : 32 + __clz(i ^ j);
+}
+// split of [a, b] (b > a), all lanes take part: the predicate delta(a, k) > delta(a, b) holds for k <= g and fails for
+// k > g; 63 positions are probed per round
+__device__ __forceinline__ int wave_split(const uint32_t* __restrict__ keys, int a, int b) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t ka = keys[a];
+  const int dn = g_delta(keys, a, ka, b);
+  int lo = a, hi = b;  // predicate true at lo, false at hi
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 62) / 63;
+    const int k = lo + (lane + 1) * step;  // lanes 0 .. 62 probe lo + step .. ; lane 63 idles
+    const bool ok = lane < 63 && k < hi && g_delta(keys, a, ka, k) > dn;
+    const unsigned long long m = __ballot(ok);
+    const int t = m ? 64 - __clzll((long long)m) : 0;  // number of leading true probes (the predicate is monotone)
+    const int nlo = lo + t * step;
+    hi = min(hi, nlo + step);
+    lo = nlo;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_hierarchy4_big(const uint32_t* __restrict__ keys, int n, int np,
+                                                        const float4* __restrict__ seg, float4* __restrict__ nodes4,
+                                                        const int* __restrict__ big_queue, int big_cap,
+                                                        const unsigned* __restrict__ big_count,
+                                                        unsigned long long* __restrict__ dbg) {
+  const int lane = threadIdx.x & 63;
+  const int n_big = min((int)*big_count, big_cap);
+  const float inf = INFINITY;
+  const float4 e_lo = make_float4(inf, inf, inf, 0.f), e_hi = make_float4(inf, inf, inf, 0.f);
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n_big; q += gridDim.x * 4) {
+    const unsigned long long t0 = dbg ? (unsigned long long)wall_clock64() : 0ull;
+    const int i = big_queue[3 * q], d = big_queue[3 * q + 1], dmin = big_queue[3 * q + 2];
+    // the node's range: largest L with delta(i, i + L d) > dmin (monotone in L).  Lanes probe L = 2^lane at once, then a
+    // 64-ary search inside [2^T, 2^(T+1)).
+    const uint32_t ki = keys[i];
+    int L;
+    {
+      const long long j0 = (long long)i + ((long long)d << min(lane, 31));
+      const bool ok0 = lane < 31 && j0 >= 0 && j0 < n && g_delta(keys, i, ki, (int)j0) > dmin;
+      const unsigned long long m0 = __ballot(ok0);
+      const int T = 63 - __clzll((long long)m0);  // >= 8: delta(i, i + LT_HBIG d) > dmin brought the node here
+      long long lo = 1ll << T, hi = 2ll << T;     // predicate true at lo, false (or out of range) at hi
+      while (hi - lo > 1) {
+        const long long step = (hi - lo + 62) / 63;
+        const long long Lk = lo + (long long)(lane + 1) * step;
+        const long long jk = (long long)i + Lk * d;
+        const bool ok = lane < 63 && Lk < hi && jk >= 0 && jk < n && g_delta(keys, i, ki, (int)jk) > dmin;
+        const unsigned long long m = __ballot(ok);
+        const int t = m ? 64 - __clzll((long long)m) : 0;
+        const long long nlo = lo + t * step;
+        hi = hi < nlo + step ? hi : nlo + step;
+        lo = nlo;
+      }
+      L = (int)lo;
+    }
+    const int j = i + L * d;
+    const int first = min(i, j), last = max(i, j);
+    const unsigned long long t1 = dbg ? (unsigned long long)wall_clock64() : 0ull;
+    const int g = wave_split(keys, first, last);
+    const unsigned long long t2 = dbg ? (unsigned long long)wall_clock64() : 0ull;
+    // both children at once: lanes 0 .. 31 search the split of the left child, lanes 32 .. 63 that of the right one (31
+    // probes per round trip; a child of <= LT_LEAF_MAX leaves is a leaf and idles)
+    const int half = lane >> 5, hl = lane & 31;
+    const int ca = half ? g + 1 : first, cb = half ? last : g;
+    const bool need = cb - ca + 1 > LT_LEAF_MAX;
+    int gc;
+    {
+      const uint32_t ka = keys[ca], kb = keys[cb];
+      const int dn = ka != kb ? __clz((int)(ka ^ kb)) : 32 + __clz(ca ^ cb);
+      int lo = ca, hi = need ? cb : ca;  // predicate true at lo, false at hi
+      while (__any(hi - lo > 1)) {
+        const int step = (hi - lo + 30) / 31;
+        const int k = lo + (hl + 1) * step;
+        const bool ok = hl < 31 && k < hi && g_delta(keys, ca, ka, k) > dn;
+        const unsigned long long m = __ballot(ok);
+        const unsigned mh = (unsigned)(m >> (32 * half));
+        const int t = mh ? 32 - __clz((int)mh) : 0;
+        if (hi - lo > 1) {
+          const int nlo = lo + t * step;
+          hi = min(hi, nlo + step);
+          lo = nlo;
+        }
+      }
+      gc = lo;
+    }
+    const unsigned long long t3 = dbg ? (unsigned long long)wall_clock64() : 0ull;
+    const int gcl = __builtin_amdgcn_readlane(gc, 0), gcr = __builtin_amdgcn_readlane(gc, 32);  // (scalars from here on)
+    const bool needl = first != g && g - first + 1 > LT_LEAF_MAX, needr = last - g > LT_LEAF_MAX;
+    // slots 0, 1: left child (or its two halves); 2, 3: right child; an unused slot is the empty range [0, -1]
+    int ra[4], rb[4], ref[4];
+    ra[0] = first; rb[0] = needl ? gcl : g;
+    ref[0] = needl ? (gcl - first + 1 <= LT_LEAF_MAX ? leaf_ref(first, gcl - first + 1) : gcl) : leaf_ref(first, g - first + 1);
+    ra[1] = needl ? gcl + 1 : 0; rb[1] = needl ? g : -1;
+    ref[1] = g - gcl <= LT_LEAF_MAX ? leaf_ref(gcl + 1, max(g - gcl, 1)) : gcl + 1;
+    ra[2] = g + 1; rb[2] = needr ? gcr : last;
+    ref[2] = needr ? (gcr - g <= LT_LEAF_MAX ? leaf_ref(g + 1, gcr - g) : gcr) : leaf_ref(g + 1, last - g);
+    ra[3] = needr ? gcr + 1 : 0; rb[3] = needr ? last : -1;
+    ref[3] = last - gcr <= LT_LEAF_MAX ? leaf_ref(gcr + 1, max(last - gcr, 1)) : gcr + 1;
+    // the range boxes two at a time (four would cost the registers of a resident wave per SIMD): lane (flank, level)
+    // loads its heap node of both ranges -- 4 x 12 bytes in flight per lane -- then one round of shuffles
+    const int lev = lane & 31;
+    float4* O = nodes4 + 8 * (size_t)i;
+    int ne = 0;
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {
+      lt_f3 lo[2], hi[2];
+      int pa[2], pb[2], pref[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pa[k] = pair ? ra[2 + k] : ra[k]; pb[k] = pair ? rb[2 + k] : rb[k]; pref[k] = pair ? ref[2 + k] : ref[k];
+        lo[k] = lt_f3{INFINITY, INFINITY, INFINITY};
+        hi[k] = lt_f3{-INFINITY, -INFINITY, -INFINITY};
+        const long long l0 = (long long)pa[k] + np, r0 = (long long)pb[k] + np + 1;
+        const long long ll = (l0 + ((1ll << lev) - 1)) >> lev, rl = r0 >> lev;
+        if (ll < rl) {
+          if (lane < 32 && (ll & 1)) { lo[k] = *(const lt_f3*)&seg[2 * (size_t)ll]; hi[k] = *(const lt_f3*)&seg[2 * (size_t)ll + 1]; }
+          if (lane >= 32 && (rl & 1)) { lo[k] = *(const lt_f3*)&seg[2 * (size_t)(rl - 1)]; hi[k] = *(const lt_f3*)&seg[2 * (size_t)(rl - 1) + 1]; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          lo[k].x = fminf(lo[k].x, __shfl_xor(lo[k].x, o, 64)); lo[k].y = fminf(lo[k].y, __shfl_xor(lo[k].y, o, 64)); lo[k].z = fminf(lo[k].z, __shfl_xor(lo[k].z, o, 64));
+          hi[k].x = fmaxf(hi[k].x, __shfl_xor(hi[k].x, o, 64)); hi[k].y = fmaxf(hi[k].y, __shfl_xor(hi[k].y, o, 64)); hi[k].z = fmaxf(hi[k].z, __shfl_xor(hi[k].z, o, 64));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (pb[k] >= pa[k]) {  // (wave-uniform)
+          if (lane == 0) put_entry(O, ne, make_float4(lo[k].x, lo[k].y, lo[k].z, 0.f), make_float4(hi[k].x, hi[k].y, hi[k].z, 0.f), pref[k]);
+          ++ne;
+        }
+    }
+    if (lane == 0)
+      for (; ne < 4; ++ne) put_entry(O, ne, e_lo, e_hi, 0x7fffffff);
+    if (dbg && lane == 0 && q < 4096) {  // debug (LIDARHIP_DEBUG_HIER=1): start and the ends of range / split / child splits / boxes
+      unsigned long long* o = dbg + 8 + 8192 + 6 * (size_t)q;
+      o[0] = t0; o[1] = t1 - t0; o[2] = t2 - t0; o[3] = t3 - t0; o[4] = (unsigned long long)wall_clock64() - t0; o[5] = (unsigned long long)(last - first + 1);
+    }
+  }
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------
@@ -605,8 +872,16 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
                          s->seg, s->nodes);
     } else {
       static const bool dbg_hier = getenv("LIDARHIP_DEBUG_HIER") != nullptr;
-      hipLaunchKernelGGL(k_hierarchy4, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n,
-                         np, s->seg, s->nodes4, dbg_hier ? s->counters : nullptr);
+      // queue of the nodes whose range search leaves the LDS key window: (i, d, dmin) triples in the sort's spare key buffer,
+      // counter in flags[2]
+      int* big_queue = (int*)s->keys[cur ^ 1];
+      const int big_cap = s->cap_faces / 3;
+      LT_HIP(hipMemsetAsync(s->flags + 2, 0, sizeof(unsigned), stream));
+      hipLaunchKernelGGL(k_hierarchy4, dim3(cdiv(n > 1 ? n - 1 : 1, LT_HNODES)), dim3(256), 0, stream, s->keys[cur], n,
+                         np, s->seg, s->nodes4, big_queue, big_cap, s->flags + 2, dbg_hier ? s->counters : nullptr);
+      if (n > LT_HBIG)
+        hipLaunchKernelGGL(k_hierarchy4_big, dim3(min(cdiv(2 * n / LT_HBIG + 4, 4), 2048)), dim3(256), 0, stream, s->keys[cur],
+                           n, np, s->seg, s->nodes4, big_queue, big_cap, s->flags + 2, dbg_hier ? s->counters : nullptr);
     }
     LT_MARK();  // 6
     LT_HIP(hipGetLastError());

@@ -904,3 +904,32 @@ def test_tiny_far_triangles_are_not_taken_for_pierced(oracle):
     nt = 3 * n
     a2, _ = _both_strategies(v[:nt], f[:n], c[:nt], r[:nt], rays, (0.0, 0.0, 0.0), H)
     assert a2["stats"]["nodes_visited"] < 8 * n, a2["stats"]["nodes_visited"] / n
+
+
+def test_lbvh_on_degenerate_morton_trees(oracle):
+    """The LBVH build's queue of wide nodes (k_hierarchy4 -> k_hierarchy4_big) on trees that are not balanced: thousands
+    of identical triangles (one Morton key: the tree is decided by the index tie-break alone and every upper node is
+    wide), and a staircase of clusters at x = 2^-k, 600 copies each (a chain of wide nodes, one per key bit)."""
+    rng = np.random.default_rng(77)
+    one = np.array([[4.0, -1.0, -1.0], [4.0, 1.0, -1.0], [4.0, 0.0, 1.5]])
+    same = np.repeat(one[None], 5000, axis=0)
+    stairs = []
+    for k in range(14):
+        base = one * [1.0, 0.2, 0.2] + [30.0 * 2.0 ** -k, 0.0, 0.0]
+        stairs.append(np.repeat(base[None], 600, axis=0) + rng.normal(size=(600, 1, 3)) * 1e-4)
+    for tri in (same, np.concatenate(stairs), np.concatenate([same] + stairs)):
+        n = len(tri)
+        v = np.ascontiguousarray(tri.reshape(-1, 3).astype(np.float32))
+        f = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+        c = rng.integers(0, 256, (3 * n, 3)).astype(np.int32)
+        r = rng.uniform(0, 1, 3 * n).astype(np.float32)
+        H, W = 8, 128
+        spread = np.where(np.arange(H * W)[:, None] % 2 == 0, 0.25, 0.03)   # (the stairs subtend +-0.05 rad)
+        rays = (np.array([1.0, 0.0, 0.0]) + rng.normal(size=(H * W, 3)) * spread * [0.0, 1.0, 1.0]).astype(np.float32)
+        a, b = _both_strategies(v, f, c, r, rays, (0.0, 0.0, 0.0), H)
+        ref = oracle.oracle_trace(rays, np.zeros(3, np.float32), v, f, c, r, H, mode=oracle.MODE_BRUTE,
+                                  norm=oracle.NORM_SSE_TABLE)
+        for k in ("tri", "endcolors", "range", "endrem", "endpoints"):
+            _assert_bits(a[k], ref[k], f"scatter {k} n={n}")
+            _assert_bits(b[k], ref[k], f"lbvh {k} n={n}")
+        assert int((ref["tri"] >= 0).sum()) > 100

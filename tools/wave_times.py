@@ -66,19 +66,25 @@ if "--quad" in sys.argv:
     for cap in (32, 40, 48, 64):
         print("    rays beyond %d steps: %.2f %%" % (cap, 100.0 * (steps > cap).mean()))
 
-# ---- k_hierarchy4 (LIDARHIP_DEBUG_HIER=1): wall-clock stamps per wave (first 16384 waves = 1 M nodes)
+# ---- k_hierarchy4 (LIDARHIP_DEBUG_HIER=1): wall-clock stamps per wave: whole kernel, and end of staging / phase 1
 if "--hier" in sys.argv:
     sc.set_mesh(*mesh); sc.build(); torch.cuda.synchronize()
-    nw = 15624
-    buf = np.zeros(2 * nw, np.uint64)
-    assert lib.lt_debug_wave_times(sc._h, buf.ctypes.data_as(C.c_void_p), nw) == 0
-    t = buf.reshape(nw, 2)
+    nw = 3908
+    buf = np.zeros(4 * 16384, np.uint64)
+    lib.lt_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert lib.lt_debug_wave_times(sc._h, buf.ctypes.data_as(C.c_void_p), 2 * 16384) == 0
+    t = buf[:2 * nw].reshape(nw, 2)
+    ph = buf[2 * 16384:2 * 16384 + 2 * nw].reshape(nw, 2).astype(np.int64) / 100.0
     start = (t[:, 0] - t[:, 0].min()).astype(np.int64) / 100.0
     dur = t[:, 1].astype(np.int64) / 100.0
     end = start + dur
     print("k_hierarchy4: waves %d, span %.1f us" % (nw, end.max()))
-    for name, a in (("start", start), ("duration", dur), ("end", end)):
-        print("  %-10s mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f p99.9 %8.1f max %8.1f" % (name, a.mean(), *[np.percentile(a, p) for p in (50, 90, 99, 99.9)], a.max()))
-    order = np.argsort(-dur)[:10]
-    print("  slowest waves (wave, start, duration us):", [(int(i), round(float(start[i]), 1), round(float(dur[i]), 1)) for i in order])
-    print("  busy fraction over the span: %.3f" % (dur.sum() / 8192 / end.max()))
+    for name, a in (("start", start), ("phase 1 done at", ph[:, 0]), ("splits done at", ph[:, 1]), ("duration", dur), ("end", end)):
+        print("  %-16s mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f max %8.1f" % (name, a.mean(), *[np.percentile(a, p) for p in (50, 90, 99)], a.max()))
+    big = buf[8192:8192 + 6 * 4096].reshape(4096, 6).astype(np.int64)
+    big = big[big[:, 0] != 0]
+    b0 = (big[:, 0] - big[:, 0].min()) / 100.0
+    print("k_hierarchy4_big: %d queued nodes stamped (of at most 4096), starts span %.1f us" % (len(big), b0.max()))
+    for name, a in (("start", b0), ("range done at", big[:, 1] / 100.0), ("split done at", big[:, 2] / 100.0), ("child splits at", big[:, 3] / 100.0),
+                    ("duration", big[:, 4] / 100.0), ("end", b0 + big[:, 4] / 100.0), ("span (leaves)", big[:, 5].astype(float))):
+        print("  %-16s mean %8.1f p50 %8.1f p90 %8.1f p99 %8.1f max %8.1f" % (name, a.mean(), *[np.percentile(a, p) for p in (50, 90, 99)], a.max()))
