@@ -678,10 +678,10 @@ def main():
                         "marching_cubes_field_stream_GBs": round(nvox * 4 / (m[2] * 1e-3) / 1e9, 1),
                         "note": "reset writes 4 fields; marching cubes reads the tsdf field once (and 128 MB of sign bits)"}}
 
-    def e2e_pipelined(n_scans=200, depth=3):
+    def e2e_pipelined(n_scans=200, depth=4):
         """The same host-buffer work for a SEQUENCE of scans (the reference's loop over output scans): lt_hostpipe keeps
-        `depth` scans in flight -- upload of scan i+1 | render of scan i | download of scan i-1 on three HIP streams,
-        pageable numpy arrays, colours as the uint8 [V,3] get_mesh returns, all five images downloaded.  Measured by
+        `depth` scans in flight -- uploads of scans i+1, i+2 (two uploader threads) | render of scan i | download of scan
+        i-1 on separate HIP streams, pageable numpy arrays, colours as the uint8 [V,3] get_mesh returns, all five images downloaded.  Measured by
         tools/hostpipe_rate.py in a numpy-only subprocess (LIDARHIP_NO_TORCH=1: the system ROCm runtime; a pageable
         hipMemcpy of the HIP runtime bundled with the torch wheel is ~35 % slower on this box -- `in_torch_process`
         is the same loop with torch imported first)."""
@@ -703,7 +703,7 @@ def main():
             return None
         t = m["ms_per_scan"] * 1e-3
         h2d = m["h2d_bytes"]
-        out = {"what": f"lt_hostpipe: {n_scans} scans, {depth} in flight (upload i+1 | render i | download i-1), host "
+        out = {"what": f"lt_hostpipe: {n_scans} scans, {depth} in flight (uploads i+1, i+2 on two threads | render i | download i-1), host "
                        f"meshes in pageable numpy arrays, colours uint8 [V,3] as get_mesh returns them, all five images "
                        f"downloaded; numpy-only process", "ms_per_scan": round(t * 1e3, 4),
                "value": round(R / t / 1e6, 2), "unit": "Mrays/s", "scans_per_s": round(1.0 / t, 1), "h2d_bytes": int(h2d),

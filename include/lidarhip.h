@@ -98,13 +98,13 @@ int lt_ctrace_ex(const float* rays, const float* origin, const float* verts, con
 
 /* ---- host buffers, pipelined: a sequence of scans with their transfers overlapped -------------------------------- */
 
-typedef struct lt_hostpipe lt_hostpipe; /* opaque: `depth` scans in flight, a worker thread, three HIP streams */
+typedef struct lt_hostpipe lt_hostpipe; /* opaque: `depth` scans in flight, uploader + launcher threads, HIP streams */
 
 /*
  * The work of lt_ctrace for a SEQUENCE of scans that share one ray set (one target sensor model, as in the reference's
  * batch loop lidar_deform.py:393-462, which calls throw_rays_at_mesh -> ctrace once per output scan,
  * fusion_lidar.py:434-451): while scan i renders, scan i + 1 uploads and scan i - 1 downloads.
- *   rays    HOST [n_rays,3] f32, uploaded and binned once;  depth = scans in flight (3 is enough to overlap)
+ *   rays    HOST [n_rays,3] f32, uploaded and binned once;  depth = scans in flight (3 overlap; from 4 on two uploader threads share the link: +7 %)
  *   flags   LT_TRACE_LABEL_IMAGE | LT_TRACE_NORM_EXACT | LT_TRACE_NORM_AMD
  * Unlike lt_ctrace the pipe writes EVERY cell of the output images (misses: 0, tri -1) -- what the reference's
  * pre-zeroed arrays (fusion_lidar.py:440-447) contain after ctrace -- so nothing is uploaded for the outputs.

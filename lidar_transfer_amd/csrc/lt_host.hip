@@ -258,13 +258,18 @@ struct lt_hostpipe {
   bool use_register = false;
   size_t b3, b1, bc;  // bytes of a [R,3] f32 image, a [R] image, the colour image
   lt_rayset* rs = nullptr;
-  hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
+  // LIDARHIP_HOSTPIPE_UPLOADERS (default: 2 when depth >= 4, else 1): uploader threads, each with its own stream, taking
+  // scans alternately -- a pageable copy occupies its caller, and the fixed part of one thread's copy (staging ramp-up
+  // and drain, ~17 us per array) runs under the other thread's transfer: C2 scans 0.452 -> 0.422 ms (52 GB/s of uploads,
+  // 0.92 of the measured wire rate); a third uploader adds nothing
+  int n_up = 1;
+  hipStream_t s_up[4] = {nullptr, nullptr, nullptr, nullptr}, s_run = nullptr, s_down = nullptr;
   std::vector<hp_slot> slots;
   std::mutex mu;
   std::condition_variable cv_work, cv_launch, cv_done;
   std::deque<int> queue;         // slots to upload, in ticket order
   std::deque<int> launch_queue;  // uploaded slots whose render + download are to be issued
-  bool uploader_done = false;
+  int uploaders_done = 0;
   int next_ticket = 0;
   double t_issue = 0, t_upload = 0, t_collect = 0;  // seconds spent by the worker issuing / uploading, by callers collecting
   long n_issued = 0;
@@ -275,7 +280,7 @@ struct lt_hostpipe {
   std::vector<hp_reg> regs;
   double trace[256][6];  // debug: per ticket % 256: submit, issue start, upload end, issue end, collect start, collect end
   bool stop = false;
-  std::thread worker, launcher;
+  std::thread worker[4], launcher;
 };
 
 static double hp_now() {
@@ -320,7 +325,7 @@ static void hp_unpin_all(lt_hostpipe* p, hp_job& j) {
 }
 
 // first half of a scan, on the UPLOADER thread: the mesh from the caller's arrays into the slot's device buffer
-static int hp_upload(lt_hostpipe* p, hp_slot& sl) {
+static int hp_upload(lt_hostpipe* p, hp_slot& sl, hipStream_t s_up) {
   hp_job& j = sl.job;
   const double t0 = hp_now();
   p->trace[j.ticket & 255][1] = t0;
@@ -353,14 +358,17 @@ static int hp_upload(lt_hostpipe* p, hp_slot& sl) {
     hp_pin(p, j, j.faces, (size_t)j.n_faces * 12);
   }
   if (j.n_verts > 0) {
-    LT_HIP(hipMemcpyAsync(dv, j.verts, (size_t)j.n_verts * 12, hipMemcpyHostToDevice, p->s_up));
-    if (j.colors_u8) LT_HIP(hipMemcpyAsync(d8, j.colors, (size_t)j.n_verts * 3, hipMemcpyHostToDevice, p->s_up));
-    else LT_HIP(hipMemcpyAsync(dc, j.colors, (size_t)j.n_verts * 12, hipMemcpyHostToDevice, p->s_up));
-    LT_HIP(hipMemcpyAsync(dr, j.rem, (size_t)j.n_verts * 4, hipMemcpyHostToDevice, p->s_up));
+    LT_HIP(hipMemcpyAsync(dv, j.verts, (size_t)j.n_verts * 12, hipMemcpyHostToDevice, s_up));
+    if (j.colors_u8) LT_HIP(hipMemcpyAsync(d8, j.colors, (size_t)j.n_verts * 3, hipMemcpyHostToDevice, s_up));
+    else LT_HIP(hipMemcpyAsync(dc, j.colors, (size_t)j.n_verts * 12, hipMemcpyHostToDevice, s_up));
+    LT_HIP(hipMemcpyAsync(dr, j.rem, (size_t)j.n_verts * 4, hipMemcpyHostToDevice, s_up));
   }
-  if (j.n_faces > 0) LT_HIP(hipMemcpyAsync(df, j.faces, (size_t)j.n_faces * 12, hipMemcpyHostToDevice, p->s_up));
-  LT_HIP(hipEventRecord(sl.ev_up, p->s_up));
-  p->t_upload += hp_now() - t0;
+  if (j.n_faces > 0) LT_HIP(hipMemcpyAsync(df, j.faces, (size_t)j.n_faces * 12, hipMemcpyHostToDevice, s_up));
+  LT_HIP(hipEventRecord(sl.ev_up, s_up));
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->t_upload += hp_now() - t0;
+  }
   p->trace[j.ticket & 255][2] = hp_now();
   return LT_OK;
 }
@@ -453,7 +461,7 @@ static void hp_fail(lt_hostpipe* p, hp_slot& sl, int rc) {
   p->cv_done.notify_all();
 }
 
-static void hp_uploader(lt_hostpipe* p) {
+static void hp_uploader(lt_hostpipe* p, int which) {
   for (;;) {
     int k;
     {
@@ -464,7 +472,7 @@ static void hp_uploader(lt_hostpipe* p) {
       p->queue.pop_front();
     }
     hp_slot& sl = p->slots[k];
-    const int rc = hp_upload(p, sl);
+    const int rc = hp_upload(p, sl, p->s_up[which]);
     if (rc != LT_OK) {
       hp_fail(p, sl, rc);
       continue;
@@ -477,7 +485,7 @@ static void hp_uploader(lt_hostpipe* p) {
   }
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    p->uploader_done = true;
+    p->uploaders_done += 1;
   }
   p->cv_launch.notify_all();
 }
@@ -487,7 +495,7 @@ static void hp_launcher(lt_hostpipe* p) {
     int k;
     {
       std::unique_lock<std::mutex> lk(p->mu);
-      p->cv_launch.wait(lk, [&] { return p->uploader_done || !p->launch_queue.empty(); });
+      p->cv_launch.wait(lk, [&] { return p->uploaders_done == p->n_up || !p->launch_queue.empty(); });
       if (p->launch_queue.empty()) return;
       k = p->launch_queue.front();
       p->launch_queue.pop_front();
@@ -514,7 +522,8 @@ extern "C" int lt_hostpipe_destroy(lt_hostpipe* p) {
     p->stop = true;
   }
   p->cv_work.notify_all();
-  if (p->worker.joinable()) p->worker.join();
+  for (std::thread& w : p->worker)
+    if (w.joinable()) w.join();
   if (p->launcher.joinable()) p->launcher.join();
   (void)hipSetDevice(p->device);
   (void)hipDeviceSynchronize();
@@ -528,7 +537,8 @@ extern "C" int lt_hostpipe_destroy(lt_hostpipe* p) {
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
   }
   if (p->rs) (void)lt_rayset_destroy(p->rs);
-  if (p->s_up) (void)hipStreamDestroy(p->s_up);
+  for (hipStream_t su : p->s_up)
+    if (su) (void)hipStreamDestroy(su);
   if (p->s_run) (void)hipStreamDestroy(p->s_run);
   if (p->s_down) (void)hipStreamDestroy(p->s_down);
   delete p;
@@ -567,7 +577,13 @@ extern "C" int lt_hostpipe_create(lt_hostpipe** out, const float* rays, int n_ra
       rc = e == hipErrorOutOfMemory ? LT_ERR_NO_MEMORY : LT_ERR_HIP;
     }
   };
-  ok(hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking), "hipStreamCreate");
+  {
+    const char* e = getenv("LIDARHIP_HOSTPIPE_UPLOADERS");
+    p->n_up = e ? atoi(e) : (depth >= 4 ? 2 : 1);  // (two uploaders with only three slots starve the render: measured slower)
+    p->n_up = p->n_up < 1 ? 1 : (p->n_up > 4 ? 4 : p->n_up);
+    if (p->n_up > depth) p->n_up = depth;
+  }
+  for (int u = 0; u < p->n_up; ++u) ok(hipStreamCreateWithFlags(&p->s_up[u], hipStreamNonBlocking), "hipStreamCreate");
   ok(hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking), "hipStreamCreate");
   ok(hipStreamCreateWithFlags(&p->s_down, hipStreamNonBlocking), "hipStreamCreate");
   // the ray set of the sensor model, once (create_rays depends only on the YAML, laserscan.py:1092-1119)
@@ -596,7 +612,7 @@ extern "C" int lt_hostpipe_create(lt_hostpipe** out, const float* rays, int n_ra
     lt_hostpipe_destroy(p);
     return rc;
   }
-  p->worker = std::thread(hp_uploader, p);
+  for (int u = 0; u < p->n_up; ++u) p->worker[u] = std::thread(hp_uploader, p, u);
   p->launcher = std::thread(hp_launcher, p);
   *out = p;
   return LT_OK;
@@ -632,7 +648,10 @@ static int hp_collect(lt_hostpipe* p, hp_slot& sl) {
     if (j.endrem) memcpy(j.endrem, h + p->b3 + p->bc + p->b1, R * 4);
     if (j.tri) memcpy(j.tri, h + p->b3 + p->bc + 2 * p->b1, R * 4);
   }
-  if (rc != LT_OK) (void)hipStreamSynchronize(p->s_up), (void)hipStreamSynchronize(p->s_down);  // nothing may still touch the caller's arrays
+  if (rc != LT_OK) {
+    for (int u = 0; u < p->n_up; ++u) (void)hipStreamSynchronize(p->s_up[u]);
+    (void)hipStreamSynchronize(p->s_down);
+  }  // nothing may still touch the caller's arrays
   hp_unpin_all(p, sl.job);
   {
     std::lock_guard<std::mutex> lk(p->mu);

@@ -170,7 +170,7 @@ class HostScanPipeline:
     ``ctrace``.  ``label_image=True`` makes ``endcolors`` the [H*W] semantic-label image (``deform``'s unpack,
     laserscan.py:912)."""
 
-    def __init__(self, rays, H, depth=3, label_image=False, device=None, normalize="intel"):
+    def __init__(self, rays, H, depth=4, label_image=False, device=None, normalize="intel"):
         import numpy as np
         self._np = np
         self._lib = _lib.load()

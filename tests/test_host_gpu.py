@@ -30,8 +30,8 @@ def _same(a, b, label_image=False):
         assert x.shape == y.shape and np.array_equal(x.view(np.int32), y.view(np.int32)), k
 
 
-@pytest.mark.parametrize("label_image", [False, True])
-def test_hostpipe_equals_one_ctrace_call_per_scan(label_image):
+@pytest.mark.parametrize("label_image,depth", [(False, 3), (True, 3), (False, 5)])   # depth >= 4: two uploader threads
+def test_hostpipe_equals_one_ctrace_call_per_scan(label_image, depth):
     from lidar_transfer_amd.pipeline import HostScanPipeline
     H, W = 32, 512
     rays = create_rays(10.0, -30.0, H, W)
@@ -41,17 +41,18 @@ def test_hostpipe_equals_one_ctrace_call_per_scan(label_image):
     n = 14
     origins = [np.array([0.1 * k, -0.05 * k, 0.02 * (k % 3)], np.float32) for k in range(n)]
     got = [None] * n
-    with HostScanPipeline(rays, H, depth=3, label_image=label_image) as pipe:
+    lag = depth - 1
+    with HostScanPipeline(rays, H, depth=depth, label_image=label_image) as pipe:
         tickets = []
         for k in range(n):
             v, f, c, r = meshes[k % len(meshes)]
             # every second scan hands the colours over as get_mesh returns them: uint8 [V,3] (fusion_lidar.py:423)
             cc = (c & 255).astype(np.uint8) if k % 2 else c
             tickets.append(pipe.submit(v, f, cc, r, origins[k]))
-            if k >= 2:
-                got[k - 2] = pipe.wait(tickets[k - 2])
+            if k >= lag:
+                got[k - lag] = pipe.wait(tickets[k - lag])
         pipe.flush()
-        for k in (n - 2, n - 1):
+        for k in range(n - lag, n):
             got[k] = pipe.wait(tickets[k])
     for k in range(n):
         v, f, c, r = meshes[k % len(meshes)]
