@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+N_SIMD, SHADER_GHZ = 1024, 2.4  # 256 CUs x 4 SIMD16; peak engine clock (MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 per direction: 32 GT/s x 16 lanes x 128/130
 PCIE_WIRE_GBS = 56.3   # what a pinned hipMemcpyAsync of 26 MB reaches on this box (tools/pcie_probe.hip)
 PROBE_EVERY = int(os.environ.get("LT_BENCH_PROBE_EVERY", "8"))  # HIP-event pair around every n-th dominant launch
@@ -468,7 +469,7 @@ def main():
         the workload, launch shape AND kernel sources it was collected on -- otherwise null, never a stale constant."""
         import glob
         want = kernel_source_hash(strategy)
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc*.json")), reverse=True):
             try:
                 doc = json.load(open(path))
             except (OSError, ValueError):
@@ -508,6 +509,17 @@ def main():
                       "runs beside the kernel)"}
         if traffic:
             d["traffic_frac_of_peak"] = round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if te and te.get("valu_active_quad_cycles_per_launch"):
+            # the issue-bound view (same PMC passes): cycles the VALUs of a SIMD were issuing = SQ_ACTIVE_INST_VALU
+            # (quad-cycles, summed over the chip's 1024 SIMDs) x 4 / 1024, against the launch's duration at the peak clock
+            busy = te["valu_active_quad_cycles_per_launch"] * 4.0 / N_SIMD
+            d["valu_issue"] = {"wave_insts_per_launch": te["valu_wave_insts_per_launch"],
+                               "busy_cycles_per_simd": int(busy), "busy_ms_at_peak_clock": round(busy / SHADER_GHZ / 1e6, 5),
+                               "frac_of_kernel_time": round(busy / SHADER_GHZ / 1e6 / serial_ms, 4),
+                               "note": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same launches (profiles pmc.json); a "
+                                       "wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at "
+                                       f"{SHADER_GHZ} GHz -- the share of the kernel's time its SIMDs spend issuing "
+                                       "vector ALU work: what actually bounds a kernel that moves few bytes per test"}
         if insitu_ms == insitu_ms:
             d["in_situ"] = {"avg_kernel_ms": round(insitu_ms, 5),
                             "achieved": round(alg / (insitu_ms * 1e-3) / 1e9, 1),
@@ -674,9 +686,11 @@ def main():
                 "unit": "Mrays/s", "voxels": nvox, "mesh_verts": nv, "mesh_faces": nf, "hit_fraction": round(hits_c / R, 4),
                 "phase_ms": {"reset": round(float(m[0]), 3), "integrate": round(float(m[1]), 3),
                              "marching_cubes": round(float(m[2]), 3), "render": round(float(m[3]), 3)},
-                "hbm": {"reset_GBs": round(4 * nvox * 4 / (m[0] * 1e-3) / 1e9, 1),
-                        "marching_cubes_field_stream_GBs": round(nvox * 4 / (m[2] * 1e-3) / 1e9, 1),
-                        "note": "reset writes 4 fields; marching cubes reads the tsdf field once (and 128 MB of sign bits)"}}
+                "dense_floor_ms": {"reset": round(4 * nvox * 4 / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+                                   "marching_cubes": round(nvox * 4 / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+                                   "note": "what ONE streaming pass over the fields would take at the HBM peak (reset writes "
+                                           "4 fields, marching cubes reads the tsdf field): the chain's phases touch only "
+                                           "the columns a scan wrote (column stamps + written z-range, 1-bit sign field)"}}
 
     def e2e_pipelined(n_scans=200, depth=4):
         """The same host-buffer work for a SEQUENCE of scans (the reference's loop over output scans): lt_hostpipe keeps

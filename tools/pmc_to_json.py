@@ -31,11 +31,11 @@ def source_hash(strategy):
     return h.hexdigest()[:16]
 
 
-def per_kernel_mean(root, counter):
+def per_kernel_mean(root, counter, subdir=None):
     """mean over launches of the per-dispatch counter sum (a counter is reported once per XCD / instance), split by
     grid size so that batch launches and single-scan launches of one kernel are told apart"""
     acc = collections.defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True)):
+    for path in sorted(glob.glob(os.path.join(root, subdir or counter, "**", "*counter_collection.csv"), recursive=True)):
         per = collections.defaultdict(float)
         meta = {}
         for r in csv.DictReader(open(path)):
@@ -58,29 +58,38 @@ def main():
     ap.add_argument("--command", default="python bench.py --no-cpu-baseline --no-other --no-e2e")
     a = ap.parse_args()
     fetch, write = per_kernel_mean(a.root, "FETCH_SIZE"), per_kernel_mean(a.root, "WRITE_SIZE")
+    # optional third pass (tools/r02_profile.sh): SQ_INSTS_VALU (wave instructions) and SQ_ACTIVE_INST_VALU (quad-cycles
+    # the VALUs were issuing, summed over the SIMDs) -- the issue-bound view of a kernel that moves few bytes per flop
+    valu_n = per_kernel_mean(a.root, "SQ_INSTS_VALU", "SQ_INSTS_VALU_group")
+    valu_c = per_kernel_mean(a.root, "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_group")
     # The grid of a launch grows with the scans it holds (and varies a little with the scene's face count): launches
     # of one kernel are clustered by round(grid / smallest grid) -- 1 = a single-scan launch (counting / isolated
     # passes), --batch = the batch call of the timed region -- and averaged (weighted by launches) per cluster.
     raw = collections.defaultdict(list)
     for (kern, grid), (f, n) in sorted(fetch.items()):
         if kern in STRATEGY_OF and (kern, grid) in write:
-            raw[kern].append((grid, n, f, write[(kern, grid)][0]))
+            raw[kern].append((grid, n, f, write[(kern, grid)][0], valu_n.get((kern, grid), (None,))[0],
+                              valu_c.get((kern, grid), (None,))[0]))
     entries = []
     for kern, rows in raw.items():
-        gmin = min(g for g, _, _, _ in rows)
+        gmin = min(r[0] for r in rows)
         clusters = collections.defaultdict(list)
-        for g, n, f, w in rows:
-            clusters[max(1, int(round(g / gmin)))].append((g, n, f, w))
+        for r in rows:
+            clusters[max(1, int(round(r[0] / gmin)))].append(r)
         for ratio, rs in sorted(clusters.items()):
             n = sum(r[1] for r in rs)
             f = sum(r[1] * r[2] for r in rs) / n
             w = sum(r[1] * r[3] for r in rs) / n
             spl = ratio if STRATEGY_OF[kern] == "scatter" else 1
-            entries.append({"kernel": kern, "scans_per_launch": spl, "launches": n,
-                            "grid_size_mean": int(sum(r[0] * r[1] for r in rs) / n), "fetch_kib": round(f, 1),
-                            "write_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
-                            "strategy": STRATEGY_OF[kern], "workload": a.workload,
-                            "kernel_source_hash": source_hash(STRATEGY_OF[kern])})
+            e = {"kernel": kern, "scans_per_launch": spl, "launches": n,
+                 "grid_size_mean": int(sum(r[0] * r[1] for r in rs) / n), "fetch_kib": round(f, 1),
+                 "write_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                 "strategy": STRATEGY_OF[kern], "workload": a.workload,
+                 "kernel_source_hash": source_hash(STRATEGY_OF[kern])}
+            if all(r[4] is not None and r[5] is not None for r in rs):
+                e["valu_wave_insts_per_launch"] = int(sum(r[1] * r[4] for r in rs) / n)
+                e["valu_active_quad_cycles_per_launch"] = int(sum(r[1] * r[5] for r in rs) / n)
+            entries.append(e)
     doc = {"what": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, "
                    "--kernel-trace only) of: " + a.command,
            "formula": "(2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",

@@ -9,8 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02
 mkdir -p $O
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | cut -d' ' -f1)
+  if [ "$tag" = "SQ_INSTS_VALU" ]; then tag=SQ_INSTS_VALU_group; fi
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_bench/$tag -o p -- python $R/bench.py --no-cpu-baseline --no-other --no-e2e --no-chain --steps 16 --warmup 2 > $O/pmc_bench_$tag.log 2>&1 || echo "FAILED pmc_bench $tag"
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_lbvh/$tag -o p -- python $R/tools/prof_scan.py --reps 5 > $O/pmc_lbvh_$tag.log 2>&1 || echo "FAILED pmc_lbvh $tag"
 done
@@ -22,8 +23,9 @@ cd $R
 python tools/pmc_to_json.py gpurun_out/r02/pmc_bench gpurun_out/r02/pmc.json --command "python bench.py --no-cpu-baseline --no-other --no-e2e --no-chain --steps 16 --warmup 2" > gpurun_out/r02/pmc_to_json.log 2>&1
 python tools/pmc_to_json.py gpurun_out/r02/pmc_lbvh gpurun_out/r02/pmc_lbvh.json --command "python tools/prof_scan.py --reps 5" >> gpurun_out/r02/pmc_to_json.log 2>&1
 python tools/wave_times.py --quad > gpurun_out/r02/wave_times_quad.txt 2>&1
+LIDARHIP_DEBUG_HIER=1 python tools/wave_times.py --hier 2>&1 | grep -A20 "^k_hierarchy4:" > gpurun_out/r02/wave_times_hier.txt
 ./tools/pcie_probe.bin > gpurun_out/r02/pcie_probe.txt 2>&1
-./tools/hostpipe_probe.bin 3 > gpurun_out/r02/hostpipe_probe.txt 2>&1
+./tools/hostpipe_probe.bin 4 > gpurun_out/r02/hostpipe_probe.txt 2>&1
 python tools/bench_aux.py > gpurun_out/r02/bench_aux.jsonl 2> /dev/null
 # the stats CSVs are what is kept; the per-dispatch traces are large
 find $O -name "*kernel_trace.csv" -size +2M -delete
