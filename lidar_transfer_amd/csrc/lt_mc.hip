@@ -29,6 +29,7 @@
 #include "lt_internal.h"
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #define LT_TABLE_ATTR __device__
@@ -43,7 +44,7 @@ struct mc_dims {
 };
 
 struct mc_rec {  // one per active word
-  int w, vbase, tbase, pad;
+  int w, vbase, tbase, pad;  // pad: the word's triangle count
   u64 ex, ey, ez;
 };
 
@@ -108,18 +109,15 @@ struct mc_masks {
 
 __device__ __forceinline__ u64 low_bits(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
 
-__device__ __forceinline__ mc_masks mc_load(const u64* __restrict__ bits, const mc_dims& D, int x, int y, int wz) {
+// masks from the 8 sign words of a word's cell corners, w8[dx | dy << 1 | dw << 2] (0 where the volume ends)
+__device__ __forceinline__ mc_masks mc_build(const u64* w8, const mc_dims& D, int x, int y, int wz) {
   mc_masks M;
-  const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny, hz = wz + 1 < D.wz;
-  const int row = x * D.ny + y;
+  const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny;
 #pragma unroll
   for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      const bool have = (dx == 0 || hx) && (dy == 0 || hy);
-      const size_t i = (size_t)(row + dx * D.ny + dy) * D.wz + wz;
-      const u64 m = have ? bits[i] : 0ull;
-      const u64 nxt = (have && hz) ? bits[i + 1] : 0ull;
+      const u64 m = w8[dx | (dy << 1)], nxt = w8[dx | (dy << 1) | 4];
       M.m[dx][dy] = m;
       M.s[dx][dy] = (m >> 1) | (nxt << 63);
     }
@@ -135,6 +133,22 @@ __device__ __forceinline__ mc_masks mc_load(const u64* __restrict__ bits, const 
     M.ac = (any & ~all) & vz;
   }
   return M;
+}
+
+__device__ __forceinline__ mc_masks mc_load(const u64* __restrict__ bits, const mc_dims& D, int x, int y, int wz) {
+  const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny, hz = wz + 1 < D.wz;
+  const int row = x * D.ny + y;
+  u64 w8[8];
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const bool have = (dx == 0 || hx) && (dy == 0 || hy);
+      const size_t i = (size_t)(row + dx * D.ny + dy) * D.wz + wz;
+      w8[dx | (dy << 1)] = have ? bits[i] : 0ull;
+      w8[dx | (dy << 1) | 4] = (have && hz) ? bits[i + 1] : 0ull;
+    }
+  return mc_build(w8, D, x, y, wz);
 }
 
 // case index of the cell at bit b: corner i at (dx, dy, dz) = (i & 1, (i >> 1) & 1, (i >> 2) & 1)
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
       r.w = w;
       r.vbase = sg[1] + blk[3 * blockIdx.x + 1] + (int)((ex >> 20) & 0xFFFFF);
       r.tbase = sg[2] + blk[3 * blockIdx.x + 2] + (int)((ex >> 40) & 0xFFFFF);
-      r.pad = 0;
+      r.pad = (int)nt;  // triangles of the word (k_mc_emit_batch: the extent of a batch)
       r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
       rec[ci] = r;
     } else {
@@ -426,6 +440,174 @@ __global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, 
   }
 }
 
+// ---- k_mc_emit_batch: one wave per K consecutive active words, one lane per VERTEX / per TRIANGLE ----------------------------
+// k_mc_emit spends its time issuing instructions for idle lanes: on the default volume's street scene an active word owns
+// 3.6 vertices and 7.3 triangles, so the double-precision vertex rule (three IEEE divisions), unrolled over the three edge
+// axes, and the 5 x 3 unrolled index computations run with 2-4 of 64 lanes live -- 252 000 waves x ~3 300 cycles = the
+// kernel's 265 us (more words per wave or a lane per word change nothing: 272 / 332 us measured).  Here a wave takes K
+// words, lists their vertices and triangles in LDS (in output order: the lists ARE the output ranges, a batch's words
+// are consecutive), and then lane j computes vertex j / triangle j: every lane live, every store coalesced.
+#define LT_MC_VCAP 256   // list windows; a batch with more vertices / triangles is emitted in several passes
+#define LT_MC_TCAP 512
+template <int K>
+__global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
+                                                      const float* __restrict__ rem_vol, const u64* __restrict__ bits,
+                                                      mc_dims D, const int* __restrict__ cmap,
+                                                      const mc_rec* __restrict__ rec, int n_active, float voxel_size,
+                                                      float ox, float oy, float oz, float* __restrict__ verts,
+                                                      int* __restrict__ faces, int* __restrict__ colors,
+                                                      float* __restrict__ rem, int cap_v, int cap_f) {
+  static_assert(K <= 16, "list entries hold the word in 4 bits");
+  __shared__ mc_rec s_rec[K];
+  __shared__ int s_xyz[K][3];       // x, y, wz of the words
+  __shared__ u64 s_sg[K][8];        // sign words of the cell corners, [dx | dy << 1 | dw << 2]
+  __shared__ mc_nb s_nb[K][8];      // records of the 8 words a cell's triangles can reference
+  __shared__ unsigned s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10
+  __shared__ unsigned s_tl[LT_MC_TCAP];  // triangle j of the window: k | b << 4 | t << 10 | case << 13
+  const int lane = threadIdx.x;
+  const int ci0 = blockIdx.x * K;
+  const int nw = min(K, n_active - ci0);
+  const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
+  if (lane < nw) {
+    const mc_rec r = rec[ci0 + lane];
+    s_rec[lane] = r;
+    const int row = r.w / D.wz;
+    s_xyz[lane][2] = r.w - row * D.wz;
+    s_xyz[lane][0] = row / D.ny;
+    s_xyz[lane][1] = row - (row / D.ny) * D.ny;
+  }
+  __syncthreads();
+  for (int p = lane; p < 8 * nw; p += 64) {  // (k, slot): sign word and record of the word (x + dx, y + dy, wz + dw)
+    const int k = p >> 3, slot = p & 7;
+    const int x = s_xyz[k][0], y = s_xyz[k][1], wz = s_xyz[k][2];
+    const int dx = slot & 1, dy = (slot >> 1) & 1, dw = slot >> 2;
+    const bool have = x + dx < D.nx && y + dy < D.ny && wz + dw < D.wz;
+    const int w2 = ((x + dx) * D.ny + (y + dy)) * D.wz + wz + dw;
+    u64 sg = 0ull;
+    int c2 = -1;
+    if (have) {
+      sg = bits[w2];
+      c2 = slot == 0 ? ci0 + k : cmap[w2];
+    }
+    mc_nb e;
+    e.ex = e.ey = e.ez = 0; e.vbase = 0; e.have = 0;
+    if (c2 >= 0) {
+      const mc_rec r2 = rec[c2];
+      e.ex = r2.ex; e.ey = r2.ey; e.ez = r2.ez; e.vbase = r2.vbase; e.have = 1;
+    }
+    s_sg[k][slot] = sg;
+    s_nb[k][slot] = e;
+  }
+  __syncthreads();
+  const u64 lm = (1ull << lane) - 1ull;
+  const mc_rec first = s_rec[0], last = s_rec[nw - 1];
+  const int vbase0 = first.vbase, tbase0 = first.tbase;
+  const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) - vbase0;
+  const int ntt = last.tbase + last.pad - tbase0;
+  // ---- vertices
+  for (int vb = 0; vb < nvt; vb += LT_MC_VCAP) {
+    for (int k = 0; k < nw; ++k) {  // lane = voxel of word k: its (up to three) vertices into the list
+      const mc_rec R = s_rec[k];
+      const int fx = (int)((R.ex >> lane) & 1ull), fy = (int)((R.ey >> lane) & 1ull), fz = (int)((R.ez >> lane) & 1ull);
+      int j = R.vbase - vbase0 - vb + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
+      const unsigned e = (unsigned)k | ((unsigned)lane << 4);
+      if (fx) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e; ++j; }
+      if (fy) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e | (1u << 10); ++j; }
+      if (fz) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e | (2u << 10); }
+    }
+    __syncthreads();
+    const int nwin = min(LT_MC_VCAP, nvt - vb);
+    for (int j = lane; j < nwin; j += 64) {
+      const unsigned e = s_vl[j];
+      const int k = e & 15, b = (e >> 4) & 63, a = (e >> 10) & 3;
+      const int x = s_xyz[k][0], y = s_xyz[k][1], z = s_xyz[k][2] * 64 + b;
+      const size_t i = (size_t)x * sx + (size_t)y * sy + z;
+      const float v0 = tsdf[i];
+      const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : (size_t)1))];
+      float p0 = (float)x, p1 = (float)y, p2 = (float)z;
+      const float pe = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
+      if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+      // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
+      // (clamped: a NaN field value must not become a wild address; numpy would raise there)
+      const int i0 = min(max((int)rintf(p0), 0), D.nx - 1), i1 = min(max((int)rintf(p1), 0), D.ny - 1),
+                i2 = min(max((int)rintf(p2), 0), D.nz - 1);
+      const size_t jj = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
+      const float rgb = color_vol[jj];
+      const float rm = rem_vol[jj];
+      const int vid = vbase0 + vb + j;
+      if (vid < cap_v) {
+        verts[3 * (size_t)vid] = p0 * voxel_size + ox;  // verts * voxel_size + vol_origin in float32 (:412)
+        verts[3 * (size_t)vid + 1] = p1 * voxel_size + oy;
+        verts[3 * (size_t)vid + 2] = p2 * voxel_size + oz;
+        // colour unfolding (:419-423) in float32, .astype(np.uint8) = truncation to 8 bits
+        const float cb = floorf(rgb / (float)(256 * 256));
+        const float cg = floorf((rgb - cb * 256.0f * 256.0f) / 256.0f);
+        const float cr = rgb - cb * 256.0f * 256.0f - cg * 256.0f;
+        colors[3 * (size_t)vid] = (int)floorf(cr) & 255;
+        colors[3 * (size_t)vid + 1] = (int)floorf(cg) & 255;
+        colors[3 * (size_t)vid + 2] = (int)floorf(cb) & 255;
+        rem[vid] = rm;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
+  for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
+    for (int k = 0; k < nw; ++k) {  // lane = cell of word k: its (up to five) triangles into the list
+      const mc_rec R = s_rec[k];
+      u64 w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w8[q] = s_sg[k][q];
+      const mc_masks M = mc_build(w8, D, s_xyz[k][0], s_xyz[k][1], s_xyz[k][2]);
+      int cs = 0, nt = 0;
+      if ((M.ac >> lane) & 1ull) {
+        cs = mc_case(M, lane);
+        nt = LT_MC_NTRIS[cs];
+      }
+      int inc = nt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int q = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += q;
+      }
+      const int j0 = R.tbase - tbase0 - tb + inc - nt;
+      const unsigned e = (unsigned)k | ((unsigned)lane << 4) | ((unsigned)cs << 13);
+      for (int t = 0; t < nt; ++t)
+        if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = e | ((unsigned)t << 10);
+    }
+    __syncthreads();
+    const int nwin = min(LT_MC_TCAP, ntt - tb);
+    for (int j = lane; j < nwin; j += 64) {
+      const unsigned e = s_tl[j];
+      const int k = e & 15, b = (e >> 4) & 63, t = (e >> 10) & 7, cs = (e >> 13) & 255;
+      const ulonglong2 pk = ((const ulonglong2*)LT_MC_PACKED)[cs];
+      const int tid = tbase0 + tb + j;
+      int id[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int sh = 8 + 5 * (3 * t + q);
+        const u64 raw = sh < 64 ? ((pk.x >> sh) | (sh > 59 ? (pk.y << (64 - sh)) : 0ull)) : (pk.y >> (sh - 64));
+        const int code = (int)(raw & 31ull);
+        const int c0 = code & 7, ax = code >> 3;
+        int b2 = b + ((c0 >> 2) & 1), slot = c0 & 3;
+        if (b2 == 64) { b2 = 0; slot |= 4; }
+        const mc_nb nbe = s_nb[k][slot];
+        const u64 l2 = (1ull << b2) - 1ull;
+        int v = nbe.vbase + __popcll(nbe.ex & l2) + __popcll(nbe.ey & l2) + __popcll(nbe.ez & l2);
+        if (ax > 0) v += (int)((nbe.ex >> b2) & 1ull);
+        if (ax > 1) v += (int)((nbe.ey >> b2) & 1ull);
+        id[q] = v;
+      }
+      if (tid < cap_f) {
+        faces[3 * (size_t)tid] = id[0];
+        faces[3 * (size_t)tid + 1] = id[1];
+        faces[3 * (size_t)tid + 2] = id[2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------
 extern "C" int lt_mesh_create(lt_mesh** out, int device) {
   if (!out) {
@@ -549,6 +731,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
   LT_HIP(hipStreamSynchronize(stream));  // the one synchronisation: the sizes of the mesh
   const int n_active = m->totals_host[0], nv = m->totals_host[1], nf = m->totals_host[2];
+  static const bool dbg_mc = getenv("LIDARHIP_DEBUG_MC") != nullptr;
+  if (dbg_mc) fprintf(stderr, "marching cubes: %d active words, %d vertices, %d triangles\n", n_active, nv, nf);
   if (nv == 2147483647 || nf == 2147483647) {
     lt_set_error("lt_marching_cubes_dev: mesh exceeds 2^31 - 1 vertices / faces");
     return LT_ERR_TOO_LARGE;
@@ -582,10 +766,23 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   }
   hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647));
-  if (n_active > 0)
-    hipLaunchKernelGGL(k_mc_emit, dim3(n_active), dim3(64), 0, stream, tsdf, color_vol, rem_vol, bits, D,
-                       m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], m->verts, m->faces,
-                       m->colors, m->rem, m->cap_v, m->cap_f);
+  static const bool emit_waves = []() {  // A/B: LIDARHIP_MC_EMIT=waves -> one wave per active word (k_mc_emit)
+    const char* e = getenv("LIDARHIP_MC_EMIT");
+    return e && strcmp(e, "waves") == 0;
+  }();
+#define LT_MC_EMIT_ARGS tsdf, color_vol, rem_vol, bits, D, m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], \
+                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f
+  if (n_active > 0 && emit_waves)
+    hipLaunchKernelGGL(k_mc_emit, dim3(n_active), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+  else if (n_active > 0)
+  {
+    static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
+    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, dim3((n_active + 15) / 16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, dim3((n_active + 7) / 8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, dim3((n_active + 3) / 4), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else hipLaunchKernelGGL(k_mc_emit_batch<2>, dim3((n_active + 1) / 2), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+  }
+#undef LT_MC_EMIT_ARGS
   LT_HIP(hipGetLastError());
   m->n_verts = nv;
   m->n_faces = nf;
