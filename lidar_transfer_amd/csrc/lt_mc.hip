@@ -462,8 +462,11 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   __shared__ int s_xyz[K][3];       // x, y, wz of the words
   __shared__ u64 s_sg[K][8];        // sign words of the cell corners, [dx | dy << 1 | dw << 2]
   __shared__ mc_nb s_nb[K][8];      // records of the 8 words a cell's triangles can reference
+  __shared__ u64 s_cm[K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
   __shared__ unsigned s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10
   __shared__ unsigned s_tl[LT_MC_TCAP];  // triangle j of the window: k | b << 4 | t << 10 | case << 13
+  __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | case << 13
+  __shared__ int s_ct[K * 64];           // ... and the (batch-relative) index of their first triangle
   const int lane = threadIdx.x;
   const int ci0 = blockIdx.x * K;
   const int nw = min(K, n_active - ci0);
@@ -497,6 +500,19 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     s_sg[k][slot] = sg;
     s_nb[k][slot] = e;
+  }
+  __syncthreads();
+  if (lane < nw) {  // the cell masks of word `lane`, once
+    u64 w8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w8[q] = s_sg[lane][q];
+    const mc_masks M = mc_build(w8, D, s_xyz[lane][0], s_xyz[lane][1], s_xyz[lane][2]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s_cm[lane][q] = M.m[q & 1][q >> 1];
+      s_cm[lane][4 + q] = M.s[q & 1][q >> 1];
+    }
+    s_cm[lane][8] = M.ac;
   }
   __syncthreads();
   const u64 lm = (1ull << lane) - 1ull;
@@ -552,26 +568,42 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     __syncthreads();
   }
   // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
-  for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
-    for (int k = 0; k < nw; ++k) {  // lane = cell of word k: its (up to five) triangles into the list
-      const mc_rec R = s_rec[k];
-      u64 w8[8];
+  // the batch's active cells in order (word, z), with their case; then one scan per 64 cells gives every cell the index
+  // of its first triangle (a scan per word cost more vector instructions than everything else in this kernel)
+  int ncell = 0;  // (wave-uniform)
+  for (int k = 0; k < nw; ++k) {
+    const u64 ac = s_cm[k][8];
+    if (ac == 0ull) continue;
+    if ((ac >> lane) & 1ull) {
+      int cs = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) w8[q] = s_sg[k][q];
-      const mc_masks M = mc_build(w8, D, s_xyz[k][0], s_xyz[k][1], s_xyz[k][2]);
-      int cs = 0, nt = 0;
-      if ((M.ac >> lane) & 1ull) {
-        cs = mc_case(M, lane);
-        nt = LT_MC_NTRIS[cs];
-      }
+      for (int q = 0; q < 8; ++q) cs |= (int)((s_cm[k][q] >> lane) & 1ull) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
+      s_cl[ncell + __popcll(ac & lm)] = (unsigned)k | ((unsigned)lane << 4) | ((unsigned)cs << 13);
+    }
+    ncell += __popcll(ac);
+  }
+  __syncthreads();
+  {
+    int run = 0;  // triangles before this chunk of cells (relative to the batch's first)
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+      const int c = c0 + lane;
+      const int nt = c < ncell ? LT_MC_NTRIS[(s_cl[c] >> 13) & 255] : 0;
       int inc = nt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const int q = __shfl_up(inc, o, 64);
         if (lane >= o) inc += q;
       }
-      const int j0 = R.tbase - tbase0 - tb + inc - nt;
-      const unsigned e = (unsigned)k | ((unsigned)lane << 4) | ((unsigned)cs << 13);
+      if (c < ncell) s_ct[c] = run + inc - nt;
+      run += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
+    for (int c = lane; c < ncell; c += 64) {  // a cell's (up to five) triangles into the window's list
+      const unsigned e = s_cl[c];
+      const int nt = LT_MC_NTRIS[(e >> 13) & 255];
+      const int j0 = s_ct[c] - tb;
       for (int t = 0; t < nt; ++t)
         if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = e | ((unsigned)t << 10);
     }
