@@ -41,7 +41,16 @@ struct mc_dims {
   int nx, ny, nz;
   int wz;        // 64-bit words per (x, y) row
   int n_words;   // nx * ny * wz
+  unsigned wz_m; int wz_s;  // w / wz by multiplication (mc_row_of): an integer division is ~40 vector instructions, and
+                            // k_mc_words runs one per word of the volume (16 M on the default one)
 };
+
+// row = w / D.wz for 0 <= w < 2^31 (round-up method: m = floor(2^32 (2^s - d) / d) + 1, s = ceil(log2 d))
+__device__ __forceinline__ int mc_row_of(const mc_dims& D, int w) {
+  if (D.wz_s == 0) return w;  // wz == 1
+  const unsigned n = (unsigned)w, t = __umulhi(n, D.wz_m);
+  return (int)((t + ((n - t) >> 1)) >> (D.wz_s - 1));
+}
 
 struct mc_rec {  // one per active word
   int w, vbase, tbase, pad;  // pad: the word's triangle count
@@ -186,32 +195,38 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
          col_epoch[min(row + D.ny + 1, last)] == epoch;
 }
 
+// One thread per ROW (x, y) of wz words, one block of the scan per WAVE (64 rows): a thread per word was 250 000 waves of
+// four stamp loads and a store -- 30 rounds of resident waves waiting for a load each, 103 us -- and the four words of a
+// row share their stamps.
 __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
                                                   unsigned epoch) {
-  __shared__ u64 wsum[4];
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  unsigned nv = 0, nt = 0;
-  if (w < D.n_words && !mc_rows_dirty(col_epoch, epoch, D, w / D.wz)) {
-    cnt[w] = 0u;
-  } else if (w < D.n_words) {
-    const int row = w / D.wz, wz = w - row * D.wz;
-    const int x = row / D.ny, y = row - x * D.ny;
-    const mc_masks M = mc_load(bits, D, x, y, wz);
-    nv = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
-    for (u64 a = M.ac; a; a &= a - 1) nt += LT_MC_NTRIS[mc_case(M, __ffsll((long long)a) - 1)];
-    cnt[w] = nv | (nt << 16);
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int n_rows = D.nx * D.ny;
+  unsigned na = 0, nv = 0, nt = 0;
+  if (row < n_rows) {
+    if (!mc_rows_dirty(col_epoch, epoch, D, row)) {
+      for (int k = 0; k < D.wz; ++k) cnt[(size_t)row * D.wz + k] = 0u;
+    } else {
+      const int x = row / D.ny, y = row - x * D.ny;
+      for (int k = 0; k < D.wz; ++k) {
+        const mc_masks M = mc_load(bits, D, x, y, k);
+        const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
+        unsigned t = 0;
+        for (u64 a = M.ac; a; a &= a - 1) t += LT_MC_NTRIS[mc_case(M, __ffsll((long long)a) - 1)];
+        cnt[(size_t)row * D.wz + k] = v | (t << 16);
+        na += (v | t) ? 1u : 0u; nv += v; nt += t;
+      }
+    }
   }
-  u64 p = pack3((nv | nt) ? 1u : 0u, nv, nt);
+  u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 320 triangles -- the host checks wz)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = p;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    p = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    blk[3 * blockIdx.x] = (int)(p & 0xFFFFF);
-    blk[3 * blockIdx.x + 1] = (int)((p >> 20) & 0xFFFFF);
-    blk[3 * blockIdx.x + 2] = (int)((p >> 40) & 0xFFFFF);
+  if ((threadIdx.x & 63) == 0) {
+    const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    blk[3 * blkid] = (int)(p & 0xFFFFF);
+    blk[3 * blkid + 1] = (int)((p >> 20) & 0xFFFFF);
+    blk[3 * blkid + 2] = (int)((p >> 40) & 0xFFFFF);
   }
 }
 
@@ -269,38 +284,49 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
                                                     const unsigned* __restrict__ cnt, const int* __restrict__ blk,
                                                     const int* __restrict__ seg, int* __restrict__ cmap,
                                                     mc_rec* __restrict__ rec, int cap_rec) {
-  __shared__ u64 wsum[4];
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  const unsigned c = w < D.n_words ? cnt[w] : 0u;
-  const unsigned nv = c & 0xFFFFu, nt = c >> 16;
-  const u64 mine = pack3(c ? 1u : 0u, nv, nt);
-  const u64 inc = wave_incl_scan(mine);
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  u64 off = 0;
-  for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += wsum[k];
-  const u64 ex = off + inc - mine;
-  if (w >= D.n_words) return;
-  int ci = -1;
-  if (c) {
-    const int* sg = seg + 3 * (blockIdx.x >> 8);
-    ci = sg[0] + blk[3 * blockIdx.x] + (int)(ex & 0xFFFFF);
-    if (ci < cap_rec) {
-      const int row = w / D.wz, wz = w - row * D.wz;
-      const int x = row / D.ny, y = row - x * D.ny;
-      const mc_masks M = mc_load(bits, D, x, y, wz);
-      mc_rec r;
-      r.w = w;
-      r.vbase = sg[1] + blk[3 * blockIdx.x + 1] + (int)((ex >> 20) & 0xFFFFF);
-      r.tbase = sg[2] + blk[3 * blockIdx.x + 2] + (int)((ex >> 40) & 0xFFFFF);
-      r.pad = (int)nt;  // triangles of the word (k_mc_emit_batch: the extent of a batch)
-      r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
-      rec[ci] = r;
-    } else {
-      ci = -1;
+  // thread = row, scan block = wave (as in k_mc_words); compact order = word order
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int n_rows = D.nx * D.ny;
+  unsigned na = 0, nv = 0, nt = 0;
+  if (row < n_rows)
+    for (int k = 0; k < D.wz; ++k) {
+      const unsigned c = cnt[(size_t)row * D.wz + k];
+      na += c ? 1u : 0u; nv += c & 0xFFFFu; nt += c >> 16;
     }
+  if (__ballot(na != 0u) == 0ull) {  // no active word in these 64 rows (most waves): nothing to rank
+    if (row < n_rows)
+      for (int k = 0; k < D.wz; ++k) cmap[(size_t)row * D.wz + k] = -1;
+    return;
   }
-  cmap[w] = ci;
+  const u64 mine = pack3(na, nv, nt);
+  const u64 ex = wave_incl_scan(mine) - mine;
+  if (row >= n_rows) return;
+  const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int* sg = seg + 3 * (blkid >> 8);
+  int ci = sg[0] + blk[3 * blkid] + (int)(ex & 0xFFFFF);
+  int vb = sg[1] + blk[3 * blkid + 1] + (int)((ex >> 20) & 0xFFFFF);
+  int tb = sg[2] + blk[3 * blkid + 2] + (int)((ex >> 40) & 0xFFFFF);
+  const int x = row / D.ny, y = row - x * D.ny;
+  for (int k = 0; k < D.wz; ++k) {
+    const int w = row * D.wz + k;
+    const unsigned c = cnt[w];
+    int mine_ci = -1;
+    if (c) {
+      if (ci < cap_rec) {
+        const mc_masks M = mc_load(bits, D, x, y, k);
+        mc_rec r;
+        r.w = w;
+        r.vbase = vb;
+        r.tbase = tb;
+        r.pad = (int)(c >> 16);  // triangles of the word (k_mc_emit_batch: the extent of a batch)
+        r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
+        rec[ci] = r;
+        mine_ci = ci;
+      }
+      ++ci; vb += (int)(c & 0xFFFFu); tb += (int)(c >> 16);
+    }
+    cmap[w] = mine_ci;
+  }
 }
 
 // ---- k_mc_emit --------------------------------------------------------------------------------------------------------
@@ -722,13 +748,24 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   mc_dims D;
   D.nx = nx; D.ny = ny; D.nz = nz;
   D.wz = (nz + 63) / 64;
+  {
+    int sh = 0;
+    while ((1u << sh) < (unsigned)D.wz) ++sh;
+    D.wz_s = sh;
+    D.wz_m = sh == 0 ? 0u : (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << sh) - (unsigned)D.wz)) / (unsigned)D.wz + 1ull);
+  }
   const size_t n_words = (size_t)nx * ny * D.wz;
   if (n_words >= 2147483647ull) {
     lt_set_error("lt_marching_cubes_dev: volume too large");
     return LT_ERR_TOO_LARGE;
   }
   D.n_words = (int)n_words;
-  const int n_blocks = (D.n_words + 255) / 256;
+  const int n_rows = nx * ny;
+  const int n_blocks = ((n_rows + 255) / 256) * 4;  // one block of the scan per wave of 64 rows
+  if (D.wz > 48) {  // (the packed per-block totals hold 20 bits a field: 64 rows x wz words x 320 triangles)
+    lt_set_error("lt_marching_cubes_dev: nz = %d exceeds 3072", nz);
+    return LT_ERR_TOO_LARGE;
+  }
   if (n_words > m->cap_words || !m->bits) {
     if (m->bits) {
       LT_HIP(hipDeviceSynchronize());
@@ -756,7 +793,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
                        tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
-  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
+  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
                      epoch);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
@@ -796,7 +833,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }
-  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
+  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647));
   static const bool emit_waves = []() {  // A/B: LIDARHIP_MC_EMIT=waves -> one wave per active word (k_mc_emit)
     const char* e = getenv("LIDARHIP_MC_EMIT");
