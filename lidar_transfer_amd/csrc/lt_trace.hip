@@ -232,13 +232,16 @@ __global__ __launch_bounds__(256) void k_trace(
 #define LT_Q_XOR1 0xB1  // quad_perm [1,0,3,2]
 #define LT_Q_XOR2 0x4E  // quad_perm [2,3,0,1]
 
+// (mov_dpp = update_dpp with an UNDEFINED old value: every source lane of a quad permutation exists, so nothing is kept
+// from it -- with old = 0 the compiler set the destination to 0 before each of the ten permutations of a node step,
+// 10 % of the vector instructions of a kernel that is vector-issue bound)
 template <int CTRL>
 __device__ __forceinline__ int qperm_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ float qperm_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 #define LT_TILE4_H 2
@@ -373,6 +376,14 @@ __global__ __launch_bounds__(256) void k_trace4(
   int n_steps = 0;          // node + leaf steps of this quad's ray
   bool handed_over = false;  // the ray goes on in k_trace4_tail
   int* spill = overflow + ray * (LT_STACK4_MAX - LT_STACK4_LDS);
+  // entry s of this quad's stack: LDS below LT_STACK4_LDS, the spill area above.  (Written as a select of the two, the
+  // compiler loads through a FLAT pointer chosen per lane: an LDS read always, the global one in a branch almost never taken.)
+  auto pop = [&](int s) {
+    typedef __attribute__((address_space(3))) int lds_int;  // (volatile LDS access: not to be merged with the other load)
+    int v = *(volatile lds_int*)(lds_int*)&stack[wave][min(s, LT_STACK4_LDS - 1)][q];
+    if (s >= LT_STACK4_LDS) v = spill[s - LT_STACK4_LDS];
+    return v;
+  };
 
   // ONE loop whose trips are steps of either kind ("if-if" traversal): a wave needs max-over-its-quads trips.  The
   // nested form (inner loop over nodes, leaf step outside) makes a quad that has reached a leaf wait for every other
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void k_trace4(
       if (nh == 0) {
         if (sp > 0) {
           --sp;
-          cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
+          cur = pop(sp);
         } else {
           cur = LT_DONE;
         }
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(256) void k_trace4(
       }
       if (sp > 0) {
         --sp;
-        cur = sp < LT_STACK4_LDS ? stack[wave][sp][q] : spill[sp - LT_STACK4_LDS];
+        cur = pop(sp);
       } else {
         cur = LT_DONE;
       }

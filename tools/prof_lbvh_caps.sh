@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for c in 40 48; do
+for c in ${CAPS:-40 48}; do
 LIDARHIP_STEP_CAP=$c rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/lb$c -o s -- python $R/tools/prof_scan.py --reps 40 > /dev/null 2>&1
 python - <<PY
 import csv
