@@ -399,14 +399,15 @@ __global__ __launch_bounds__(256) void k_trace4(
       float tn;
       int ref;
       const int hit = trace_slab(a, b, ox, oy, oz, ix, iy, iz, best_t, tn, ref);
-      // rank of this child among the hit children of the quad (by tn, then lane)
-      const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
-      const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);
-      const int h0 = qperm_i<LT_Q_BCAST(0)>(hit), h1 = qperm_i<LT_Q_BCAST(1)>(hit);
-      const int h2 = qperm_i<LT_Q_BCAST(2)>(hit), h3 = qperm_i<LT_Q_BCAST(3)>(hit);
-      const int nh = h0 + h1 + h2 + h3;
-      const int rank = (h0 & ((t0 < tn) | ((t0 == tn) & (0 < j)))) + (h1 & ((t1 < tn) | ((t1 == tn) & (1 < j)))) +
-                       (h2 & ((t2 < tn) | ((t2 == tn) & (2 < j)))) + (h3 & ((t3 < tn) | ((t3 == tn) & (3 < j))));
+      // rank of this child among the hit children of the quad: by (tn, lane) packed into one unsigned key -- tn >= 0, so
+      // its bits order like its value; the two mantissa bits given to the lane only perturb the ORDER of near-equal
+      // children, which the result does not depend on; a child that is not hit has the largest key and is never counted
+      const unsigned key = hit ? ((__float_as_uint(tn) & ~3u) | (unsigned)j) : 0xFFFFFFFFu;
+      const unsigned k0 = (unsigned)qperm_i<LT_Q_BCAST(0)>((int)key), k1 = (unsigned)qperm_i<LT_Q_BCAST(1)>((int)key);
+      const unsigned k2 = (unsigned)qperm_i<LT_Q_BCAST(2)>((int)key), k3 = (unsigned)qperm_i<LT_Q_BCAST(3)>((int)key);
+      const int rank = (int)(k0 < key) + (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+      const unsigned long long hm = __ballot(hit != 0);
+      const int nh = __popc((unsigned)(hm >> (lane & ~3)) & 15u);
       if (nh == 0) {
         if (sp > 0) {
           --sp;
@@ -576,15 +577,14 @@ __global__ __launch_bounds__(64) void k_trace4_tail(
       }
       // push the hit children of all quads: far ones first inside a quad (the nearer child is popped first); the
       // quads are stacked in reverse order so that quad 0's children -- the subtree of the old top -- end on top
-      const float t0 = qperm_f<LT_Q_BCAST(0)>(tn), t1 = qperm_f<LT_Q_BCAST(1)>(tn);
-      const float t2 = qperm_f<LT_Q_BCAST(2)>(tn), t3 = qperm_f<LT_Q_BCAST(3)>(tn);
-      const int h0 = qperm_i<LT_Q_BCAST(0)>(hit), h1 = qperm_i<LT_Q_BCAST(1)>(hit);
-      const int h2 = qperm_i<LT_Q_BCAST(2)>(hit), h3 = qperm_i<LT_Q_BCAST(3)>(hit);
-      const int nh = h0 + h1 + h2 + h3;
-      const int rank = (h0 & ((t0 < tn) | ((t0 == tn) & (0 < j)))) + (h1 & ((t1 < tn) | ((t1 == tn) & (1 < j)))) +
-                       (h2 & ((t2 < tn) | ((t2 == tn) & (2 < j)))) + (h3 & ((t3 < tn) | ((t3 == tn) & (3 < j))));
+      // rank inside the quad by the packed (tn, lane) key, as in k_trace4
+      const unsigned key = hit ? ((__float_as_uint(tn) & ~3u) | (unsigned)j) : 0xFFFFFFFFu;
+      const unsigned k0 = (unsigned)qperm_i<LT_Q_BCAST(0)>((int)key), k1 = (unsigned)qperm_i<LT_Q_BCAST(1)>((int)key);
+      const unsigned k2 = (unsigned)qperm_i<LT_Q_BCAST(2)>((int)key), k3 = (unsigned)qperm_i<LT_Q_BCAST(3)>((int)key);
+      const int rank = (int)(k0 < key) + (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
       // exclusive prefix of nh over the quads ABOVE this one (quads q+1 .. 15), via the hit ballot
       const unsigned long long hm = __ballot(hit != 0);
+      const int nh = __popc((unsigned)(hm >> (lane & ~3)) & 15u);
       const int above = q == 15 ? 0 : __popcll(hm >> ((q + 1) * 4));
       const int total = __popcll(hm);
       if (hit) stk[sp + above + (nh - 1 - rank)] = ref;
