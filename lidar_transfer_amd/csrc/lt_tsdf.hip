@@ -141,14 +141,20 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(float* __restrict__ tsdf
                      rem_im[py * im_w + px]);
 }
 
-// largest depth of every image column (W threads)
+// largest depth of every image column: a workgroup takes 64 columns, its four waves a quarter of the rows each (rows of
+// the image are contiguous: coalesced), partial maxima through LDS.  (One thread per column walking its rows: 8
+// workgroups, 64 dependent-latency loads each, 18 us.)
 __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ depth_im, int im_h, int im_w,
                                                      float* __restrict__ colmax) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= im_w) return;
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + tx;
   float m = 0.f;
-  for (int y = 0; y < im_h; ++y) m = fmaxf(m, depth_im[y * im_w + x]);
-  colmax[x] = m;
+  if (x < im_w)
+    for (int y = ty; y < im_h; y += 4) m = fmaxf(m, depth_im[y * im_w + x]);
+  part[ty][tx] = m;
+  __syncthreads();
+  if (ty == 0 && x < im_w) colmax[x] = fmaxf(fmaxf(part[0][tx], part[1][tx]), fmaxf(part[2][tx], part[3][tx]));
 }
 
 // per voxel column (x, y): its image column px -- the kernel's own expressions on voxel_x = x, voxel_y = y -- or -1
@@ -568,7 +574,7 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     t->cap_w = im_w;
   }
   const int n_cols = t->dim[0] * t->dim[1];
-  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 255) / 256), dim3(256), 0, stream, depth_im, im_h, im_w, t->colmax);
+  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, im_h, im_w, t->colmax);
   hipLaunchKernelGGL(k_tsdf_columns, dim3((n_cols + 255) / 256), dim3(256), 0, stream, t->dim[0], t->dim[1], t->origin[0],
                      t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo);
   // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
