@@ -244,8 +244,12 @@ __device__ __forceinline__ float qperm_f(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-#define LT_TILE4_H 2
-#define LT_TILE4_W 8
+// rays of a wave: a LT_TILE4_H x LT_TILE4_W tile of the image (16 rays).  k_trace4 on C2 (tools/tile_ab.sh): 2 x 8 60.3 us,
+// 1 x 16 61.9, 4 x 4 57.0, 8 x 2 56.9 -- a beam step is 2.5 azimuth steps there, 4 x 4 is the most compact in angle
+#ifndef LT_TILE4_H
+#define LT_TILE4_H 4
+#define LT_TILE4_W 4
+#endif
 
 // hit write-back of one ray (RayTracer.cpp:73-90); misses are written only with LT_TRACE_WRITE_MISSES
 __device__ __forceinline__ void trace_writeback(size_t ray, float best_t, int best_face, float ox, float oy, float oz,
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void k_trace4(
   const int tiles_h = (H + LT_TILE4_H - 1) / LT_TILE4_H, tiles_w = (W + LT_TILE4_W - 1) / LT_TILE4_W;
   const int wt = lb * 4 + wave;
   const int tile_x = wt / tiles_h, tile_y = wt - tile_x * tiles_h;
-  const int h = tile_y * LT_TILE4_H + (q >> 3), w = tile_x * LT_TILE4_W + (q & 7);
+  const int h = tile_y * LT_TILE4_H + q / LT_TILE4_W, w = tile_x * LT_TILE4_W + q % LT_TILE4_W;
   const bool active = tile_x < tiles_w && h < H && w < W;
   const size_t ray = (size_t)h * W + w;
 
