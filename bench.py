@@ -771,6 +771,12 @@ def main():
                                     "frac_of_peak": round(K / dt * per_scan / 1e9 / HBM_PEAK_GBS, 4),
                                     "note": "PMC traffic of k_sc_tris + k_sc_rest + k_sc_resolve per scan x scans/s of "
                                             "this rank; 6290 GB/s is what a float4 copy reaches on this chip"}
+                ents = [measured_traffic("scatter", args.batch, k)[2] for k in ("k_sc_tris", "k_sc_rest", "k_sc_resolve")]
+                if all(e and e.get("valu_active_quad_cycles_per_launch") for e in ents):
+                    # the three kernels' vector-issue cycles per SIMD per scan against the wall time of a scan in the timed
+                    # region (world == 1 figure of this rank): how full the chip's vector units are over the whole region
+                    busy = sum(e["valu_active_quad_cycles_per_launch"] for e in ents) * 4.0 / N_SIMD / args.batch
+                    rl["whole_path"]["valu_busy_frac_of_timed_region"] = round(busy / SHADER_GHZ / 1e9 / (dt / K), 4)
             else:
                 rl["whole_path"] = None
         out = {
