@@ -53,6 +53,10 @@ struct rs_params {
   float el_lo, el_scale;
   float dev_az, dev_el;  // written with atomicMax on the float bits (non-negative)
   float dev_fit[2];      // k_rs_fit: dev_az the grid would have with W / W - 1 columns
+  // derived on the host once the deviations are known (rs_derive): tri_bins' bin coordinates as ONE fma each,
+  //   row bounds    ceil(th * el_scale + el_c0), floor(th * el_scale + el_c1)
+  //   column bounds ceil(a * az_scale + az_c0),  floor(a * az_scale + az_c1)
+  float el_c0, el_c1, az_c0, az_c1;
 };
 
 __device__ __forceinline__ float rs_az_off(float phi0, float az_scale) {
@@ -284,8 +288,10 @@ struct bin_rect { int a0, na, e0, e1; };  // azimuth: na bins starting at a0 (mo
 // conservative angular bounds of a triangle seen from the origin -> bin rectangle (na == 0: nothing to do).
 // Everything in here is approximate-but-padded, so contraction to FMA is allowed (unlike the triangle test)
 // and minima / maxima are taken on squared lengths (4 square roots per triangle instead of 15).
+// (e1 = v1 - v0, e2 = v2 - v0 in the xy plane: the record's edge vectors, which the callers have anyway)
 __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float y0, float z0, float x1, float y1,
-                                             float z1, float x2, float y2, float z2) {
+                                             float z1, float x2, float y2, float z2, float e1x, float e1y, float e2x,
+                                             float e2y) {
 #pragma clang fp contract(fast)
   bin_rect R;  // only R.na is defined when the rectangle is empty (callers test R.na > 0 first)
   R.na = 0;
@@ -320,8 +326,8 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   // d^2 >= min(q) - L^2 / 4 with L the longest edge.  For a triangle small against its distance from the axis
   // (every triangle of a 5 cm mesh beyond half a metre) that is within 0.13 % of the exact distance at a third
   // of its cost; waves holding a triangle for which it is loose take the three exact point-segment distances.
-  const float e01x = x1 - x0, e01y = y1 - y0, e12x = x2 - x1, e12y = y2 - y1, e20x = x0 - x2, e20y = y0 - y2;
-  const float lmax2 = fmaxf(e01x * e01x + e01y * e01y, fmaxf(e12x * e12x + e12y * e12y, e20x * e20x + e20y * e20y));
+  const float e12x = e2x - e1x, e12y = e2y - e1y;
+  const float lmax2 = fmaxf(e1x * e1x + e1y * e1y, fmaxf(e12x * e12x + e12y * e12y, e2x * e2x + e2y * e2y));
   const float qmin = fminf(q0, fminf(q1, q2));
   float rho_edges2;
   if (__ballot(!(lmax2 <= 0.01f * qmin)) == 0ull) {  // wave-uniform
@@ -342,7 +348,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   // angular padding: float rounding of atan2 and of the ray bins, plus the positional slop (<= ~1e-4 m) with
   // which the float Moller-Trumbore test may accept a ray that passes just outside the triangle, seen from the
   // closest the triangle can be: every point of it has rho >= rho_min and |z| >= z_near
-  const float z_near = zmin > 0.f ? zmin : (zmax < 0.f ? zmax : 0.f);
+  const float z_near = __builtin_amdgcn_fmed3f(zmin, 0.f, zmax);  // 0 clamped into [zmin, zmax]
   const float dlo2 = fmaxf((pierced ? 0.f : rho_edges2) + z_near * z_near, 0.0025f);
   const float pad = 3e-4f + 2e-4f * __builtin_amdgcn_rsqf(dlo2);
   // the same positional slop seen in AZIMUTH subtends slop / rho (horizontal distance), not slop / distance: a
@@ -354,8 +360,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   th_hi += pad;
   th_lo -= pad;
   // rows whose rays can lie inside [th_lo, th_hi]; LT_BIN_SLACK covers the float rounding of the coordinates
-  const float de = P.dev_el + LT_BIN_SLACK, da = P.dev_az + LT_BIN_SLACK;
-  const float fe0 = ceilf((th_lo - P.el_lo) * P.el_scale - de), fe1 = floorf((th_hi - P.el_lo) * P.el_scale + de);
+  const float fe0 = ceilf(th_lo * P.el_scale + P.el_c0), fe1 = floorf(th_hi * P.el_scale + P.el_c1);  // (rs_derive)
   if (!(fe1 >= 0.f) || !(fe0 <= (float)(P.nb_el - 1)) || !(fe0 <= fe1)) return R;  // no row (or NaN)
   R.e0 = (int)fmaxf(fe0, 0.f);
   R.e1 = (int)fminf(fe1, (float)(P.nb_el - 1));
@@ -387,8 +392,8 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   }
   a_lo -= pad_az;
   a_hi += pad_az;
-  const float fa0 = ceilf((a_lo + LT_PI_F) * P.az_scale - P.az_off - da);
-  const float fa1 = floorf((a_hi + LT_PI_F) * P.az_scale - P.az_off + da);
+  const float fa0 = ceilf(a_lo * P.az_scale + P.az_c0);
+  const float fa1 = floorf(a_hi * P.az_scale + P.az_c1);
   const int na = (int)(fa1 - fa0) + 1;
   if (!(na >= 1)) return R;  // no ray column inside the arc (or NaN)
   if (na >= P.nb_az) { R.a0 = 0; R.na = P.nb_az; return R; }
@@ -494,16 +499,20 @@ __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ 
       const f3 C = *at<WIDE>((const f3*)verts, (unsigned)c);
       const float v0x = A.x, v0y = A.y, v0z = A.z, v1x = B.x, v1y = B.y, v1z = B.z;
       const float v2x = C.x, v2y = C.y, v2z = C.z;
+#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads only
+      return (v0x + v1y + v2z == 12345.f) ? 1 : 0;
+#endif
+      const float e1x = v1x - v0x, e1y = v1y - v0y, e2x = v2x - v0x, e2y = v2y - v0y;
       const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
-                                  v2z - oz);
+                                  v2z - oz, e1x, e1y, e2x, e2y);
       if (R.na > 0) {  // (rows e0..e1 are non-empty whenever na > 0)
         const int c32 = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
         if (c32 > LT_SC_BIG) {
           if (PUSH) large[atomicAdd(large_count, 1)] = f;
         } else {
           cnt = c32;
-          S.q0[tid] = make_float4(v0x, v0y, v0z, v1x - v0x);
-          S.q1[tid] = make_float4(v1y - v0y, v1z - v0z, v2x - v0x, v2y - v0y);
+          S.q0[tid] = make_float4(v0x, v0y, v0z, e1x);
+          S.q1[tid] = make_float4(e1y, v1z - v0z, e2x, e2y);
           // a0 < 8192, na <= LT_SC_BIG; 1-ulp reciprocal is enough, see sc_round_robin
           S.q2[tid] = make_float4(v2z - v0z, __int_as_float(R.a0 | (R.na << 16)), __int_as_float(R.e0),
                                   f_rcp((float)R.na));
@@ -655,6 +664,10 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   const float ox = J.ox, oy = J.oy, oz = J.oz;
   const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P, J.large,
                                        J.large_count, J.flags);
+#if defined(LT_SC_STOP) && LT_SC_STOP <= 2  // ... up to the angular bounds and the LDS record
+  if (cnt == 0x7fffffff) J.counters[7] = 1;
+  return;
+#endif
   int total;
   const int mypre = sc_prefix(S, cnt, total);
   // The workgroup keeps the triangles that start below the cap; exactly one thread sees the crossing and
@@ -676,6 +689,10 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
     S.kept = kept;
   }
   __syncthreads();
+#if defined(LT_SC_STOP) && LT_SC_STOP == 3  // ... up to the prefix sums and the cap
+  if (S.kept == 0x7fffffff) J.counters[7] = 1;
+  return;
+#endif
   unsigned n_tests = 0, n_cand = 0;
   sc_round_robin<COUNT, WIDE>(S, P, J.grid, J.sdirs, J.cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
   sc_count<COUNT>(n_tests, n_cand, J.counters);
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
     T.e1x = v1x - T.v0x; T.e1y = v1y - T.v0y; T.e1z = v1z - T.v0z;
     T.e2x = v2x - T.v0x; T.e2y = v2y - T.v0y; T.e2z = v2z - T.v0z;
     const bin_rect R = tri_bins(P, T.v0x - ox, T.v0y - oy, T.v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox,
-                                v2y - oy, v2z - oz);
+                                v2y - oy, v2z - oz, T.e1x, T.e1y, T.e2x, T.e2y);
     const int total = R.na > 0 ? R.na * (R.e1 - R.e0 + 1) : 0;  // <= 8192 x 4096 bins (lt_rayset_create_dev)
     const int parts = min(max((total + 1023) / 1024, 1), LT_SC_PARTS);
     if (part >= parts) continue;
@@ -813,6 +830,15 @@ __global__ __launch_bounds__(256) void k_sc_resolve(const sc_batch B) {
 // sort kernels of lt_build.hip
 void lt_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, int n, int key_bits, hipStream_t stream,
                    int* out_buffer);
+
+// el_c0 = -el_lo el_scale - (dev_el + slack), el_c1 = ... + ..., az_c0 = pi az_scale - az_off - (dev_az + slack), az_c1 = ... +
+static void rs_derive(rs_params& p) {
+  const float de = p.dev_el + LT_BIN_SLACK, da = p.dev_az + LT_BIN_SLACK;
+  p.el_c0 = -p.el_lo * p.el_scale - de;
+  p.el_c1 = -p.el_lo * p.el_scale + de;
+  p.az_c0 = LT_PI_F * p.az_scale - p.az_off - da;
+  p.az_c1 = LT_PI_F * p.az_scale - p.az_off + da;
+}
 
 struct lt_rayset {
   int device;
@@ -933,6 +959,7 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
     free(r);
     return LT_ERR_HIP;
   }
+  rs_derive(r->prm_host);
   *out = r;
   return LT_OK;
 }
