@@ -493,6 +493,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   __shared__ unsigned s_tl[LT_MC_TCAP];  // triangle j of the window: k | b << 4 | t << 10 | case << 13
   __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | case << 13
   __shared__ int s_ct[K * 64];           // ... and the (batch-relative) index of their first triangle
+  __shared__ int s_cpre[K + 1];          // active cells before word k
   const int lane = threadIdx.x;
   const int ci0 = blockIdx.x * K;
   const int nw = min(K, n_active - ci0);
@@ -540,14 +541,59 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     s_cm[lane][8] = M.ac;
   }
+  {  // active cells before each word (lanes 0 .. nw - 1 hold the words' counts)
+    int c = lane < nw ? __popcll(s_cm[lane][8]) : 0;  // (own write: same lane)
+    const int mine = c;
+#pragma unroll
+    for (int o = 1; o < K; o <<= 1) {
+      const int q = __shfl_up(c, o, 64);
+      if (lane >= o) c += q;
+    }
+    if (lane < nw) s_cpre[lane + 1] = c;
+    if (lane == 0) s_cpre[0] = 0;
+    (void)mine;
+  }
   __syncthreads();
   const u64 lm = (1ull << lane) - 1ull;
   const mc_rec first = s_rec[0], last = s_rec[nw - 1];
   const int vbase0 = first.vbase, tbase0 = first.tbase;
   const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) - vbase0;
   const int ntt = last.tbase + last.pad - tbase0;
+#if defined(LT_MC_STOP) && LT_MC_STOP == 1  // instruction-count experiment (tools/mc_sections.sh): staging only
+  return;
+#endif
   // ---- vertices
+  // Two ways to list them.  SPARSE batch (the usual one: a street scene's word owns 3.6 vertices): lane j finds vertex j --
+  // its word by the words' vertex bases, its voxel by a binary search over the popcounts of the three edge masks below a
+  // bit -- one pass of ~150 vector instructions for up to 64 vertices.  DENSE batch (walls along z, noise): a pass per
+  // word with a lane per voxel, ~35 instructions a word, whatever it holds.
+  const bool sparse_v = nvt <= 128;
   for (int vb = 0; vb < nvt; vb += LT_MC_VCAP) {
+    if (sparse_v) {
+      for (int j = lane; j < min(LT_MC_VCAP, nvt - vb); j += 64) {
+        const int g = vb + j;  // vertex g of the batch
+        int k = 0;
+        for (int q = 1; q < nw; ++q) k += (s_rec[q].vbase - vbase0 <= g) ? 1 : 0;
+        const mc_rec R = s_rec[k];
+        const int r = g - (R.vbase - vbase0);  // rank inside the word, in (voxel, axis) order
+        int b = 0;  // largest b with (vertices of voxels below b) <= r: the owner voxel
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+          const u64 below = (1ull << (b + sh)) - 1ull;  // (b + sh <= 63)
+          const int c = __popcll(R.ex & below) + __popcll(R.ey & below) + __popcll(R.ez & below);
+          if (c <= r) b += sh;
+        }
+        const u64 below = (1ull << b) - 1ull;
+        int a_r = r - (__popcll(R.ex & below) + __popcll(R.ey & below) + __popcll(R.ez & below));  // 0 .. 2 among the voxel's
+        const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull);
+        int axis = 0;
+        if (!(fx && a_r == 0)) {
+          a_r -= fx;
+          axis = (fy && a_r == 0) ? 1 : 2;
+        }
+        s_vl[j] = (unsigned)k | ((unsigned)b << 4) | ((unsigned)axis << 10);
+      }
+    } else
     for (int k = 0; k < nw; ++k) {  // lane = voxel of word k: its (up to three) vertices into the list
       const mc_rec R = s_rec[k];
       const int fx = (int)((R.ex >> lane) & 1ull), fy = (int)((R.ey >> lane) & 1ull), fz = (int)((R.ez >> lane) & 1ull);
@@ -558,6 +604,9 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       if (fz) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e | (2u << 10); }
     }
     __syncthreads();
+#if defined(LT_MC_STOP) && LT_MC_STOP == 2  // ... + vertex list
+    return;
+#endif
     const int nwin = min(LT_MC_VCAP, nvt - vb);
     for (int j = lane; j < nwin; j += 64) {
       const unsigned e = s_vl[j];
@@ -593,10 +642,32 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     __syncthreads();
   }
+#if defined(LT_MC_STOP) && LT_MC_STOP == 3  // ... + vertex pass
+  return;
+#endif
   // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
   // the batch's active cells in order (word, z), with their case; then one scan per 64 cells gives every cell the index
   // of its first triangle (a scan per word cost more vector instructions than everything else in this kernel)
-  int ncell = 0;  // (wave-uniform)
+  int ncell = s_cpre[nw];  // (wave-uniform)
+  if (ncell <= 128) {  // SPARSE batch: lane c finds cell c -- its word by the prefix, its voxel as the r-th set bit of the mask
+    for (int c = lane; c < ncell; c += 64) {
+      int k = 0;
+      for (int q = 1; q < nw; ++q) k += (s_cpre[q] <= c) ? 1 : 0;
+      int r = c - s_cpre[k];
+      const u64 ac = s_cm[k][8];
+      int b = 0;  // the r-th (0-based) set bit of ac
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) {
+        const int cnt = __popc((unsigned)(ac >> b) & (sh == 32 ? 0xFFFFFFFFu : ((1u << sh) - 1u)));
+        if (cnt <= r) { r -= cnt; b += sh; }
+      }
+      int cs = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cs |= (int)((s_cm[k][q] >> b) & 1ull) << q;
+      s_cl[c] = (unsigned)k | ((unsigned)b << 4) | ((unsigned)cs << 13);
+    }
+  } else {
+  ncell = 0;
   for (int k = 0; k < nw; ++k) {
     const u64 ac = s_cm[k][8];
     if (ac == 0ull) continue;
@@ -607,6 +678,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       s_cl[ncell + __popcll(ac & lm)] = (unsigned)k | ((unsigned)lane << 4) | ((unsigned)cs << 13);
     }
     ncell += __popcll(ac);
+  }
   }
   __syncthreads();
   {
@@ -625,6 +697,9 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
   }
   __syncthreads();
+#if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
+  return;
+#endif
   for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
     for (int c = lane; c < ncell; c += 64) {  // a cell's (up to five) triangles into the window's list
       const unsigned e = s_cl[c];
