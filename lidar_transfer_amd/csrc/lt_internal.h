@@ -120,6 +120,8 @@ struct lt_tsdf {
   int* colinfo;         // [dim_x * dim_y] per integrate call: image column px of the voxel column, or -1 = dead
   float* colmax;        // [cap_w] per integrate call: largest depth of every image column
   int cap_w;
+  float2* dct;          // [cap_dct] per integrate call: (depth, colour) of pixel (row, px) at [px * im_h + row] -- the voxels of
+  size_t cap_dct;       // a column walk read consecutive rows of ONE image column: contiguous here, a line apart in the image
 };
 
 #define LT_BOUNDS_BLOCKS 256

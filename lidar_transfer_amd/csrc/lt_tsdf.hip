@@ -33,6 +33,10 @@
 #include <string.h>
 
 #define LT_PI_D 3.14159265358979323846
+#ifndef LT_TSDF_WAVES_ATTR
+#define LT_TSDF_WAVES_ATTR
+#endif
+#define LT_TSDF_DBG_WAVES (1 << 18)  // debug stamps: 65 536 workgroups (the default volume has 62 500 chunks)
 
 __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, float* __restrict__ weight,
                                                    float* __restrict__ color, float* __restrict__ rem, size_t n) {
@@ -144,14 +148,20 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(float* __restrict__ tsdf
 // largest depth of every image column: a workgroup takes 64 columns, its four waves a quarter of the rows each (rows of
 // the image are contiguous: coalesced), partial maxima through LDS.  (One thread per column walking its rows: 8
 // workgroups, 64 dependent-latency loads each, 18 us.)
-__global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ depth_im, int im_h, int im_w,
-                                                     float* __restrict__ colmax) {
+// ... and the transposed, packed copy of the depth and colour images (lt_tsdf::dct).
+__global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ depth_im,
+                                                     const float* __restrict__ color_im, int im_h, int im_w,
+                                                     float* __restrict__ colmax, float2* __restrict__ dct) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int x = blockIdx.x * 64 + tx;
   float m = 0.f;
   if (x < im_w)
-    for (int y = ty; y < im_h; y += 4) m = fmaxf(m, depth_im[y * im_w + x]);
+    for (int y = ty; y < im_h; y += 4) {
+      const float d = depth_im[y * im_w + x];
+      m = fmaxf(m, d);
+      dct[(size_t)x * im_h + y] = make_float2(d, color_im[y * im_w + x]);
+    }
   part[ty][tx] = m;
   __syncthreads();
   if (ty == 0 && x < im_w) colmax[x] = fmaxf(fmaxf(part[0][tx], part[1][tx]), fmaxf(part[2][tx], part[3][tx]));
@@ -179,7 +189,9 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
   const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
   const float cm = colmax[px];
   const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
-  colinfo[c] = dead ? -1 : px;
+  // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
+  // voxels of the (x + 1, -1) "column" there), each finding its own px
+  colinfo[c] = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
 }
 
 // A walk over z in [z0, z1) of the table column (cx, cy) is PLAIN when the reference's float decomposition of every voxel
@@ -220,7 +232,7 @@ __device__ __forceinline__ int tsdf_voxel(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch, bool fresh, const col_plain& C, int z_plain) {
+    unsigned epoch, bool fresh, const col_plain& C, int z_plain, const float2* __restrict__ dct) {
   int px = -2;
   float rho2, pt_z;
   if (C.plain) {
@@ -265,13 +277,52 @@ __device__ __forceinline__ int tsdf_voxel(
   int py = (int)floorf(proj_y);
   py = min(im_h - 1, py);
   py = max(0, py);
-  const float depth_value = depth_im[py * im_w + px];
+  const float2 dc = dct[px * im_h + py];  // (depth_im, color_im)[py * im_w + px], transposed copy (lt_tsdf::dct)
+  const float new_rem = rem_im[py * im_w + px];  // (issued with it: one round trip, not two)
+  const float depth_value = dc.x;
   if (depth_value == 0.f) return 0;
   const float depth_diff = depth_value - depth;
   if (depth_diff < -trunc_margin) return 0;
   const float dist = fminf(1.0f, depth_diff / trunc_margin);
-  return tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight,
-                            color_im[py * im_w + px], rem_im[py * im_w + px], fresh);
+  return tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight, dc.y, new_rem, fresh);
+}
+
+// Can voxel z of a FRESH plain column be written by the class-aware update?  On a fresh volume (the reference builds one
+// per output scan, laserscan.py:886-887, and fuses number_of_scans = 1 into it by default) a voxel is written only inside
+// the truncation band behind a surface -- depth in (D, D + trunc] of its pixel -- or, where the pixel carries colour 0 (the
+// fresh volume's own colour: "same class"), anywhere in front of that band.  That is 1 voxel in 4 of those inside the
+// field of view, and the exact evaluation costs ~150 vector instructions per 64 voxels against ~35 for this test:
+// approximate depth (rsq), approximate pitch (odd polynomial, |s| <= 0.5: error < 1e-6 rad) -> the one or two image rows the
+// exact projection can choose (+-0.25 row against an error below 0.01) -> their depth / colour with a margin far above
+// the approximation errors.  CONSERVATIVE: it may only say yes too often; every candidate then runs the reference's
+// expressions (tsdf_voxel), which decide.
+__device__ __forceinline__ bool tsdf_band_candidate(int z, const col_plain& C, float oz, float voxel_size, int im_h,
+                                                    int im_w, float trunc_margin, float kA, float kB, float sin_up_hi,
+                                                    float sin_down_lo, const float2* __restrict__ dct) {
+  // (branch-free, loads unconditional at clamped indices: the caller evaluates three voxels per lane at once and wants
+  // their loads in flight together)
+  const float pt_z = __fmaf_rn((float)z, voxel_size, oz);
+  const float d2 = __fmaf_rn(pt_z, pt_z, C.rho2);
+  const bool odd = !(d2 > 0.f && d2 < 1e30f);  // the voxel at the sensor, NaN, overflow: the exact path decides
+  const float rinv = __builtin_amdgcn_rsqf(d2);
+  const float s = pt_z * rinv, depth = d2 * rinv;
+  const bool in_fov = !(s > sin_up_hi + 1e-4f || s < sin_down_lo - 1e-4f);  // (with margin)
+  const float q = s * s;
+  const float pitch = s * (1.0f + q * (0.16666667f + q * (0.075f + q * (0.044642857f + q * 0.030381944f))));
+  const float py = __fmaf_rn(pitch, kA, kB);  // ~ proj_y * im_h
+  const int r0 = min(max((int)floorf(py - 0.25f), 0), im_h - 1), r1 = min(max((int)floorf(py + 0.25f), 0), im_h - 1);
+  const float eps = __fmaf_rn(4e-6f, depth, 1e-6f);
+  // (depth, colour) pairs of the two rows from the transposed copy: the lanes of a column walk read neighbouring rows of
+  // one image column -- a few lines per wave instead of one per lane
+  const float2 p0 = dct[C.px * im_h + r0], p1 = dct[C.px * im_h + r1];
+  const float D0 = p0.x, D1 = p1.x, c0 = p0.y, c1 = p1.y;
+  const float f0 = D0 - depth, f1 = D1 - depth;
+  // (written so that a NaN depth pixel -- which the reference's comparisons let through to the same-class test --
+  // stays a candidate)
+  const bool k0 = D0 != 0.f && !(f0 < -trunc_margin - eps) && (!(f0 >= eps) || c0 == 0.0f);
+  const bool k1 = D1 != 0.f && !(f1 < -trunc_margin - eps) && (!(f1 >= eps) || c1 == 0.0f);
+  const bool cand = odd || (in_fov && (k0 || k1));
+  return cand;
 }
 
 // z range [z0, z1) of the voxel column (cx, cy) that can lie inside the vertical field of view -- conservative: the
@@ -312,29 +363,63 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
 // is negative), which marching cubes reads instead of the float field; a 16-aligned chunk of z lies inside one word and
 // only this quarter wave works on this column, so the read-modify-write needs no atomic.
 template <bool MERGE>
-__global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
+__global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
     float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
     unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
-    unsigned* __restrict__ col_zw) {
-  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    unsigned* __restrict__ col_zw, const float2* __restrict__ dct, float kA, float kB,
+    unsigned long long* __restrict__ dbg) {
+  const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;  // (LIDARHIP_DEBUG_TSDF: per-wave stamps)
+  // candidates of the band test (fresh plain columns, class-aware update) wait here, per wave, until 64 are together:
+  // then lane j evaluates candidate j exactly
+  __shared__ int q_col[4][128], q_z[4][128], q_px[4][128];
+  __shared__ float q_rho2[4][128];
+  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15, wv = threadIdx.x >> 6;
   const int n_cols = vol_dim_x * vol_dim_y;
   const int n_chunks = (n_cols + 63) / 64;
-  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  // (kA, kB: the band test's row = pitch * kA + kB, from the host: a quarter of a million waves need not divide for them)
+  int qn = 0;  // (wave-uniform)
+  auto flush = [&](int n) {  // the exact evaluation + update of the queue's last n (<= 64) candidates, one per lane
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      const int e = qn - n + lane;
+      const int col = q_col[wv][e], z = q_z[wv][e];
+      col_plain Cq;
+      Cq.plain = true; Cq.px = q_px[wv][e]; Cq.rho2 = q_rho2[wv][e];
+      const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
+                                         vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight,
+                                         fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo,
+                                         col_epoch, epoch, true, Cq, z, dct);
+      if (code) {  // the sign of the value written -> the column's sign bit (other lanes may hold voxels of the same word)
+        unsigned long long* w = sign_bits + (size_t)col * words_z + (z >> 6);
+        const unsigned long long bit = 1ull << (z & 63);
+        if (code == 2) atomicOr(w, bit);
+        else atomicAnd(w, ~bit);
+      }
+    }
+    qn -= n;
+    __builtin_amdgcn_wave_barrier();
+  };
+  // A workgroup takes a chunk of 64 columns and its four waves share the chunk's live columns, every fourth quad each: the
+  // cost of a chunk ranges from nothing to 200 us (a wall: every voxel of every column a candidate), and with a chunk per
+  // wave the launch ended in a 110 us tail of a few such waves (per-wave stamps: tools/tsdf_wave_times.py)
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const int c = chunk * 64 + lane;
     bool live = false, written = false;
     if (c < n_cols) {
-      live = colinfo[c] != -1 || (c % vol_dim_y) == vol_dim_y - 1;
+      live = colinfo[c] != -1;  // (-2: the dead columns with y = dim_y - 1, see k_tsdf_columns)
       written = col_epoch[c] == epoch;  // before this launch: its voxels hold something else than the initial values
     }
     unsigned long long m = __ballot(live);
     const unsigned long long wm = __ballot(written);
-    while (m) {
+    for (int quad = 0; m; ++quad) {
       const int bit = nth_set_bit(m, grp);  // this quarter wave's column of the next four
       m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
+      if ((quad & 3) != wv) continue;  // (another wave of the workgroup)
       int z0 = 0, z1 = 0, cc = 0;
       col_plain C;
       C.plain = false; C.px = -2; C.rho2 = 0.f;
@@ -350,23 +435,55 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
       int trips = (z1 - (z0 & ~15) + 15) >> 4;
       trips = max(trips, __shfl_xor(trips, 16, 64));
       trips = max(trips, __shfl_xor(trips, 32, 64));
-      for (int k = 0; k < trips; ++k) {
-        const int zc = (z0 & ~15) + 16 * k, z = zc + gl;
-        int code = 0;
-        if (z >= z0 && z < z1)
-          code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
-                                   vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
-                                   fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch, epoch,
-                                   fresh, C, z);
-        const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2);
-        const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
-        if (wrote) {
-          wz_lo = min(wz_lo, zc + (__ffsll((long long)wrote) - 1));
-          wz_hi = max(wz_hi, zc + 63 - __clzll((long long)wrote));
-          if (gl == 0) {
-            unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
-            const int sh = zc & 63;
-            *w = (*w & ~(wrote << sh)) | (neg << sh);
+#ifdef LT_TSDF_NO_BAND  // A/B (LIDARHIP_EXTRA_FLAGS=-DLT_TSDF_NO_BAND): every voxel through the exact evaluation
+      const bool band = false;
+#else
+      const bool band = MERGE && fresh && C.plain;  // (per quarter wave)
+#endif
+      for (int k0 = 0; k0 < trips; k0 += 3) {
+        // band columns: the candidate tests of three chunks of z at once (their loads in flight together: a wave's life
+        // is a chain of load round trips, and this makes it a third as long)
+        bool cd[3] = {false, false, false};
+        if (band) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int z = (z0 & ~15) + 16 * (k0 + u) + gl;
+            const bool c1 = tsdf_band_candidate(min(z, vol_dim_z - 1), C, oz, voxel_size, im_h, im_w, trunc_margin, kA, kB,
+                                                sin_up_hi, sin_down_lo, dct);
+            cd[u] = c1 && z >= z0 && z < z1;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int k = k0 + u;
+          if (k >= trips) break;  // (wave-uniform)
+          const int zc = (z0 & ~15) + 16 * k, z = zc + gl;
+          int code = 0;
+          const bool cand = cd[u];
+          if (!band && z >= z0 && z < z1)
+            code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
+                                     vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
+                                     fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch,
+                                     epoch, fresh, C, z, dct);
+          const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2), cand_w = __ballot(cand);
+          const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
+          const unsigned long long cands = (cand_w >> (16 * grp)) & 0xFFFFull;
+          if (wrote | cands) {  // (a candidate counts as written for the column's stamp and z range: a superset is safe)
+            wz_lo = min(wz_lo, zc + (__ffsll((long long)(wrote | cands)) - 1));
+            wz_hi = max(wz_hi, zc + 63 - __clzll((long long)(wrote | cands)));
+            if (wrote && gl == 0) {
+              unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
+              const int sh = zc & 63;
+              *w = (*w & ~(wrote << sh)) | (neg << sh);
+            }
+          }
+          if (cand_w) {  // (wave-uniform)
+            if (cand) {
+              const int e = qn + __popcll(cand_w & lanes_below);
+              q_col[wv][e] = cc; q_z[wv][e] = z; q_px[wv][e] = C.px; q_rho2[wv][e] = C.rho2;
+            }
+            qn += __popcll(cand_w);
+            if (qn >= 64) flush(64);
           }
         }
       }
@@ -382,6 +499,12 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_cols(
         col_epoch[cc] = epoch;
       }
     }
+  }
+  if (qn > 0) flush(qn);
+  if (dbg && (threadIdx.x & 63) == 0) {
+    const size_t w = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) % LT_TSDF_DBG_WAVES;
+    dbg[2 * w] = t_dbg;
+    dbg[2 * w + 1] = (unsigned long long)wall_clock64() - t_dbg;
   }
 }
 
@@ -424,7 +547,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw};
+  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -433,6 +556,8 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
 
 // geometry of the per-column z range: slopes of the field of view with the 1e-5 margin of the sine test on the angles;
 // off for fields of view beyond +-80 degrees
+static unsigned long long* g_tsdf_dbg = nullptr;  // LIDARHIP_DEBUG_TSDF: per-wave stamps of k_tsdf_integrate_cols
+
 static col_geom tsdf_geom(const lt_tsdf* t) {
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
   const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
@@ -573,24 +698,42 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     LT_HIP(hipMalloc((void**)&t->colmax, (size_t)im_w * sizeof(float)));
     t->cap_w = im_w;
   }
+  if ((size_t)im_w * im_h > t->cap_dct) {
+    if (t->dct) {
+      LT_HIP(hipDeviceSynchronize());
+      (void)hipFree(t->dct);
+      t->dct = nullptr;
+      t->cap_dct = 0;
+    }
+    LT_HIP(hipMalloc((void**)&t->dct, (size_t)im_w * im_h * sizeof(float2)));
+    t->cap_dct = (size_t)im_w * im_h;
+  }
   const int n_cols = t->dim[0] * t->dim[1];
-  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, im_h, im_w, t->colmax);
+  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->colmax,
+                     t->dct);
   hipLaunchKernelGGL(k_tsdf_columns, dim3((n_cols + 255) / 256), dim3(256), 0, stream, t->dim[0], t->dim[1], t->origin[0],
                      t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo);
   // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
   const col_geom G = tsdf_geom(t);
-  const unsigned nbc = (unsigned)min((n_cols + 255) / 256, 16384);  // 64 columns per wave and trip
+  static const int env_blocks = []() { const char* e = getenv("LIDARHIP_TSDF_BLOCKS"); return e ? atoi(e) : 0; }();
+  const unsigned nbc = (unsigned)min((n_cols + 63) / 64, env_blocks > 0 ? env_blocks : (1 << 20));  // a chunk of 64 columns each
+  // debug (LIDARHIP_DEBUG_TSDF=1, tools/tsdf_wave_times.py): start / duration of every wave at 100 MHz
+  static const bool want_dbg = getenv("LIDARHIP_DEBUG_TSDF") != nullptr;
+  if (want_dbg && !g_tsdf_dbg) LT_HIP(hipMalloc((void**)&g_tsdf_dbg, (size_t)LT_TSDF_DBG_WAVES * 2 * sizeof(unsigned long long)));
+  unsigned long long* dbg = g_tsdf_dbg;
+  const float fov_abs = fabsf(fu) + fabsf(fd);
+  const float kA = -(float)im_h / fov_abs, kB = (float)im_h * (1.0f - fabsf(fd) / fov_abs);
   if (flags & LT_TSDF_MERGE)
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, dbg);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, dbg);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }
@@ -620,5 +763,14 @@ extern "C" int lt_tsdf_volumes(lt_tsdf* t, int* dims, float* origin, float** tsd
   if (weight) *weight = t->weight;
   if (color) *color = t->color;
   if (rem) *rem = t->rem;
+  return LT_OK;
+}
+
+// debug helper (not part of the documented ABI): the per-wave stamps of the last column-aware integrate
+// (LIDARHIP_DEBUG_TSDF=1); out: [n_waves][2] = {start, duration} at 100 MHz
+extern "C" int lt_debug_tsdf_wave_times(unsigned long long* out, int n_waves) {
+  if (!out || n_waves < 0 || n_waves > LT_TSDF_DBG_WAVES || !g_tsdf_dbg) return LT_ERR_INVALID_ARG;
+  LT_HIP(hipDeviceSynchronize());
+  LT_HIP(hipMemcpy(out, g_tsdf_dbg, (size_t)n_waves * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return LT_OK;
 }
