@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ d
 // when no voxel of the column can pass the truncation test
 __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim_y, float ox, float oy, float voxel_size,
                                                       int im_w, float trunc_margin, const float* __restrict__ colmax,
-                                                      int* __restrict__ colinfo) {
+                                                      int* __restrict__ colinfo, int* __restrict__ chunk_live) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= vol_dim_x * vol_dim_y) return;
   const int x = c / vol_dim_y, y = c - x * vol_dim_y;
@@ -191,7 +191,13 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
   const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
   // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
   // voxels of the (x + 1, -1) "column" there), each finding its own px
-  colinfo[c] = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
+  const int info = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
+  colinfo[c] = info;
+  // one flag per chunk of 64 columns (= this wave): does the integrate kernel have anything to walk there?  Three chunks
+  // in four have not, and a workgroup that reads its flag through the scalar cache is gone in a fraction of the 1.6 us
+  // it took to load and ballot 64 table entries
+  const unsigned long long any = __ballot(info != -1);
+  if ((threadIdx.x & 63) == 0) chunk_live[c >> 6] = any ? 1 : 0;
 }
 
 // A walk over z in [z0, z1) of the table column (cx, cy) is PLAIN when the reference's float decomposition of every voxel
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
     unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, float kA, float kB,
-    unsigned long long* __restrict__ dbg) {
+    const int* __restrict__ chunk_live, unsigned long long* __restrict__ dbg) {
   const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;  // (LIDARHIP_DEBUG_TSDF: per-wave stamps)
   // candidates of the band test (fresh plain columns, class-aware update) wait here, per wave, until 64 are together:
   // then lane j evaluates candidate j exactly
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
   // cost of a chunk ranges from nothing to 200 us (a wall: every voxel of every column a candidate), and with a chunk per
   // wave the launch ended in a 110 us tail of a few such waves (per-wave stamps: tools/tsdf_wave_times.py)
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    if (!chunk_live[chunk]) continue;  // (uniform: a scalar load)
     const int c = chunk * 64 + lane;
     bool live = false, written = false;
     if (c < n_cols) {
@@ -642,7 +649,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   }
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
-      hipMalloc((void**)&t->colinfo, n_cols * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&t->colinfo, (n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk
       hipMalloc((void**)&t->col_zw, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
@@ -712,7 +719,7 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->colmax,
                      t->dct);
   hipLaunchKernelGGL(k_tsdf_columns, dim3((n_cols + 255) / 256), dim3(256), 0, stream, t->dim[0], t->dim[1], t->origin[0],
-                     t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo);
+                     t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo, t->colinfo + n_cols);
   // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
   const col_geom G = tsdf_geom(t);
@@ -728,12 +735,12 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, dbg);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, dbg);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }
