@@ -167,39 +167,6 @@ __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ d
   if (ty == 0 && x < im_w) colmax[x] = fmaxf(fmaxf(part[0][tx], part[1][tx]), fmaxf(part[2][tx], part[3][tx]));
 }
 
-// per voxel column (x, y): its image column px -- the kernel's own expressions on voxel_x = x, voxel_y = y -- or -1
-// when no voxel of the column can pass the truncation test
-__global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim_y, float ox, float oy, float voxel_size,
-                                                      int im_w, float trunc_margin, const float* __restrict__ colmax,
-                                                      int* __restrict__ colinfo, int* __restrict__ chunk_live) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= vol_dim_x * vol_dim_y) return;
-  const int x = c / vol_dim_y, y = c - x * vol_dim_y;
-  const float pt_x = __fmaf_rn((float)x, voxel_size, ox);
-  const float pt_y = __fmaf_rn((float)y, voxel_size, oy);
-  const float yaw = -atan2f(pt_y, pt_x);
-  float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
-  proj_x *= (float)im_w;
-  int px = (int)floorf(proj_x);
-  px = min(im_w - 1, px);
-  px = max(0, px);
-  // every voxel of the column has depth = sqrtf(fma(z, z, fma(y, y, x * x))) >= rho (fma and sqrtf are monotonic), so
-  // depth_value - depth <= colmax - rho: if that is already < -trunc_margin the column is dead.  A column of zeros
-  // (colmax == 0) leaves at `depth_value == 0`.
-  const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
-  const float cm = colmax[px];
-  const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
-  // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
-  // voxels of the (x + 1, -1) "column" there), each finding its own px
-  const int info = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
-  colinfo[c] = info;
-  // one flag per chunk of 64 columns (= this wave): does the integrate kernel have anything to walk there?  Three chunks
-  // in four have not, and a workgroup that reads its flag through the scalar cache is gone in a fraction of the 1.6 us
-  // it took to load and ballot 64 table entries
-  const unsigned long long any = __ballot(info != -1);
-  if ((threadIdx.x & 63) == 0) chunk_live[c >> 6] = any ? 1 : 0;
-}
-
 // A walk over z in [z0, z1) of the table column (cx, cy) is PLAIN when the reference's float decomposition of every voxel
 // index in it (:95-98) yields (cx, cy, z): (float)voxel_idx is monotone in voxel_idx and so is the quotient's floor, hence
 // it is enough that both ends of the walk decompose to cx -- voxel_y and voxel_z then follow in exact integer / small-float
@@ -359,6 +326,52 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
   return m ? __ffsll((long long)m) - 1 : -1;
 }
 
+// per voxel column (x, y): its image column px -- the kernel's own expressions on voxel_x = x, voxel_y = y -- or -1
+// when no voxel of the column can pass the truncation test
+__global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim_y, float ox, float oy, float voxel_size,
+                                                      int im_w, float trunc_margin, const float* __restrict__ colmax,
+                                                      int* __restrict__ colinfo, int* __restrict__ chunk_live, col_geom G,
+                                                      int vol_dim_z, unsigned* __restrict__ colz,
+                                                      float* __restrict__ colrho2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= vol_dim_x * vol_dim_y) return;
+  const int x = c / vol_dim_y, y = c - x * vol_dim_y;
+  const float pt_x = __fmaf_rn((float)x, voxel_size, ox);
+  const float pt_y = __fmaf_rn((float)y, voxel_size, oy);
+  const float yaw = -atan2f(pt_y, pt_x);
+  float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
+  proj_x *= (float)im_w;
+  int px = (int)floorf(proj_x);
+  px = min(im_w - 1, px);
+  px = max(0, px);
+  // every voxel of the column has depth = sqrtf(fma(z, z, fma(y, y, x * x))) >= rho (fma and sqrtf are monotonic), so
+  // depth_value - depth <= colmax - rho: if that is already < -trunc_margin the column is dead.  A column of zeros
+  // (colmax == 0) leaves at `depth_value == 0`.
+  const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
+  const float cm = colmax[px];
+  const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
+  // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
+  // voxels of the (x + 1, -1) "column" there), each finding its own px
+  const int info = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
+  colinfo[c] = info;
+  // the walk the integrate kernel will do in this column -- its z range, whether it is plain (col_plain_of), the
+  // column's fma(pt_y, pt_y, pt_x^2) -- computed HERE, one lane per column, instead of by the 16 lanes that walk the
+  // column there (two square roots and four IEEE divisions per column: a sixth of that kernel's vector instructions)
+  if (info != -1) {
+    int z0, z1;
+    col_zrange(G, x, y, z0, z1);
+    colinfo[c] = info;  // (col_plain_of reads it)
+    const col_plain C = col_plain_of(x, y, z0, z1, vol_dim_y, vol_dim_z, ox, oy, voxel_size, colinfo);
+    colz[c] = (unsigned)z0 | ((unsigned)z1 << 15) | (C.plain ? 0x80000000u : 0u);  // z < 2^15 (lt_tsdf_create)
+    colrho2[c] = C.rho2;
+  }
+  // one flag per chunk of 64 columns (= this wave): does the integrate kernel have anything to walk there?  Three chunks
+  // in four have not, and a workgroup that reads its flag through the scalar cache is gone in a fraction of the 1.6 us
+  // it took to load and ballot 64 table entries
+  const unsigned long long any = __ballot(info != -1);
+  if ((threadIdx.x & 63) == 0) chunk_live[c >> 6] = any ? 1 : 0;
+}
+
 // A wave looks at the table entries of 64 voxel columns at once and then walks only the columns that are not dead:
 // FOUR columns at a time, 16 lanes each with z along the lanes (a column's walk is a chain of dependent loads -- table
 // entry, depth pixel, the voxel's fields -- and only the z range inside the field of view, 20 - 60 voxels, has work:
@@ -377,7 +390,8 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
     unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, float kA, float kB,
-    const int* __restrict__ chunk_live, unsigned long long* __restrict__ dbg) {
+    const int* __restrict__ chunk_live, const unsigned* __restrict__ colz, const float* __restrict__ colrho2,
+    unsigned long long* __restrict__ dbg) {
   const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;  // (LIDARHIP_DEBUG_TSDF: per-wave stamps)
   // candidates of the band test (fresh plain columns, class-aware update) wait here, per wave, until 64 are together:
   // then lane j evaluates candidate j exactly
@@ -433,9 +447,12 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
       const bool fresh = bit >= 0 && !((wm >> bit) & 1ull);
       if (bit >= 0) {
         cc = chunk * 64 + bit;
-        const int cx = cc / vol_dim_y;
-        col_zrange(G, cx, cc - cx * vol_dim_y, z0, z1);
-        C = col_plain_of(cx, cc - cx * vol_dim_y, z0, z1, vol_dim_y, vol_dim_z, ox, oy, voxel_size, colinfo);
+        const unsigned zz = colz[cc];  // (k_tsdf_columns)
+        z0 = (int)(zz & 0x7FFFu);
+        z1 = (int)((zz >> 15) & 0xFFFFu);
+        C.plain = (zz >> 31) != 0u;
+        C.px = colinfo[cc];
+        C.rho2 = colrho2[cc];
       }
       int wz_lo = 0x7fff, wz_hi = -1;  // z range this launch writes in the column (any field; uniform over the group)
       // (uniform trip count over the wave: the ballots below need every lane)
@@ -634,6 +651,11 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
     free(t);
     return LT_ERR_TOO_LARGE;
   }
+  if (t->dim[2] > 32767) {  // (the per-column z ranges are packed into 15 / 16 bits)
+    lt_set_error("lt_tsdf_create: %d voxels along z exceed 32767", t->dim[2]);
+    free(t);
+    return LT_ERR_TOO_LARGE;
+  }
   t->n = (size_t)n;
   t->voxel_size = (float)voxel_size;
   t->trunc_margin = (float)(voxel_size * 5);  // fusion_lidar.py:31
@@ -649,7 +671,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   }
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
-      hipMalloc((void**)&t->colinfo, (n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk
+      hipMalloc((void**)&t->colinfo, (3 * n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk, colz, colrho2
       hipMalloc((void**)&t->col_zw, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
@@ -716,13 +738,18 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     t->cap_dct = (size_t)im_w * im_h;
   }
   const int n_cols = t->dim[0] * t->dim[1];
+  const col_geom G = tsdf_geom(t);
+  // behind the table: one flag per chunk of 64 columns, then the walks' z ranges and the columns' rho^2
+  const size_t n_flags = ((size_t)n_cols + 63) / 64 + 64;
+  unsigned* colz = (unsigned*)(t->colinfo + n_cols + n_flags);
+  float* colrho2 = (float*)(t->colinfo + n_cols + n_flags + n_cols);
   hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->colmax,
                      t->dct);
   hipLaunchKernelGGL(k_tsdf_columns, dim3((n_cols + 255) / 256), dim3(256), 0, stream, t->dim[0], t->dim[1], t->origin[0],
-                     t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo, t->colinfo + n_cols);
+                     t->origin[1], t->voxel_size, im_w, t->trunc_margin, t->colmax, t->colinfo, t->colinfo + n_cols, G,
+                     t->dim[2], colz, colrho2);
   // sine thresholds of the conservative field-of-view test: 1e-5 beyond the limits (asinf is good to ~1e-7)
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
-  const col_geom G = tsdf_geom(t);
   static const int env_blocks = []() { const char* e = getenv("LIDARHIP_TSDF_BLOCKS"); return e ? atoi(e) : 0; }();
   const unsigned nbc = (unsigned)min((n_cols + 63) / 64, env_blocks > 0 ? env_blocks : (1 << 20));  // a chunk of 64 columns each
   // debug (LIDARHIP_DEBUG_TSDF=1, tools/tsdf_wave_times.py): start / duration of every wave at 100 MHz
@@ -735,12 +762,12 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, dbg);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, dbg);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }
