@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ d
   if (x < im_w)
     for (int y = ty; y < im_h; y += 4) {
       const float d = depth_im[y * im_w + x];
-      m = fmaxf(m, d);
+      m = d == d ? fmaxf(m, d) : INFINITY;  // (a NaN pixel passes every depth test of the reference kernel: never "dead")
       dct[(size_t)x * im_h + y] = make_float2(d, color_im[y * im_w + x]);
     }
   part[ty][tx] = m;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
 #ifdef LT_TSDF_NO_BAND  // A/B (LIDARHIP_EXTRA_FLAGS=-DLT_TSDF_NO_BAND): every voxel through the exact evaluation
       const bool band = false;
 #else
-      const bool band = MERGE && fresh && C.plain;  // (per quarter wave)
+      const bool band = MERGE && fresh && C.plain && kA == kA;  // (per quarter wave; kA is NaN when the test is off)
 #endif
       for (int k0 = 0; k0 < trips; k0 += 3) {
         // band columns: the candidate tests of three chunks of z at once (their loads in flight together: a wave's life
@@ -757,7 +757,11 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   if (want_dbg && !g_tsdf_dbg) LT_HIP(hipMalloc((void**)&g_tsdf_dbg, (size_t)LT_TSDF_DBG_WAVES * 2 * sizeof(unsigned long long)));
   unsigned long long* dbg = g_tsdf_dbg;
   const float fov_abs = fabsf(fu) + fabsf(fd);
-  const float kA = -(float)im_h / fov_abs, kB = (float)im_h * (1.0f - fabsf(fd) / fov_abs);
+  // the band test's pitch polynomial is good to 1e-5 rad for |sin| <= 0.5 and its row choice has +-0.25 row of slack: it is
+  // used for fields of view inside +-30 degrees with rows at least 2e-4 rad apart (every spinning LiDAR); otherwise
+  // kA = NaN switches it off and every voxel takes the exact evaluation
+  const bool band_ok = fabsf(su) <= 0.5f && fabsf(sd) <= 0.5f && fov_abs / (float)im_h >= 2e-4f;
+  const float kA = band_ok ? -(float)im_h / fov_abs : NAN, kB = (float)im_h * (1.0f - fabsf(fd) / fov_abs);
   if (flags & LT_TSDF_MERGE)
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,

@@ -116,7 +116,7 @@ sys.path.insert(0, %r)
 import torch
 from lidar_transfer_amd.fusion import TSDFVolume
 merge = sys.argv[2] == "1"
-H, W, fu, fd = 32, 256, 10.0, -25.0
+H, W, fu, fd = 32, 256, float(sys.argv[3]), float(sys.argv[4])
 rng = np.random.default_rng(5)
 yaw = np.linspace(-np.pi, np.pi, W)
 vol = TSDFVolume(np.array([[-15.0, 15.0], [-15.0, 15.0], [-5.0, 5.0]]), 0.05, fu, fd, merge=merge)   # 600 x 600 x 200 = 72 M voxels
@@ -126,6 +126,8 @@ for rnd in range(2):          # second round: after a reset the volume must equa
         depth = (6.0 + 3.0 * np.sin(3 * yaw + k)[None, :] + 0.2 * rng.random((H, W))).astype(np.float32)
         depth[rng.random((H, W)) < 0.05] = 0.0
         depth[:, 40:60] = 0.0                                  # image columns without any return
+        depth[rng.random((H, W)) < 0.003] = np.nan            # broken pixels: both kernels must treat them alike
+        depth[rng.random((H, W)) < 0.003] = np.inf
         lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
         label3 = np.stack([lab, np.zeros_like(lab), np.zeros_like(lab)], 2)
         rem = rng.random((H, W)).astype(np.float32)
@@ -140,13 +142,15 @@ np.savez(sys.argv[1], **{f"{k}{i}": a for k, v in out.items() for i, a in enumer
 """
 
 
-@pytest.mark.parametrize("merge", [True, False])
-def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge):
+@pytest.mark.parametrize("merge,fu,fd", [(True, 10.0, -25.0), (False, 10.0, -25.0), (True, 40.0, -50.0), (True, 2.0, -24.8)])
+def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd):
     """The work-saving integrate (per-column image column and dead-column test, conservative sine test, dirty-column
     reset) against the plain one-thread-per-voxel kernel (LIDARHIP_TSDF=dense) on a 72 M-voxel volume -- beyond 2^24
     voxels, where the reference's float voxel index misplaces voxels next to x boundaries -- two observations, a
     reset, the same two observations again: all four fields bit-identical, and the volume after the reset round equals
-    the first round."""
+    the first round.  The first observation of a round goes through the band test + candidate queue (fresh columns), the
+    second through the exact evaluation of every voxel; (40, -50) degrees is a field of view for which the band test is
+    switched off; zero, NaN and infinite depth pixels and colour 0 (the fresh volume's own) are in the images."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -158,7 +162,7 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge)
         else:
             env.pop("LIDARHIP_TSDF", None)
         path = str(tmp_path / f"{mode}.npz")
-        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0"], env=env,
+        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd)], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = np.load(path)
