@@ -201,6 +201,9 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
 __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
                                                   unsigned epoch) {
+  __shared__ unsigned char s_nt[256];  // triangles per case: the loops below look it up once per active cell, a chain of
+  s_nt[threadIdx.x] = LT_MC_NTRIS[threadIdx.x];  // dependent loads that is three times shorter through LDS
+  __syncthreads();
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int n_rows = D.nx * D.ny;
   unsigned na = 0, nv = 0, nt = 0;
@@ -209,11 +212,39 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
       for (int k = 0; k < D.wz; ++k) cnt[(size_t)row * D.wz + k] = 0u;
     } else {
       const int x = row / D.ny, y = row - x * D.ny;
+      if (D.wz <= 4) {
+        // the sign words of the four rows (x + dx, y + dy), ALL loaded before the first is used -- a word's masks need
+        // its row neighbours' words at k and k + 1, so a loop over k loaded every word twice, in wz dependent rounds
+        const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny;
+        u64 w[4][5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dx = q & 1, dy = q >> 1;
+          const bool have = (dx == 0 || hx) && (dy == 0 || hy);
+          const size_t base = (size_t)(row + dx * D.ny + dy) * D.wz;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[q][k] = (have && k < D.wz) ? bits[base + k] : 0ull;
+          w[q][4] = 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k >= D.wz) break;
+          u64 w8[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { w8[q] = w[q][k]; w8[q | 4] = w[q][k + 1]; }
+          const mc_masks M = mc_build(w8, D, x, y, k);
+          const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
+          unsigned t = 0;
+          for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
+          cnt[(size_t)row * D.wz + k] = v | (t << 16);
+          na += (v | t) ? 1u : 0u; nv += v; nt += t;
+        }
+      } else
       for (int k = 0; k < D.wz; ++k) {
         const mc_masks M = mc_load(bits, D, x, y, k);
         const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
         unsigned t = 0;
-        for (u64 a = M.ac; a; a &= a - 1) t += LT_MC_NTRIS[mc_case(M, __ffsll((long long)a) - 1)];
+        for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
         cnt[(size_t)row * D.wz + k] = v | (t << 16);
         na += (v | t) ? 1u : 0u; nv += v; nt += t;
       }
