@@ -39,7 +39,9 @@ void lt_set_error(const char* fmt, ...);
 // child reference c >= 0: node index; c < 0: leaf, ~c = start | (count-1) << 28.
 
 #define LT_LEAF_MAX 4
+#ifndef LT_SORT_TILE
 #define LT_SORT_TILE 4096      // keys per workgroup per radix pass (256 threads x 16)
+#endif
 #define LT_SORT_THREADS 256
 #define LT_SEG_SUB 512         // segment-tree leaves reduced per workgroup
 #define LT_STACK_LDS 32        // per-ray stack entries kept in LDS; deeper entries spill to HBM
