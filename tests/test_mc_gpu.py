@@ -50,6 +50,25 @@ def test_white_noise_equals_oracle_on_every_word_layout(oracle, shape):
         assert want[1].shape[0] > 10
 
 
+@pytest.mark.parametrize("p_neg", [0.0005, 0.004, 0.02, 0.08, 0.3])
+def test_speckled_fields_cross_the_sparse_and_dense_emission_paths(oracle, p_neg):
+    """The emission kernel lists a batch of 8 active words with a lane per vertex / cell when the batch holds <= 128 of them
+    and with a pass per word otherwise (k_mc_emit_batch): fields that are +1 with isolated negative voxels at five
+    densities put batches on both sides of both thresholds, next to each other in one volume."""
+    shape = (24, 20, 200)
+    rng = np.random.default_rng(int(p_neg * 1e4))
+    t = np.ones(shape, np.float32)
+    t[rng.random(shape) < p_neg] = -0.5
+    t[:, :, 100:] = np.where(rng.random((24, 20, 100)) < 4 * p_neg, -0.25, 1.0)   # denser upper half: mixed batches
+    col = (rng.integers(0, 260, shape) * 65536).astype(np.float32)
+    rem = rng.random(shape).astype(np.float32)
+    org = np.zeros(3, np.float32)
+    want = oracle.marching_cubes(t, col, rem, 0.1, org)
+    got = _gpu_mesh(t, col, rem, 0.1, org)
+    _assert_same_mesh(got, want)
+    assert want[0].shape[0] > 50
+
+
 def test_smooth_field_and_reuse_of_one_mesh_object(oracle):
     import torch
     from lidar_transfer_amd.fusion import DeviceMesh
