@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
 #else
       const bool band = MERGE && fresh && C.plain && kA == kA;  // (per quarter wave; kA is NaN when the test is off)
 #endif
+      const bool any_direct = __ballot(bit >= 0 && !band) != 0ull;  // (wave-uniform: usually false on a fresh volume)
       for (int k0 = 0; k0 < trips; k0 += 3) {
         // band columns: the candidate tests of three chunks of z at once (their loads in flight together: a wave's life
         // is a chain of load round trips, and this makes it a third as long)
@@ -482,15 +483,20 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
           const int k = k0 + u;
           if (k >= trips) break;  // (wave-uniform)
           const int zc = (z0 & ~15) + 16 * k, z = zc + gl;
-          int code = 0;
           const bool cand = cd[u];
-          if (!band && z >= z0 && z < z1)
-            code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
-                                     vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
-                                     fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch,
-                                     epoch, fresh, C, z, dct);
-          const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2), cand_w = __ballot(cand);
-          const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
+          unsigned long long wrote = 0ull, neg = 0ull;
+          if (any_direct) {
+            int code = 0;
+            if (!band && z >= z0 && z < z1)
+              code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
+                                       vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
+                                       fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo, col_epoch,
+                                       epoch, fresh, C, z, dct);
+            const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2);
+            wrote = (wrote_w >> (16 * grp)) & 0xFFFFull;
+            neg = (neg_w >> (16 * grp)) & 0xFFFFull;
+          }
+          const unsigned long long cand_w = __ballot(cand);
           const unsigned long long cands = (cand_w >> (16 * grp)) & 0xFFFFull;
           if (wrote | cands) {  // (a candidate counts as written for the column's stamp and z range: a superset is safe)
             wz_lo = min(wz_lo, zc + (__ffsll((long long)(wrote | cands)) - 1));
