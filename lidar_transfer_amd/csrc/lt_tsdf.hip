@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, float kA, float kB,
     const int* __restrict__ chunk_live, const unsigned* __restrict__ colz, const float* __restrict__ colrho2,
-    unsigned long long* __restrict__ dbg) {
+    int all_written, unsigned long long* __restrict__ dbg) {
   const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;  // (LIDARHIP_DEBUG_TSDF: per-wave stamps)
   // candidates of the band test (fresh plain columns, class-aware update) wait here, per wave, until 64 are together:
   // then lane j evaluates candidate j exactly
@@ -433,7 +433,9 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     bool live = false, written = false;
     if (c < n_cols) {
       live = colinfo[c] != -1;  // (-2: the dead columns with y = dim_y - 1, see k_tsdf_columns)
-      written = col_epoch[c] == epoch;  // before this launch: its voxels hold something else than the initial values
+      // before this launch: its voxels hold something else than the initial values (all_written: the caller wrote into
+      // the volumes through the raw pointers, lt_tsdf_touch, or a kernel without stamps did: nothing may be folded)
+      written = all_written != 0 || col_epoch[c] == epoch;
     }
     unsigned long long m = __ballot(live);
     const unsigned long long wm = __ballot(written);
@@ -772,12 +774,12 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }

@@ -138,6 +138,16 @@ for rnd in range(2):          # second round: after a reset the volume must equa
         rng = np.random.default_rng(5)
     else:
         out["second"] = [t.cpu().numpy() for t in vol.get_volume_tensors()]
+# the caller writes into the volumes through the raw tensors (a region of the SAME class as some pixels, in columns no
+# observation has stamped yet after a reset) and says so: nothing may be taken for fresh from here on
+vol.reset()
+ts = vol.get_volume_tensors()
+ts[0][60:160, 380:520, :] = 0.25; ts[1][60:160, 380:520, :] = 2.0; ts[2][60:160, 380:520, :] = 40.0 * 65536.0
+vol.touch()
+depth = (7.0 + 2.0 * np.cos(2 * yaw)[None, :] + 0.1 * rng.random((H, W))).astype(np.float32)
+lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
+vol.integrate(np.stack([lab, np.zeros_like(lab), np.zeros_like(lab)], 2), depth, rng.random((H, W)).astype(np.float32), np.eye(4))
+out["third"] = [t.cpu().numpy() for t in vol.get_volume_tensors()]
 np.savez(sys.argv[1], **{f"{k}{i}": a for k, v in out.items() for i, a in enumerate(v)})
 """
 
@@ -171,5 +181,6 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
         assert np.array_equal(a.view(np.int32), b.view(np.int32)), key
     for i in range(4):
         assert np.array_equal(res["cols"][f"first{i}"].view(np.int32), res["cols"][f"second{i}"].view(np.int32)), i
+    assert (res["cols"]["third0"][60:160, 380:520, :] != 0.25).any()   # the touched region was observed
     t = res["cols"]["first0"]
     assert (t < 0).sum() > 10000 and (t != 1).mean() < 0.5
