@@ -82,11 +82,20 @@ static int ctrace_thread(const float* rays, const float* origin, const float* ve
   if (c.device != dev) {
     c.release();
     LT_HIP(hipSetDevice(dev));
-    c.device = dev;
-    LT_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    LT_CHECK(lt_scene_create(&c.scene, dev));
-    LT_HIP(hipMalloc((void**)&c.flag_dev, sizeof(unsigned)));
-    LT_HIP(hipHostMalloc((void**)&c.flag_host, sizeof(unsigned), hipHostMallocDefault));
+    // the context counts as initialised (c.device == dev) only once ALL of its resources exist: a failure half way
+    // releases what was created, and the next call on this thread starts over instead of finding a NULL scene
+    int rc = LT_OK;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) rc = LT_ERR_HIP;
+    if (rc == LT_OK) rc = lt_scene_create(&c.scene, dev);
+    if (rc == LT_OK && hipMalloc((void**)&c.flag_dev, sizeof(unsigned)) != hipSuccess) rc = LT_ERR_NO_MEMORY;
+    if (rc == LT_OK && hipHostMalloc((void**)&c.flag_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) rc = LT_ERR_NO_MEMORY;
+    c.device = dev;  // (release() frees on this device)
+    if (rc != LT_OK) {
+      lt_set_error("lt_ctrace: creating the per-thread context on device %d failed: %s", dev,
+                   hipGetErrorString(hipGetLastError()));
+      c.release();  // resets c.device to -1: the next call starts over
+      return rc;
+    }
   }
   lt_scene* s = c.scene;
   hipStream_t stream = c.stream;

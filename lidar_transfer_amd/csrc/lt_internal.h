@@ -116,7 +116,7 @@ struct lt_tsdf {
   unsigned* col_epoch;  // [dim_x * dim_y]
   unsigned* col_zw;     // [dim_x * dim_y] z range written in the column since the last reset: lo | hi << 16 (valid when dirty)
   unsigned epoch;
-  int all_dirty;        // an integrate without stamps ran (LIDARHIP_TSDF=dense): every column counts as written
+  int all_dirty;        // the fields were written without column stamps (lt_tsdf_touch): every column counts as written
   unsigned long long* bits;  // [dim_x * dim_y][ceil(dim_z / 64)] sign bit of every voxel's tsdf (the layout of lt_mc.hip),
                              // kept up to date by the column-aware integrate and by reset; invalid while all_dirty
   int* colinfo;         // [dim_x * dim_y] per integrate call: image column px of the voxel column, or -1 = dead

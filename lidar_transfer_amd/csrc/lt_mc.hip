@@ -365,9 +365,12 @@ struct mc_nb { u64 ex, ey, ez; int vbase; int have; };
 
 // float32 vertex coordinate along the edge from lattice coordinate c (value v1) to c + 1 (value v2): scikit-image's
 // centre-of-mass rule (Cell._add_face_from_edge_index), evaluated in double, stored as float32
+// (its `FLT_EPSILON` is, despite the name, `np.spacing(1.0)` = 2^-52 -- a double; C's FLT_EPSILON, 1.19e-7, would move
+// every vertex by ~1e-7 voxel and exact-zero samples visibly.  Still PARITY UNPINNED: no scikit-image output to check.)
+#define LT_MC_EPS 2.220446049250313e-16
 __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
-  const double w1 = 1.0 / ((double)FLT_EPSILON + fabs((double)v1));
-  const double w2 = 1.0 / ((double)FLT_EPSILON + fabs((double)v2));
+  const double w1 = 1.0 / (LT_MC_EPS + fabs((double)v1));
+  const double w2 = 1.0 / (LT_MC_EPS + fabs((double)v2));
   return (float)((double)c + w2 / (w1 + w2));
 }
 
@@ -924,9 +927,15 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
       m->verts = nullptr; m->colors = nullptr; m->rem = nullptr;
     }
     const size_t cap = (size_t)nv + nv / 4 + 1024;
-    LT_HIP(hipMalloc((void**)&m->verts, cap * 12));
-    LT_HIP(hipMalloc((void**)&m->colors, cap * 12));
-    LT_HIP(hipMalloc((void**)&m->rem, cap * 4));
+    m->cap_v = 0;  // (a failure below must not leave the old capacity standing over freed / missing buffers)
+    if (hipMalloc((void**)&m->verts, cap * 12) != hipSuccess || hipMalloc((void**)&m->colors, cap * 12) != hipSuccess ||
+        hipMalloc((void**)&m->rem, cap * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(m->verts); (void)hipFree(m->colors); (void)hipFree(m->rem);
+      m->verts = nullptr; m->colors = nullptr; m->rem = nullptr;
+      lt_set_error("lt_marching_cubes_dev: hipMalloc of the vertex arrays (%zu vertices) failed", cap);
+      return LT_ERR_NO_MEMORY;
+    }
     m->cap_v = (int)min(cap, (size_t)2147483647);
   }
   if (nf > m->cap_f || !m->faces) {
@@ -936,6 +945,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
       m->faces = nullptr;
     }
     const size_t cap = (size_t)nf + nf / 4 + 1024;
+    m->cap_f = 0;
     LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }

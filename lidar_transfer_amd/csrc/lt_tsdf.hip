@@ -25,8 +25,8 @@
 //     field of view before asinf; the band around the limits takes the exact path;
 //   * columns written since the last reset are stamped with the volume's epoch: reset re-initialises those only, and
 //     marching cubes (lt_mc.hip) does not read the clean ones.
-// LIDARHIP_TSDF=dense selects the one-thread-per-voxel kernel without any of this (A/B: bit-identical volumes,
-// tests/test_tsdf_gpu.py).
+// The one-thread-per-voxel restatement of the reference kernel is test infrastructure (tests/csrc/lt_tsdf_dense.hip,
+// not in this library): the A/B partner of the kernels below -- bit-identical volumes, tests/test_tsdf_gpu.py.
 #include "lt_internal.h"
 #include <math.h>
 #include <stdlib.h>
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
   }
 }
 
-// the update of one voxel (fusion_lidar.py:178-228), shared by the dense and the column-aware kernel; returns what
+// the update of one voxel (fusion_lidar.py:178-228); returns what
 // happened to the voxel's tsdf: 0 untouched, 1 written (not negative), 2 written negative (the sign bit marching cubes
 // needs, lt_mc.hip)
 // `fresh`: the voxel's column has not been written since the last reset, so the old values are the initial ones
@@ -101,50 +101,6 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
   }
 }
 
-template <bool MERGE>
-__global__ __launch_bounds__(256) void k_tsdf_integrate(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
-                                                        float* __restrict__ color_vol, float* __restrict__ rem_vol,
-                                                        int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy,
-                                                        float oz, float voxel_size, int im_h, int im_w,
-                                                        float trunc_margin, float obs_weight, float fov_up,
-                                                        float fov_down, const float* __restrict__ color_im,
-                                                        const float* __restrict__ depth_im,
-                                                        const float* __restrict__ rem_im) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)vol_dim_x * vol_dim_y * vol_dim_z) return;  // the reference tests `>` (one past the end)
-  const int voxel_idx = (int)gid;
-  // voxel grid coordinates -- float division exactly as the reference ("be careful when casting", :95-98)
-  const float voxel_x = floorf(((float)voxel_idx) / ((float)(vol_dim_y * vol_dim_z)));
-  const float voxel_y = floorf(((float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z)) / ((float)vol_dim_z));
-  const float voxel_z = (float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z - ((int)voxel_y) * vol_dim_z);
-  const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
-  const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
-  const float pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
-  // spherical projection (:120-146); cam_pose is not used by the reference kernel (:112-114)
-  const float fov = fabsf(fov_up) + fabsf(fov_down);
-  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, __fmaf_rn(pt_y, pt_y, pt_x * pt_x)));  // norm3df
-  const float yaw = -atan2f(pt_y, pt_x);
-  const float pitch = asinf(pt_z / depth);
-  if (pitch > fov_up || pitch < fov_down) return;
-  float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
-  float proj_y = (float)(1.0 - (double)((pitch + fabsf(fov_down)) / fov));
-  proj_x *= (float)im_w;
-  proj_y *= (float)im_h;
-  int px = (int)floorf(proj_x);
-  px = min(im_w - 1, px);
-  px = max(0, px);
-  int py = (int)floorf(proj_y);
-  py = min(im_h - 1, py);
-  py = max(0, py);
-  const float depth_value = depth_im[py * im_w + px];
-  if (depth_value == 0.f) return;
-  const float depth_diff = depth_value - depth;
-  if (depth_diff < -trunc_margin) return;
-  const float dist = fminf(1.0f, depth_diff / trunc_margin);
-  tsdf_update<MERGE>(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, dist, obs_weight, color_im[py * im_w + px],
-                     rem_im[py * im_w + px]);
-}
-
 // largest depth of every image column: a workgroup takes 64 columns, its four waves a quarter of the rows each (rows of
 // the image are contiguous: coalesced), partial maxima through LDS.  (One thread per column walking its rows: 8
 // workgroups, 64 dependent-latency loads each, 18 us.)
@@ -155,11 +111,15 @@ __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ d
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int x = blockIdx.x * 64 + tx;
-  float m = 0.f;
+  // the maximum over the pixels the reference kernel does not leave at `depth_value == 0` -- NOT started at 0: the
+  // reference's "no data" value is -1 (laserscan.py:38), and with a truncation margin above 1 m (voxel_size > 0.2) the
+  // voxels within trunc_margin - 1 of the sensor ARE written through such a pixel (depth_diff = -1 - depth >= -trunc)
+  float m = -INFINITY;  // no non-zero pixel: every voxel of the column leaves at `depth_value == 0`
   if (x < im_w)
     for (int y = ty; y < im_h; y += 4) {
       const float d = depth_im[y * im_w + x];
-      m = d == d ? fmaxf(m, d) : INFINITY;  // (a NaN pixel passes every depth test of the reference kernel: never "dead")
+      // (a NaN pixel passes every depth test of the reference kernel: never "dead")
+      m = d == d ? (d != 0.f ? fmaxf(m, d) : m) : INFINITY;
       dct[(size_t)x * im_h + y] = make_float2(d, color_im[y * im_w + x]);
     }
   part[ty][tx] = m;
@@ -345,11 +305,11 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
   px = min(im_w - 1, px);
   px = max(0, px);
   // every voxel of the column has depth = sqrtf(fma(z, z, fma(y, y, x * x))) >= rho (fma and sqrtf are monotonic), so
-  // depth_value - depth <= colmax - rho: if that is already < -trunc_margin the column is dead.  A column of zeros
-  // (colmax == 0) leaves at `depth_value == 0`.
+  // depth_value - depth <= colmax - rho for every non-zero pixel: if that is already < -trunc_margin the column is dead.
+  // A column without a non-zero pixel has colmax = -inf (every voxel leaves at `depth_value == 0`): dead by the same test.
   const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
   const float cm = colmax[px];
-  const bool dead = cm == 0.f || (cm - rho) < -trunc_margin;
+  const bool dead = (cm - rho) < -trunc_margin;
   // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
   // voxels of the (x + 1, -1) "column" there), each finding its own px
   const int info = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
@@ -708,24 +668,6 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   // degrees as float32 (:278-280)
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
   const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
-  const unsigned nb = (unsigned)((t->n + 255) / 256);
-  static const bool dense = []() {
-    const char* e = getenv("LIDARHIP_TSDF");
-    return e && strcmp(e, "dense") == 0;
-  }();
-  if (dense) {
-    t->all_dirty = 1;  // no column stamps from this kernel: the next reset / extraction treats every column as written
-    if (flags & LT_TSDF_MERGE)
-      hipLaunchKernelGGL(k_tsdf_integrate<true>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
-                         t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h,
-                         im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
-    else
-      hipLaunchKernelGGL(k_tsdf_integrate<false>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
-                         t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h,
-                         im_w, t->trunc_margin, obs_weight, fu, fd, color_im, depth_im, rem_im);
-    LT_HIP(hipGetLastError());
-    return LT_OK;
-  }
   if (im_w > t->cap_w) {
     if (t->colmax) {
       LT_HIP(hipDeviceSynchronize());

@@ -185,7 +185,7 @@ class HostScanPipeline:
                    "lt_hostpipe_create")
         self._h = h
         self.depth = int(depth)
-        self._live = {}  # ticket -> (inputs kept alive, outputs)
+        self._live = {}  # ticket -> [inputs kept alive (dropped when the slot is reused), outputs (kept until wait())]
 
     def alloc_outputs(self):
         np = self._np
@@ -218,19 +218,30 @@ class HostScanPipeline:
                                           rem.ctypes.data_as(fp), verts.size // 3, faces.size // 3, p("endpoints", fp),
                                           p("endcolors", ip), p("range", fp), p("endrem", fp), p("tri", ip), C.byref(t))
         if t.value >= 0:
-            self._live[t.value] = ((verts, faces, colors, rem, org), out)
-            self._live.pop(t.value - self.depth, None)  # that scan was completed by this submit
+            self._live[t.value] = [(verts, faces, colors, rem, org), out]
+            # the scan whose slot this submit reused was completed by it (its images are already in ITS output
+            # arrays): the library no longer reads its inputs -- drop those, but keep the outputs until the caller
+            # collects them with wait() (a caller may submit more than `depth` scans before waiting)
+            old = self._live.get(t.value - self.depth)
+            if old is not None:
+                old[0] = None
         _lib.check(rc, "lt_hostpipe_submit")
         return t.value
 
     def wait(self, ticket):
-        """Images of the scan with this ticket (complete when the call returns)."""
-        _lib.check(self._lib.lt_hostpipe_wait(self._h, int(ticket)), "lt_hostpipe_wait")
-        item = self._live.get(ticket)
-        return item[1] if item is not None else None
+        """Images of the scan with this ticket (complete when the call returns).  A ticket is handed out once: a second
+        wait() for it -- or a ticket this pipe never issued -- raises ``KeyError``."""
+        ticket = int(ticket)
+        if ticket not in self._live:
+            raise KeyError(f"HostScanPipeline.wait: ticket {ticket} is unknown or was already collected")
+        _lib.check(self._lib.lt_hostpipe_wait(self._h, ticket), "lt_hostpipe_wait")
+        return self._live.pop(ticket)[1]
 
     def flush(self):
+        """Complete every submitted scan; their images stay collectable with :meth:`wait`."""
         _lib.check(self._lib.lt_hostpipe_flush(self._h), "lt_hostpipe_flush")
+        for item in self._live.values():
+            item[0] = None
 
     def close(self):
         if getattr(self, "_h", None):

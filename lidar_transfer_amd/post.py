@@ -102,10 +102,10 @@ def compare(source_label, source_color, target_label, source_range, target_range
     mx = int(max(np.max(src_l), np.max(tgt_l), 0)) + 1
     lo = int(min(np.min(src_l), np.min(tgt_l), 0))
     if lo < 0:
-        # The reference renumbers the labels by rank among the values present (np.unique, laserscan.py:1216-1222)
-        # BEFORE they index the confusion matrix, so a negative label is simply the lowest class.  The histogram
-        # kernel counts non-negative codes: negatives travel as codes above the largest label (mx - 1 - v) -- raw 0
-        # stays 0, which is what the background rule tests -- and are put back in value order below.
+        # The reference renumbers the labels among the values present (np.unique, laserscan.py:1216-1222) BEFORE
+        # they index the confusion matrix (in place -- see the replay below: negative labels can merge classes).  The
+        # histogram kernel counts non-negative codes: negatives travel as codes above the largest label (mx - 1 - v)
+        # -- raw 0 stays 0, which is what the background rule tests -- and are put back in value order below.
         src_l = np.where(src_l < 0, mx - 1 - src_l, src_l).astype(np.int32)
         tgt_l = np.where(tgt_l < 0, mx - 1 - tgt_l, tgt_l).astype(np.int32)
     NL = 1
@@ -129,17 +129,26 @@ def compare(source_label, source_color, target_label, source_range, target_range
     conf = conf.cpu().numpy()          # conf[target, source] over raw labels
     # class compaction + iouEval on the (tiny) confusion matrix: host bookkeeping, no image work
     present = np.nonzero(conf.sum(0) + conf.sum(1))[0]
-    if lo < 0:  # codes of negative labels back into value order: code c >= mx stands for mx - 1 - c
-        value = np.where(present >= mx, mx - 1 - present, present)
-        present = present[np.argsort(value, kind="stable")]
-    k = len(present)
-    if k > nclasses:
+    # codes of negative labels back to values: code c >= mx stands for mx - 1 - c
+    value = np.where(present >= mx, mx - 1 - present, present) if lo < 0 else present.copy()
+    order = np.argsort(value, kind="stable")
+    present, value = present[order], value[order]
+    # The reference renumbers IN PLACE on the arrays it scans (laserscan.py:1216-1222: label[label == value] = i for
+    # the sorted values present).  For non-negative labels that is the rank (u_i >= i: no rank meets a value still to
+    # come); with negative labels a rank can equal a later value and the two classes MERGE ({-1, 0, 3}: -1 -> 0, then
+    # every 0 -> 1).  Replayed here on the list of values, not on the images.
+    cur = value.copy()
+    for i, v in enumerate(value):
+        cur[cur == v] = i
+    final = cur  # final[j] = class of the pixels whose raw label is value[j]
+    if len(final) and int(final.max()) >= nclasses:
         # np.add.at would raise IndexError in the reference (np_ioueval.py:47)
-        raise IndexError(f"compare: {k} distinct labels present but nclasses = {nclasses}")
+        raise IndexError(f"compare: class index {int(final.max())} after renumbering but nclasses = {nclasses}")
     cm = np.zeros((nclasses, nclasses), np.int64)
-    cm[:k, :k] = conf[np.ix_(present, present)]
-    ignore = np.arange(k, nclasses)
-    include = np.arange(k)
+    np.add.at(cm, (final[:, None], final[None, :]), conf[np.ix_(present, present)])
+    used = np.unique(final)
+    ignore = np.setdiff1d(np.arange(nclasses), used)
+    include = np.array([c for c in range(nclasses) if c not in set(ignore.tolist())], dtype=np.int64)
     c2 = cm.copy()
     c2[ignore] = 0
     c2[:, ignore] = 0
@@ -151,7 +160,7 @@ def compare(source_label, source_color, target_label, source_range, target_range
     m_iou = (tp[include] / union[include]).mean()
     m_acc = tp.sum() / (tp[include].sum() + fp[include].sum() + 1e-15)
     remap = np.full(NL, -1, np.int32)
-    remap[present] = np.arange(k, dtype=np.int32)
+    remap[present] = final.astype(np.int32)
     return dict(range_diff=rd.cpu().numpy().reshape(H, W), rem_diff=md.cpu().numpy().reshape(H, W), m_iou=m_iou,
                 m_acc=m_acc, MSE=float(sq.item()) / n, iou=iou,
                 source_label=remap[slm.cpu().numpy()].reshape(H, W), target_label=remap[tlm.cpu().numpy()].reshape(H, W))

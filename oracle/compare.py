@@ -18,12 +18,16 @@ def compare(source_label, source_color, target_label, source_range, target_range
     target_label[black_values] = 0
     bg_label = source_label == 0
     target_label[bg_label] = 0
-    # laserscan.py:1216-1222: renumber by rank among the values present
+    # laserscan.py:1216-1222: renumber by rank among the values present -- IN PLACE, on the arrays being scanned, as
+    # the reference does: with negative labels a rank can exceed a value that is still to come ({-1, 0, 3}: -1 -> 0,
+    # then every 0, the former -1 included, -> 1), so classes merge.  Non-negative label sets never alias (u_i >= i).
     unique_values = np.union1d(np.unique(source_label), np.unique(target_label))
-    sl, tl = np.copy(source_label), np.copy(target_label)
+    sl, tl = source_label, target_label   # (copies made above)
     for i, value in enumerate(unique_values):
-        sl[source_label == value] = i
-        tl[target_label == value] = i
+        mask_source = sl == value
+        mask_target = tl == value
+        sl[mask_source] = i
+        tl[mask_target] = i
     unique_values = np.union1d(np.unique(sl), np.unique(tl))
     empty = np.isin(np.arange(nclasses), unique_values, invert=True)
     ignore = np.arange(nclasses)[empty]

@@ -13,7 +13,7 @@
  * of it can be obtained.  What is restated from its published algorithm (skimage/measure/
  * _marching_cubes_lewiner_cy.pyx, Cell._add_face_from_edge_index): one vertex per sign-changing lattice edge,
  * shared by all cells around the edge, placed by the centre-of-mass rule
- *     w_i = 1 / (FLT_EPSILON + |v_i - level|)   (double),   p = (p_1 w_1 + p_2 w_2) / (w_1 + w_2),
+ *     w_i = 1 / (eps + |v_i - level|)   (double, eps = np.spacing(1.0)),   p = (p_1 w_1 + p_2 w_2) / (w_1 + w_2),
  * stored as float32.  The triangulation comes from the generated table oracle/lt_mc_table.h (classic marching
  * cubes with a face-consistent, watertight disambiguation -- oracle/gen_mc_table.py); on ambiguous cells
  * scikit-image's Lewiner variant may connect differently, and the ORDER of vertices / faces is this
@@ -35,9 +35,11 @@
 static inline int mc_inside(float v) { return v < 0.0f; } /* level = 0; NaN is outside */
 
 /* float32 vertex coordinate along the edge from voxel coordinate c (value v1) to c + 1 (value v2) */
+/* scikit-image's `FLT_EPSILON` is np.spacing(1.0) = 2^-52 (a double), not C's FLT_EPSILON */
+#define LT_MC_EPS 2.220446049250313e-16
 static inline float mc_edge_coord(int c, float v1, float v2) {
-  const double w1 = 1.0 / ((double)FLT_EPSILON + fabs((double)v1));
-  const double w2 = 1.0 / ((double)FLT_EPSILON + fabs((double)v2));
+  const double w1 = 1.0 / (LT_MC_EPS + fabs((double)v1));
+  const double w2 = 1.0 / (LT_MC_EPS + fabs((double)v2));
   const double ff = w1 + w2;
   return (float)((double)c + w2 / ff);
 }

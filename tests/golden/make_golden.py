@@ -322,6 +322,29 @@ def main():
     f7.update(cmp_range_diff=range_diff, cmp_rem_diff=rem_diff, cmp_m_iou=m_iou, cmp_m_acc=m_acc, cmp_mse=mse)
     save("f7_post", **f7)
 
+    # ---- F7b: compare() with NEGATIVE labels: the in-place renumbering (laserscan.py:1216-1222) lets a rank meet a
+    # value that is still to come, so classes merge ({-1, 0, 3}: -1 -> 0, then every 0 -> 1).  Pins that behaviour. --
+    f7b = {}
+    rngb = np.random.default_rng(77)
+    Hb, Wb = 8, 96
+    for case, vals in (("a", [-1, 0, 3]), ("b", [-7, -1, 0, 1, 10, 40, 259]), ("c", [-3, 2, 5, 6])):
+        vals = np.array(vals, np.int32)
+        sl_ = rngb.choice(vals, (Hb, Wb)).astype(np.int32)
+        tl_ = np.where(rngb.random((Hb, Wb)) < 0.75, sl_, rngb.choice(vals, (Hb, Wb))).astype(np.int32)
+        sc_ = rngb.random((Hb, Wb, 3))
+        sc_[rngb.random((Hb, Wb)) < 0.1] = 0
+        sr_, tr_ = (rngb.uniform(0, 80, (Hb, Wb)).astype(np.float32) for _ in range(2))
+        sm_, tm_ = (rngb.random((Hb, Wb)).astype(np.float32) for _ in range(2))
+        s_ = types.SimpleNamespace(proj_color=sc_, proj_label=sl_, proj_range=sr_, proj_remissions=sm_, nclasses=20)
+        t_ = types.SimpleNamespace(adaption="mesh", proj_color=rngb.random((Hb, Wb, 3)), label_image=tl_, proj_range=tr_,
+                                   proj_remissions=tm_)
+        _, rd_, md_, miou_, macc_, mse_ = ls.compare(s_, t_)
+        f7b.update({f"{case}_source_label": sl_, f"{case}_source_color": sc_, f"{case}_target_label": tl_,
+                    f"{case}_source_range": sr_, f"{case}_target_range": tr_, f"{case}_source_rem": sm_,
+                    f"{case}_target_rem": tm_, f"{case}_range_diff": rd_, f"{case}_rem_diff": md_,
+                    f"{case}_m_iou": miou_, f"{case}_m_acc": macc_, f"{case}_mse": mse_})
+    save("f7b_compare_negative", **f7b)
+
     # ---- F8: TSDF integrate, the reference's numpy CPU mode (fusion_lidar.py:289-392; = the `merge == false`
     # branch of the CUDA kernel without remissions).  The CUDA kernel itself cannot be run here. ---------------
     Ht, Wt, fut, fdt = 32, 256, 3.0, -25.0

@@ -62,6 +62,25 @@ def test_hostpipe_equals_one_ctrace_call_per_scan(label_image, depth):
     assert (got[0]["tri"] >= 0).sum() > 1000 and (got[2]["tri"] >= 0).sum() == 0
 
 
+def test_hostpipe_submit_everything_then_wait():
+    """More than `depth` scans submitted before the first wait (out=None): every ticket's images stay collectable --
+    the slot reuse completes the old scan into ITS arrays, which the pipe keeps until wait() hands them out once."""
+    from lidar_transfer_amd.pipeline import HostScanPipeline
+    H, W = 16, 256
+    rays = create_rays(3.0, -25.0, H, W)
+    meshes = [synth_scene(400 + i, 8000 + 4000 * i) for i in range(3)]
+    n, depth = 9, 2
+    origins = [np.array([0.2 * k, 0.0, 0.01 * k], np.float32) for k in range(n)]
+    with HostScanPipeline(rays, H, depth=depth) as pipe:
+        tickets = [pipe.submit(*meshes[k % 3], origins[k]) for k in range(n)]
+        got = [pipe.wait(t) for t in tickets]          # oldest first: long evicted from their slots
+        with pytest.raises(KeyError):
+            pipe.wait(tickets[0])                      # handed out once
+    for k in range(n):
+        assert got[k] is not None
+        _same(got[k], _ctrace(rays, origins[k], *meshes[k % 3], H, W))
+
+
 def test_hostpipe_reports_bad_indices_and_bad_arguments():
     from lidar_transfer_amd.pipeline import HostScanPipeline
     H, W = 8, 64

@@ -350,3 +350,18 @@ def test_compare_restatement_vs_reference_python():
     assert np.array_equal(r["rem_diff"].view(np.int32), g["cmp_rem_diff"].view(np.int32))
     assert r["m_iou"] == float(g["cmp_m_iou"]) and r["m_acc"] == float(g["cmp_m_acc"])
     assert np.float32(r["MSE"]) == g["cmp_mse"]
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_compare_restatement_negative_labels_vs_reference_python(case):
+    """Negative labels: the reference's in-place renumbering (laserscan.py:1216-1222) MERGES classes when a rank meets a
+    value still to come; the restatement replays that, pinned by golden F7b (made by the reference's own compare())."""
+    from oracle.compare import compare
+    g = np.load(os.path.join(GOLD, "f7b_compare_negative.npz"))
+    r = compare(g[f"{case}_source_label"], g[f"{case}_source_color"], g[f"{case}_target_label"],
+                g[f"{case}_source_range"], g[f"{case}_target_range"], g[f"{case}_source_rem"], g[f"{case}_target_rem"],
+                nclasses=20)
+    assert np.array_equal(r["range_diff"].view(np.int32), g[f"{case}_range_diff"].view(np.int32))
+    assert np.array_equal(r["rem_diff"].view(np.int32), g[f"{case}_rem_diff"].view(np.int32))
+    assert r["m_iou"] == float(g[f"{case}_m_iou"]) and r["m_acc"] == float(g[f"{case}_m_acc"])
+    assert np.float32(r["MSE"]) == g[f"{case}_mse"]

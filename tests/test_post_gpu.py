@@ -126,3 +126,17 @@ def test_compare_fuzz_incl_negative_labels_vs_oracle(seed):
     assert np.array_equal(got["rem_diff"].view(np.int32), want["rem_diff"].view(np.int32))
     assert abs(got["m_iou"] - want["m_iou"]) < 1e-12 and abs(got["m_acc"] - want["m_acc"]) < 1e-12
     assert np.allclose(got["iou"], want["iou"], atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_compare_negative_labels_vs_reference_golden(case):
+    """Golden F7b: the reference's own compare() on label sets with negative values, where its in-place renumbering
+    merges classes (laserscan.py:1216-1222) -- the device histogram + host replay must give its mIoU / accuracy."""
+    from lidar_transfer_amd.post import compare
+    g = np.load(os.path.join(GOLD, "f7b_compare_negative.npz"))
+    r = compare(g[f"{case}_source_label"], g[f"{case}_source_color"], g[f"{case}_target_label"],
+                g[f"{case}_source_range"], g[f"{case}_target_range"], g[f"{case}_source_rem"], g[f"{case}_target_rem"],
+                nclasses=20)
+    assert np.array_equal(r["range_diff"].view(np.int32), g[f"{case}_range_diff"].view(np.int32))
+    assert np.array_equal(r["rem_diff"].view(np.int32), g[f"{case}_rem_diff"].view(np.int32))
+    assert abs(r["m_iou"] - float(g[f"{case}_m_iou"])) < 1e-12 and abs(r["m_acc"] - float(g[f"{case}_m_acc"])) < 1e-12

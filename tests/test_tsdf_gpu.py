@@ -111,21 +111,47 @@ def test_volume_geometry_and_reset():
 
 
 _AB_SCRIPT = r"""
-import sys, numpy as np
+import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, %r)
 import torch
 from lidar_transfer_amd.fusion import TSDFVolume
 merge = sys.argv[2] == "1"
 H, W, fu, fd = 32, 256, float(sys.argv[3]), float(sys.argv[4])
+voxel = float(sys.argv[5]) if len(sys.argv) > 5 else 0.05
 rng = np.random.default_rng(5)
 yaw = np.linspace(-np.pi, np.pi, W)
-vol = TSDFVolume(np.array([[-15.0, 15.0], [-15.0, 15.0], [-5.0, 5.0]]), 0.05, fu, fd, merge=merge)   # 600 x 600 x 200 = 72 M voxels
+half = 15.0 if voxel < 0.1 else 20.0
+vol = TSDFVolume(np.array([[-half, half], [-half, half], [-5.0, 5.0]]), voxel, fu, fd, merge=merge)   # 0.05: 600 x 600 x 200 = 72 M voxels
+if os.environ.get("LT_TEST_TSDF") == "dense":
+    # the A/B partner: the one-thread-per-voxel restatement of the reference kernel (tests/csrc/lt_tsdf_dense.hip, a
+    # TEST library) writes the volume's fields through their raw pointers; the product only allocates and resets them
+    sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+    import build_helpers
+    dense = C.CDLL(build_helpers.build("liblt_tsdf_dense.so"))
+    def integrate_dense(color_im, depth_im, rem_im, cam_pose=None, obs_weight=1.):
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+        c = dev(color_im)
+        folded = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()   # fusion_lidar.py:261-264
+        d, r = dev(depth_im), dev(rem_im)
+        t, w, cv, rv = vol.get_volume_tensors()
+        dims = (C.c_int * 3)(*[int(x) for x in t.shape])
+        org = (C.c_float * 3)(*[float(x) for x in vol._vol_origin])
+        vp = C.c_void_p
+        rc = dense.lt_test_tsdf_integrate_dense(vp(t.data_ptr()), vp(w.data_ptr()), vp(cv.data_ptr()), vp(rv.data_ptr()), dims, org,
+                                                C.c_float(np.float32(voxel)), C.c_float(np.float32(voxel * 5)), C.c_float(fu), C.c_float(fd),
+                                                vp(folded.data_ptr()), vp(d.data_ptr()), vp(r.data_ptr()), H, W,
+                                                C.c_float(obs_weight), 1 if merge else 0, vp(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        vol.touch()   # written without column stamps: reset / extraction must take every column for written
+    vol.integrate = integrate_dense
 out = {}
 for rnd in range(2):          # second round: after a reset the volume must equal a fresh one
     for k in range(2):
         depth = (6.0 + 3.0 * np.sin(3 * yaw + k)[None, :] + 0.2 * rng.random((H, W))).astype(np.float32)
         depth[rng.random((H, W)) < 0.05] = 0.0
         depth[:, 40:60] = 0.0                                  # image columns without any return
+        depth[:, 100:110] = -1.0                               # ... and with the reference's "no data" value (laserscan.py:38)
         depth[rng.random((H, W)) < 0.003] = np.nan            # broken pixels: both kernels must treat them alike
         depth[rng.random((H, W)) < 0.003] = np.inf
         lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
@@ -142,7 +168,8 @@ for rnd in range(2):          # second round: after a reset the volume must equa
 # observation has stamped yet after a reset) and says so: nothing may be taken for fresh from here on
 vol.reset()
 ts = vol.get_volume_tensors()
-ts[0][60:160, 380:520, :] = 0.25; ts[1][60:160, 380:520, :] = 2.0; ts[2][60:160, 380:520, :] = 40.0 * 65536.0
+rx, ry = (slice(60, 160), slice(380, 520)) if voxel < 0.1 else (slice(20, 60), slice(100, 140))
+ts[0][rx, ry, :] = 0.25; ts[1][rx, ry, :] = 2.0; ts[2][rx, ry, :] = 40.0 * 65536.0
 vol.touch()
 depth = (7.0 + 2.0 * np.cos(2 * yaw)[None, :] + 0.1 * rng.random((H, W))).astype(np.float32)
 lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
@@ -152,15 +179,19 @@ np.savez(sys.argv[1], **{f"{k}{i}": a for k, v in out.items() for i, a in enumer
 """
 
 
-@pytest.mark.parametrize("merge,fu,fd", [(True, 10.0, -25.0), (False, 10.0, -25.0), (True, 40.0, -50.0), (True, 2.0, -24.8)])
-def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd):
+@pytest.mark.parametrize("merge,fu,fd,voxel", [(True, 10.0, -25.0, 0.05), (False, 10.0, -25.0, 0.05), (True, 40.0, -50.0, 0.05),
+                                                (True, 2.0, -24.8, 0.05), (True, 10.0, -25.0, 0.25), (False, 10.0, -25.0, 0.25)])
+def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd, voxel):
     """The work-saving integrate (per-column image column and dead-column test, conservative sine test, dirty-column
-    reset) against the plain one-thread-per-voxel kernel (LIDARHIP_TSDF=dense) on a 72 M-voxel volume -- beyond 2^24
+    reset) against the plain one-thread-per-voxel restatement of the reference kernel (tests/csrc/lt_tsdf_dense.hip: a TEST
+    library, not in liblidarhip.so) on a 72 M-voxel volume -- beyond 2^24
     voxels, where the reference's float voxel index misplaces voxels next to x boundaries -- two observations, a
     reset, the same two observations again: all four fields bit-identical, and the volume after the reset round equals
     the first round.  The first observation of a round goes through the band test + candidate queue (fresh columns), the
     second through the exact evaluation of every voxel; (40, -50) degrees is a field of view for which the band test is
-    switched off; zero, NaN and infinite depth pixels and colour 0 (the fresh volume's own) are in the images."""
+    switched off; zero, NaN and infinite depth pixels and colour 0 (the fresh volume's own) are in the images, and image
+    columns holding only the reference's "no data" depth -1 -- with voxel_size 0.25 the truncation margin is 1.25 m, so the
+    voxels within 0.25 m of the sensor ARE written through such pixels (depth_diff = -1 - depth >= -trunc_margin)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -168,11 +199,12 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
     for mode in ("cols", "dense"):
         env = dict(os.environ)
         if mode == "dense":
-            env["LIDARHIP_TSDF"] = "dense"
+            env["LT_TEST_TSDF"] = "dense"
         else:
-            env.pop("LIDARHIP_TSDF", None)
+            env.pop("LT_TEST_TSDF", None)
         path = str(tmp_path / f"{mode}.npz")
-        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd)], env=env,
+        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd), str(voxel)],
+                           env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = np.load(path)
@@ -181,6 +213,9 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
         assert np.array_equal(a.view(np.int32), b.view(np.int32)), key
     for i in range(4):
         assert np.array_equal(res["cols"][f"first{i}"].view(np.int32), res["cols"][f"second{i}"].view(np.int32)), i
-    assert (res["cols"]["third0"][60:160, 380:520, :] != 0.25).any()   # the touched region was observed
+    rx, ry = (slice(60, 160), slice(380, 520)) if voxel < 0.1 else (slice(20, 60), slice(100, 140))
+    assert (res["cols"]["third0"][rx, ry, :] != 0.25).any()   # the touched region was observed
     t = res["cols"]["first0"]
-    assert (t < 0).sum() > 10000 and (t != 1).mean() < 0.5
+    assert (t < 0).sum() > (10000 if voxel < 0.1 else 1000) and (t != 1).mean() < 0.5
+    if voxel > 0.2:   # voxels next to the sensor written through the all -1 image columns (trunc_margin 1.25 m > 1)
+        assert (res["dense"]["first1"] != 0).sum() > 0
