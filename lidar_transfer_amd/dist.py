@@ -7,7 +7,27 @@ on the GPU box, ``gloo`` in CPU tests) and the rendered images are gathered ONCE
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
+
+#: xGMI: every pair of the 8 GPUs of a node has its own link, ~64 GB/s per direction (7 links x ~153 GB/s bidirectional
+#: minus protocol).  A gather to ONE root moves each peer's images over that peer's own link into
+#: the root: the per-link rate bounds it, and the root's HBM takes the sum.
+XGMI_LINK_GBS = 64.0
+
+
+def choose_gather(world_size: int, bytes_per_scan: float, scans_per_s_per_rank: float,
+                  link_gbs: float = XGMI_LINK_GBS, headroom: float = 0.7) -> str:
+    """``"root"`` or ``"sharded"``: can the images of a job be gathered on one rank while they are rendered?
+
+    Each peer produces ``bytes_per_scan * scans_per_s_per_rank`` bytes per second for the root, over its own
+    point-to-point xGMI link.  Beyond ``headroom`` of the link rate the gather, not the renderer, would set the job's
+    throughput -- then every rank keeps (and writes) the scans it rendered, as the reference's loop would if it were
+    started once per shard (lidar_deform.py:385-390 with ``--offset`` / ``--batch_interval``), and only per-scan
+    metadata travels (:func:`render_scans` with ``gather="sharded"``)."""
+    if world_size <= 1:
+        return "root"
+    per_link = float(bytes_per_scan) * float(scans_per_s_per_rank) / 1e9
+    return "sharded" if per_link > headroom * link_gbs else "root"
 
 
 def scan_indices(n_scan_files: int, nscans: int = 1, offset: int = 0, batch_interval: int = 1) -> List[int]:
@@ -56,7 +76,8 @@ def gather_to_root(src, recv=None, dst: int = 0, group=None, copy_self: bool = T
 
 
 def render_scans(indices: Sequence[int], render_fn: Callable[[int], Dict[str, "object"]], keys: Sequence[str],
-                 group=None, dst: int = 0):
+                 group=None, dst: int = 0, gather: str = "root",
+                 meta_fn: Optional[Callable[[Dict[str, "object"]], "object"]] = None):
     """Render ``indices`` scan-parallel and gather the images on rank ``dst``.
 
     ``render_fn(idx)`` returns a dict of equally shaped ``torch`` tensors per scan (e.g. ``range`` [H*W]
@@ -64,14 +85,51 @@ def render_scans(indices: Sequence[int], render_fn: Callable[[int], Dict[str, "o
     go to ``dst`` with ONE gather per key (``gather_to_root``: no padding, every rank sends exactly its
     block).  Returns on ``dst`` a dict ``key -> tensor [len(indices), ...]`` in the order of ``indices``
     (``None`` on other ranks).
+
+    ``gather="sharded"`` (see :func:`choose_gather`): the images STAY on the rank that rendered them -- every rank
+    gets ``{"sharded": True, "indices": its block, "local": {key: stack}, "counts": block sizes of all ranks}`` --
+    and only ``meta_fn(result)`` (a small 1-D tensor per scan, e.g. hit count and checksum; default: the number of
+    non-zero elements of the first key) is gathered: ``"meta"`` on ``dst`` is ``[len(indices), M]`` in index order.
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if gather not in ("root", "sharded"):
+        raise ValueError("render_scans: gather must be 'root' or 'sharded'")
     mine = partition(list(indices), world, rank)
     local = [render_fn(i) for i in mine]
     counts = [len(partition(list(indices), world, r)) for r in range(world)]
+    if gather == "sharded":
+        if meta_fn is None:
+            def meta_fn(d):  # noqa: E731
+                return (d[keys[0]] != 0).sum().reshape(1).to(torch.int64)
+        stacks = {k: (torch.stack([d[k] for d in local]) if local else None) for k in keys}
+        metas = [meta_fn(d).reshape(-1).to(torch.int64) for d in local]
+        width = [metas[0].numel() if metas else 0]
+        if world > 1:  # (block partition: rank 0 holds a scan whenever anybody does)
+            dist.broadcast_object_list(width, src=0, group=group)
+        out = {"sharded": True, "indices": mine, "local": stacks, "counts": counts, "meta": None}
+        if width[0] == 0:
+            return out
+        dev = metas[0].device if metas else (local[0][keys[0]].device if local else torch.device("cpu"))
+        mstack = torch.stack(metas) if metas else torch.empty((0, width[0]), dtype=torch.int64, device=dev)
+        if world == 1:
+            out["meta"] = mstack
+            return out
+        if rank == dst:
+            if not metas:  # a root with an empty block: its device
+                dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and \
+                    dist.get_backend(group) == "nccl" else torch.device("cpu")
+            full = torch.empty((sum(counts), width[0]), dtype=torch.int64, device=dev)
+            offs = [sum(counts[:r]) for r in range(world)]
+            works = gather_to_root(mstack, [full[offs[r]:offs[r] + counts[r]] for r in range(world)], dst, group)
+            out["meta"] = full
+        else:
+            works = gather_to_root(mstack, None, dst, group)
+        for w in works:
+            w.wait()
+        return out
     out = {}
     for k in keys:
         stack = torch.stack([d[k] for d in local]) if local else None

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lidar_transfer_amd.dist import partition, render_scans, scan_indices
+from lidar_transfer_amd.dist import choose_gather, partition, render_scans, scan_indices
 
 
 def test_scan_indices_follow_the_reference_batch_loop():
@@ -64,6 +64,68 @@ def test_render_scans_two_ranks_equals_one(n):
         assert p.exitcode == 0
     assert np.array_equal(got["range"], single["range"].numpy())
     assert np.array_equal(got["label"], single["label"].numpy())
+
+
+def _meta(d):
+    return torch.stack([(d["range"] > 0.5).sum(), d["label"].to(torch.int64).sum()])
+
+
+def _sharded_worker(rank, world, port, indices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = render_scans(indices, _fake_render, ("range", "label"), gather="sharded", meta_fn=_meta)
+    q.put((rank, out["indices"], out["counts"], {k: (v.numpy() if v is not None else None) for k, v in out["local"].items()},
+           out["meta"].numpy() if out["meta"] is not None else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 7), (3, 4), (2, 1)])
+def test_render_scans_sharded_keeps_images_local_and_gathers_metadata(world, n):
+    """The fallback for jobs whose image rate exceeds the xGMI links into one root: every rank keeps the scans it
+    rendered (the same bytes the root gather would have delivered), only the per-scan metadata is gathered."""
+    indices = list(range(10, 10 + n))
+    single = render_scans(indices, _fake_render, ("range", "label"))
+    want_meta = torch.stack([_meta(_fake_render(i)) for i in indices]).numpy()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, indices, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    off = 0
+    for rank, mine, counts, local, meta in got:
+        assert mine == partition(indices, world, rank) and counts == [len(partition(indices, world, r)) for r in range(world)]
+        if mine:
+            assert np.array_equal(local["range"], single["range"].numpy()[off:off + len(mine)])
+            assert np.array_equal(local["label"], single["label"].numpy()[off:off + len(mine)])
+        else:
+            assert local["range"] is None
+        off += len(mine)
+        if rank == 0:
+            assert np.array_equal(meta, want_meta)
+        else:
+            assert meta is None
+    # single process: same structure
+    one = render_scans(indices, _fake_render, ("range", "label"), gather="sharded", meta_fn=_meta)
+    assert one["sharded"] and np.array_equal(one["meta"].numpy(), want_meta)
+
+
+def test_choose_gather_rule():
+    """Root gather while each peer's image stream fits its own xGMI link (with headroom), sharded beyond."""
+    R = 64 * 2048
+    assert choose_gather(1, 6 * R, 1e6) == "root"                      # nothing to gather from
+    assert choose_gather(8, 6 * R, 10_000) == "root"                   # 7.9 GB/s per link
+    assert choose_gather(8, 6 * R, 80_000) == "sharded"                # 63 GB/s per link: at the wire
+    assert choose_gather(8, 6 * R, 50_000, headroom=0.7) == "root"     # 39 GB/s < 44.8
+    assert choose_gather(8, 6 * R, 60_000, headroom=0.7) == "sharded"  # 47 GB/s > 44.8
 
 
 def _gather_worker(rank, world, port, q):

@@ -102,3 +102,83 @@ def test_bench_gpus_more_than_present_fails_loudly():
                           "--warmup", "1"], capture_output=True, text=True, timeout=300,
                          env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
     assert res.returncode != 0 and f"--gpus {n + 1}" in res.stderr and not res.stdout.strip()
+
+
+# ---- RCCL at the only world size the single-GPU test box has ------------------------------------------------------------
+_NCCL1_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from lidar_transfer_amd.dist import gather_to_root, render_scans
+from test_multigpu_gpu import _render_fn_factory
+mode = sys.argv[1]
+indices = list(range(4))
+keys = ("range", "label", "tri")
+if mode == "nccl":
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.barrier()                                     # the communicator really exists
+    t = torch.arange(8, device="cuda", dtype=torch.float32)
+    dist.all_reduce(t)
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+out = render_scans(indices, _render_fn_factory(0), keys)
+sh = render_scans(indices, _render_fn_factory(0), keys, gather="sharded")
+if mode == "nccl":
+    # the explicit gather path of bench.py at world size 1: root part by device copy, no peers
+    recv = torch.empty((1,) + tuple(out["range"].shape), dtype=torch.float32, device="cuda")
+    for w in gather_to_root(out["range"], recv, dst=0):
+        w.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(recv[0], out["range"])
+    dist.barrier()
+    dist.destroy_process_group()
+for k in keys:
+    assert torch.equal(sh["local"][k], out[k]), k
+assert sh["meta"].shape == (4, 1) and int(sh["meta"].min()) > 0
+np.savez(sys.argv[2], **{k: out[k].cpu().numpy() for k in keys})
+"""
+
+
+def test_rccl_world_size_1_gather_equals_no_dist(tmp_path):
+    """RCCL communicator creation, a collective, `render_scans` and `gather_to_root` under backend nccl at world size 1 --
+    the only size the single-GPU test box offers -- byte-equal to the run without torch.distributed; the sharded mode
+    keeps the same images local."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = {}
+    for mode in ("nodist", "nccl"):
+        path = str(tmp_path / f"{mode}.npz")
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, "-c", _NCCL1_SCRIPT % (ROOT, ROOT), mode, path, str(port)], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = np.load(path)
+    for k in ("range", "label", "tri"):
+        assert res["nodist"][k].tobytes() == res["nccl"][k].tobytes(), k
+    assert (res["nccl"]["range"] > 0).any()
+
+
+@pytest.mark.parametrize("gather", ["root", "sharded"])
+def test_bench_under_torchrun_one_rank_rccl(gather):
+    """`torchrun --nproc-per-node 1 bench.py`: backend nccl (= RCCL) is initialised, the gather path of the timed region
+    runs (root: images; sharded: metadata), and the line says the timed scans were verified."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(LT_BENCH_GATHER=gather, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps",
+                          "2", "--warmup", "1", "--workload", "C1", "--scenes", "4", "--no-cpu-baseline", "--no-other", "--no-e2e", "--no-chain"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and "RCCL" in out["config"]["parallelism"] and out["verified"] is True
+    assert out["config"]["gather"]["mode"] == gather
+    assert ("sharded" in out["config"]["parallelism"]) == (gather == "sharded")
+    assert np.isfinite(out["value"]) and out["value"] > 0
