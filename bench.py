@@ -42,10 +42,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROARCH.md, L2 section)
 N_SIMD, SHADER_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-# Calibrated with tools/valu_calib.hip (profiles/r03/valu_calib.txt): SQ_ACTIVE_INST_VALU counts in units of this many
-# shader cycles, and a SIMD issues one wave64 VALU instruction per this many cycles at full occupancy.
-SQ_CYCLES_PER_COUNT = 4.0
-VALU_CYCLES_PER_WAVE_INST = 4.0
+# Calibrated with tools/valu_calib.hip (profiles/r03/valu_calib.txt, 4096 straight-line v_fma_f32 per lane):
+#   * SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in every regime (1.000 per instruction): it counts issued instructions, it is NOT
+#     a duration -- round 2 multiplied it by 4 cycles ("quad-cycles") and called k_sc_tris 0.79 VALU-busy: wrong by 2x;
+#   * with >= 3 waves resident a SIMD issues one wave64 VALU instruction every ~2 cycles (0.89 SIMD-cycles per wave-inst
+#     measured per wave with ~3.6 waves co-resident = 2 x 3.6 / 8; 102 TFLOP/s non-packed fp32 over the launch), which is
+#     MI355X_MICROARCH.md's "v_fma_f32 (wave64): 2 cyc"; ONE wave alone issues only every 4.67 cycles (dependent or not);
+#   * the shader clock under full VALU load is 2.0-2.2 GHz, not the 2.4 GHz peak (s_memtime ticks / 100 MHz wall clock).
+# VALU-busy time of a launch = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / clock.
+SQ_CYCLES_PER_COUNT = 2.0
+VALU_CYCLES_PER_WAVE_INST = 2.0
 PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 per direction: 32 GT/s x 16 lanes x 128/130
 PCIE_WIRE_GBS = 56.3   # what a pinned hipMemcpyAsync of 26 MB reaches on this box (tools/pcie_probe.hip)
 PROBE_EVERY = int(os.environ.get("LT_BENCH_PROBE_EVERY", "8"))  # HIP-event pair around every n-th dominant launch
@@ -669,11 +675,11 @@ def main():
             valu = {"wave_insts_per_launch": te["valu_wave_insts_per_launch"],
                     "busy_cycles_per_simd": int(busy), "busy_ms_at_peak_clock": round(busy / SHADER_GHZ / 1e6, 5),
                     "frac_of_kernel_time": round(busy / SHADER_GHZ / 1e6 / serial_ms, 4),
-                    "note": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same launches (profiles pmc.json); unit of the "
-                            f"counter = {SQ_CYCLES_PER_COUNT:g} shader cycles, fixed by tools/valu_calib.hip "
-                            "(profiles/r03/valu_calib.txt); 256 CUs x 4 SIMDs at "
-                            f"{SHADER_GHZ} GHz -- the share of the kernel's time its SIMDs spend issuing "
-                            "vector ALU work: what actually bounds a kernel that moves few bytes per test"}
+                    "note": "SQ_INSTS_VALU of the same launches (profiles pmc.json) x "
+                            f"{SQ_CYCLES_PER_COUNT:g} cycles per wave64 instruction (tools/valu_calib.hip, "
+                            "profiles/r03/valu_calib.txt: SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU, it is a count) / 1024 "
+                            f"SIMDs at {SHADER_GHZ} GHz (the chip sustains 2.0-2.2 under load): the share of the kernel's "
+                            "time a SIMD needs to ISSUE its vector work at the peak rate"}
             d["valu_issue"] = valu
         if strategy == "lbvh":
             # The contract figure above prices the algorithmic bytes against HBM, but the tree is L2-resident (counter
