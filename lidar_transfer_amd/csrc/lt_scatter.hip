@@ -431,7 +431,7 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
 //              (azimuth) from the closest point of the triangle, which is at least cos(0.14) of the closest VERTEX
 //              away: the records carry 3e-4 + 2e-4 / (0.95 d) and 3e-4 + 2e-4 / (0.95 rho), in bins.
 // Everything else -- a vertex closer than 5 cm to the vertical axis or steeper than 1.1 rad, NaN / huge coordinates,
-// triangles wider than 0.1 rad, degenerate grids -- takes tri_bins as before (the record's gx is NaN, or the extent test
+// triangles wider than 0.1 rad, degenerate grids -- takes tri_bins as before (the record's padding is infinite, or the extent test
 // fails), wave-uniformly skipped when no lane needs it.  The rectangles differ from tri_bins' (both are supersets of the
 // rays the triangle test can accept); the images cannot, they are the minimum over ACCEPTED (t, face).
 struct vang_rec { float gx, gy, pa, pe; };
@@ -446,7 +446,10 @@ __device__ __forceinline__ float4 sc_vertex_record(const rs_params& P, float x, 
   const float gx = phi * P.az_scale + P.az_mid, gy = th * P.el_scale + P.el_mid;
   const float pa = (3e-4f + 2e-4f * __builtin_amdgcn_rsqf(0.9f * q)) * P.az_scale;
   const float pe = (3e-4f + 2e-4f * __builtin_amdgcn_rsqf(0.9f * d2)) * P.el_scale;
-  return make_float4(ok ? gx : NAN, gy, pa, pe);
+  // a vertex that may not take the fast path is marked by an INFINITE azimuth padding, not by a NaN coordinate: the min /
+  // max instructions of sc_fast_rect drop NaN operands (a NaN gx simply vanished from the extent -- found by
+  // tools/stress_scatter.py on meshes with a vertex flung to 1e30), an infinity survives every maximum
+  return ok ? make_float4(gx, gy, pa, pe) : make_float4(0.f, 0.f, INFINITY, 0.f);
 }
 
 // bin rectangle of a small triangle from its three vertex records; false = take tri_bins (R is then meaningless).
@@ -462,8 +465,9 @@ __device__ __forceinline__ bool sc_fast_rect(const rs_params& P, const float4 A,
   const float lo = fminf(0.f, fminf(d1, d2)), hi = fmaxf(0.f, fmaxf(d1, d2));
   const float ylo = fminf(A.y, fminf(B.y, C.y)), yhi = fmaxf(A.y, fmaxf(B.y, C.y));
   const float wx = hi - lo, wy = yhi - ylo;
-  const bool small = wx <= P.lim_x && wy <= P.lim_y;  // false when too wide -- or a record is NaN
-  const float pa = fmaxf(A.z, fmaxf(B.z, C.z)) + P.pad_dev_az;
+  const float pa_max = fmaxf(A.z, fmaxf(B.z, C.z));
+  const bool small = wx <= P.lim_x && wy <= P.lim_y && pa_max < 1e30f;  // false when too wide, or a vertex is marked
+  const float pa = pa_max + P.pad_dev_az;
   const float pe = fmaxf(A.w, fmaxf(B.w, C.w)) + P.pad_dev_el + (P.kx * (wx * wx) + P.ky * (wy * wy));
   const float e0f = fmaxf(ceilf(ylo - pe), 0.f), e1f = fminf(floorf(yhi + pe), (float)(P.nb_el - 1));
   const float fa0 = ceilf(A.x + lo - pa), fa1 = floorf(A.x + hi + pa);

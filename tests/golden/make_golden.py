@@ -28,23 +28,26 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-REF = "/root/reference"
+REF = os.environ.get("LT_REFERENCE", "/root/reference")
 sys.path.insert(0, ROOT)
 
 from oracle import binding as ob  # noqa: E402
 from lidar_transfer_amd.synth import soup, synth_cloud, synth_scene  # noqa: E402
 
 
-def import_reference():
+def import_reference(stub_skimage=True):
+    """`stub_skimage=False` (make_golden_mc.py): the REAL scikit-image must be importable -- marching cubes is then on the
+    computed path."""
     if not os.path.isdir(REF):
-        raise SystemExit("make_golden.py needs /root/reference")
+        raise SystemExit("make_golden.py needs the reference checkout at " + REF)
     ob.build(quiet=True)
     np.float = float  # removed alias used at laserscan.py:568, :714
     sys.modules["imageio"] = types.ModuleType("imageio")
-    sk = types.ModuleType("skimage")
-    sk.measure = types.ModuleType("skimage.measure")
-    sys.modules["skimage"] = sk
-    sys.modules["skimage.measure"] = sk.measure
+    if stub_skimage:
+        sk = types.ModuleType("skimage")
+        sk.measure = types.ModuleType("skimage.measure")
+        sys.modules["skimage"] = sk
+        sys.modules["skimage.measure"] = sk.measure
     # auxiliary.raytracer.RayTracerCython -> the compiled reference ctrace (same C_Trace signature)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_strict.so"))
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)

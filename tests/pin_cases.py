@@ -1,0 +1,85 @@
+"""Seeded inputs shared by the generators of the still-missing golden fixtures (tests/golden/make_golden_mc.py,
+make_golden_tsdf_cuda.py -- they need scikit-image / pycuda, which this image does not have) and by the GPU tests that
+consume those fixtures when present (tests/test_pin_f10_f11_gpu.py).  numpy only, deterministic for a seed on any machine
+(integer lattices, float64 sin/cos rounded to float32 afterwards)."""
+from __future__ import annotations
+
+import numpy as np
+
+# ---- F10: marching cubes (fusion_lidar.py:403-424) ----------------------------------------------------------------------
+#: name -> (H, W, fov_up, fov_down) of the image rendered from the extracted mesh (None: no render, mesh only)
+MC_CASES = {"street": (64, 1024, 3.0, -25.0), "blob": (32, 256, 40.0, -40.0), "noise": None}
+
+
+def mc_case(name):
+    """(tsdf, color_vol, rem_vol, voxel_size, vol_origin) of a marching-cubes case; float32 volumes, C order."""
+    if name == "street":
+        # a truncated signed distance field of a street scene seen from the origin: ground height field, four boxes,
+        # a pole -- what `integrate` leaves behind (values in [-1, 1], +1 in free space), 25 cm voxels, labels by object
+        vs = np.float32(0.25)
+        dims = (160, 160, 32)
+        org = np.array([-20.0, -20.0, -4.0], np.float32)
+        x, y, z = np.meshgrid(*[org[k] + vs * np.arange(dims[k]) for k in range(3)], indexing="ij")
+        ground = z - (-1.73 + 0.15 * np.sin(0.3 * x) * np.cos(0.2 * y))          # > 0 above the ground
+        sd, lab = ground.copy(), np.full(dims, 40.0)
+        boxes = [(6.0, 3.0, 2.0, 3.0, 2.5, 50.0), (-7.5, -4.0, 3.0, 2.0, 3.5, 50.0), (2.0, -9.0, 1.0, 2.2, 1.6, 10.0),
+                 (-3.0, 8.0, 4.0, 1.5, 2.0, 50.0)]
+        for cx, cy, hx, hy, top, lb in boxes:
+            q = np.stack([np.abs(x - cx) - hx, np.abs(y - cy) - hy, z - top], 0)
+            d = np.linalg.norm(np.maximum(q, 0), axis=0) + np.minimum(q.max(0), 0)
+            lab = np.where(d < sd, lb, lab)
+            sd = np.minimum(sd, d)
+        pole = np.maximum(np.hypot(x - 4.0, y + 3.0) - 0.2, z - 3.0)
+        lab = np.where(pole < sd, 80.0, lab)
+        sd = np.minimum(sd, pole)
+        tsdf = np.clip(sd / (5 * float(vs)), -1.0, 1.0).astype(np.float32)
+        # what the reference would not have seen stays at the initial 1 (behind surfaces by more than the margin)
+        tsdf[sd < -5 * float(vs)] = 1.0
+        color = (lab * 65536.0).astype(np.float32)                                # label in the b channel (:261-264)
+        rem = (0.5 + 0.4 * np.sin(0.7 * x + 0.3 * y)).astype(np.float32)
+        return tsdf, color, rem, vs, org
+    if name == "blob":
+        shape = (64, 64, 64)
+        g = [np.linspace(-1, 1, n) for n in shape]
+        x, y, z = np.meshgrid(*g, indexing="ij")
+        t = (np.sqrt(x * x + 1.3 * y * y + 0.7 * z * z) - 0.6 + 0.05 * np.sin(9 * x) * np.cos(7 * y)).astype(np.float32)
+        t = (-t).astype(np.float32)            # inside-out: free space (positive) around the origin, surface around it
+        col = np.full(shape, 40 * 65536, np.float32)
+        col[:, :, 32:] = 50 * 65536
+        rem = (0.5 + 0.5 * np.sin(3 * z)).astype(np.float32)
+        return t, col, rem, np.float32(0.1), np.array([-3.2, -3.2, -3.2], np.float32)
+    if name == "noise":                          # all 256 cases, every ambiguous face and interior
+        shape = (20, 18, 22)
+        rng = np.random.default_rng(2024)
+        t = rng.normal(size=shape).astype(np.float32)
+        t[rng.random(shape) < 0.05] = 0.0
+        col = (rng.integers(0, 260, shape) * 65536 + rng.integers(0, 256, shape) * 256 + rng.integers(0, 256, shape)).astype(np.float32)
+        rem = rng.random(shape).astype(np.float32)
+        return t, col, rem, np.float32(0.05), np.array([-1.25, 2.5, 0.75], np.float32)
+    raise KeyError(name)
+
+
+# ---- F11: class-aware TSDF integrate (the CUDA kernel, fusion_lidar.py:66-229) ------------------------------------------
+TSDF_BOUNDS = np.array([[-16.0, 16.0], [-16.0, 16.0], [-4.0, 4.0]])
+TSDF_VOXEL, TSDF_H, TSDF_W, TSDF_FOV = 0.25, 32, 256, (3.0, -25.0)
+
+
+def tsdf_observations(n=3):
+    """n observations (label3 [H,W,3] with the label in channel 0 as laserscan.py:893-895 builds it, depth, remission) of
+    a scene with several classes side by side -- so that voxels see DIFFERENT classes in successive observations and the
+    kernel's `dist < dist_old` branch (it compares with the WEIGHT volume, :191-228) is exercised."""
+    H, W = TSDF_H, TSDF_W
+    yaw = np.linspace(-np.pi, np.pi, W)
+    out = []
+    for k in range(n):
+        rng = np.random.default_rng(700 + k)
+        depth = (7.0 + 2.5 * np.sin(3 * yaw + 0.4 * k)[None, :] + 0.05 * rng.standard_normal((H, W))).astype(np.float32)
+        depth[rng.random((H, W)) < 0.04] = 0.0
+        lab = np.where(np.sin(5 * yaw + 0.9 * k)[None, :] + 0.2 * rng.standard_normal((H, W)) > 0, 40.0, 50.0)
+        lab[rng.random((H, W)) < 0.05] = 10.0
+        lab[rng.random((H, W)) < 0.03] = 0.0
+        label3 = np.zeros((H, W, 3), np.float64)
+        label3[:, :, 0] = lab
+        rem = rng.random((H, W)).astype(np.float32)
+        out.append((label3, depth, rem))
+    return out

@@ -11,27 +11,8 @@ from lidar_transfer_amd.synth import synth_scene
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_trace_gpu import _adversarial_soup
 
-ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--batch", type=int, default=0, help="also render groups of up to this many cases with one lt_scene_render_batch_dev call")
-ap.add_argument("--oracle", action="store_true", help="also compare with the brute-force CPU oracle where tris x rays < 3e7")
-a = ap.parse_args()
-dev = torch.device("cuda", 0)
-rng = np.random.default_rng(a.seed)
-bad = 0; tot_rays = tot_hits = tot_tris = 0; n_or = 0; pending = []; n_batched = 0
-
-
-def flush(pending):
-    """the scans rendered one by one above, once more as ONE batch call"""
-    global bad
-    outs = Scene.render_batch([p[0] for p in pending], [p[1] for p in pending], [p[2] for p in pending])
-    torch.cuda.synchronize()
-    for (sc_, rs_, org_, A_, case_), o in zip(pending, outs):
-        if not all(torch.equal(A_[k].view(torch.int32), o[k].view(torch.int32)) for k in ("tri", "range", "endpoints", "endcolors", "endrem")):
-            bad += 1
-            print(f"BATCH MISMATCH case {case_}")
-        rs_.close(); sc_.close()
-
-for case in range(a.cases):
+def make_case(rng):
+    """One random case (same draws, same order as ever: seeds reproduce)."""
     H = int(rng.choice([1, 2, 5, 16, 64, 128])); W = int(rng.choice([1, 3, 64, 301, 1024, 2048, 4000]))
     if rng.random() < 0.03: H, W = 5000, int(rng.choice([1, 3]))     # more rows than the bin grid has (4096)
     elif rng.random() < 0.03: H, W = int(rng.choice([1, 2])), 10000  # more columns than the bin grid has (8192)
@@ -74,6 +55,36 @@ for case in range(a.cases):
         broken = rng.integers(0, rays.shape[0], size=max(1, rays.shape[0] // 50))
         rays[broken[: broken.size // 2]] = 0.0
         rays[broken[broken.size // 2:], rng.integers(0, 3)] = np.nan
+    return H, W, up, down, kind, v, f, c, r, origin, rays, rk
+
+
+if __name__ != "__main__":  # imported (tools/debug_fast_rect.py): make_case() only, nothing below needs to run
+    sys.exit = lambda *a: None
+ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--batch", type=int, default=0, help="also render groups of up to this many cases with one lt_scene_render_batch_dev call")
+ap.add_argument("--first", type=int, default=0, help="skip the GPU work of the cases before this one (same random draws)")
+ap.add_argument("--oracle", action="store_true", help="also compare with the brute-force CPU oracle where tris x rays < 3e7")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(a.seed)
+bad = 0; tot_rays = tot_hits = tot_tris = 0; n_or = 0; pending = []; n_batched = 0
+
+
+def flush(pending):
+    """the scans rendered one by one above, once more as ONE batch call"""
+    global bad
+    outs = Scene.render_batch([p[0] for p in pending], [p[1] for p in pending], [p[2] for p in pending])
+    torch.cuda.synchronize()
+    for (sc_, rs_, org_, A_, case_), o in zip(pending, outs):
+        if not all(torch.equal(A_[k].view(torch.int32), o[k].view(torch.int32)) for k in ("tri", "range", "endpoints", "endcolors", "endrem")):
+            bad += 1
+            print(f"BATCH MISMATCH case {case_}")
+        rs_.close(); sc_.close()
+
+for case in range(a.cases):
+    H, W, up, down, kind, v, f, c, r, origin, rays, rk = make_case(rng)
+    if case < a.first:
+        continue
     if os.environ.get('LT_STRESS_VERBOSE'): print(f'case {case}: H={H} W={W} kind={kind} rk={rk:.3f} tris={f.shape[0]} origin={origin}', flush=True)
     sc = Scene(0); t = [torch.from_numpy(x).to(dev) for x in (v, f, c, r)]
     sc.set_mesh(*t); rt = torch.from_numpy(rays).to(dev); rs = RaySet(rt, H)
@@ -92,6 +103,12 @@ for case in range(a.cases):
         bad += 1
         nd = int((A["tri"] != B["tri"]).sum())
         print(f"MISMATCH case {case}: H={H} W={W} fov=({up:.2f},{down:.2f}) kind={kind} tris={f.shape[0]} origin={origin} differing rays={nd}")
+        if os.environ.get("LT_STRESS_DUMP"):  # for tools/debug_fast_rect.py: which rays, and the triangle each path found
+            os.makedirs(os.environ["LT_STRESS_DUMP"], exist_ok=True)
+            ids = torch.nonzero(A["tri"] != B["tri"]).reshape(-1)
+            np.savez(os.path.join(os.environ["LT_STRESS_DUMP"], f"case{case}.npz"), rays=ids.cpu().numpy(),
+                     tri_scatter=A["tri"][ids].cpu().numpy(), tri_lbvh=B["tri"][ids].cpu().numpy(),
+                     t_scatter=A["range"][ids].cpu().numpy(), t_lbvh=B["range"][ids].cpu().numpy())
     if a.batch > 1:
         pending.append((sc, rs, origin, {k: t_.clone() for k, t_ in A.items() if hasattr(t_, 'clone')}, case)); n_batched += 1
         if len(pending) == a.batch or case % 5 == 0:  # groups of 1 .. batch scans
