@@ -142,7 +142,6 @@ extern "C" int lt_scene_destroy(lt_scene* s) {
   if (s->sc_large) (void)hipFree(s->sc_large);
   if (s->sc_slices) (void)hipFree(s->sc_slices);
   if (s->sc_large_count) (void)hipFree(s->sc_large_count);
-  if (s->sc_vang) (void)hipFree(s->sc_vang);
   for (int k = 0; k < s->have_events; ++k) (void)hipEventDestroy(s->ev[k]);
   free(s);
   return LT_OK;

@@ -93,8 +93,6 @@ struct lt_scene {
   int2* sc_slices;              // [sc_cap_queue] queue of (block, first candidate) slices
   int* sc_large_count;          // [4]: [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
   int sc_cap_cells, sc_cap_queue;
-  float4* sc_vang;              // [sc_cap_vang] per-vertex angular record of the render in flight (k_sc_verts, lt_scatter.hip)
-  int sc_cap_vang;
   int built;
   hipStream_t last_stream;
   hipEvent_t probe[2];   // caller's events to record around the dominant kernel of the next cast (one shot)

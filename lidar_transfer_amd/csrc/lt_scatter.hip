@@ -57,14 +57,6 @@ struct rs_params {
   //   row bounds    ceil(th * el_scale + el_c0), floor(th * el_scale + el_c1)
   //   column bounds ceil(a * az_scale + az_c0),  floor(a * az_scale + az_c1)
   float el_c0, el_c1, az_c0, az_c1;
-  // the per-vertex path (k_sc_verts / sc_fast_rect): a vertex's continuous grid coordinates are
-  //   gx = phi * az_scale + az_mid,   gy = th * el_scale + el_mid
-  // fast_ok: the grid has >= 4 columns and a non-degenerate elevation scale (else every triangle takes tri_bins);
-  // lim_x / lim_y: 0.1 rad in bins -- the largest extent of a triangle that may take the fast path;
-  // kx / ky: the great-circle bulge of an edge in row bins = kx * w_x^2 + ky * w_y^2 (sc_fast_rect);
-  // pad_dev_az / pad_dev_el = dev + LT_BIN_SLACK;  nbf = nb_az, inv_nb = 1 / nb_az as floats
-  int fast_ok;
-  float az_mid, el_mid, lim_x, lim_y, kx, ky, pad_dev_az, pad_dev_el, nbf, inv_nb;
 };
 
 __device__ __forceinline__ float rs_az_off(float phi0, float az_scale) {
@@ -413,76 +405,6 @@ __device__ __forceinline__ bin_rect tri_bins(const rs_params& P, float x0, float
   return R;
 }
 
-// ---- the per-vertex path ---------------------------------------------------------------------------------------------
-// tri_bins recomputes, per TRIANGLE, what are properties of its VERTICES: an indexed mesh uses a vertex in ~6 triangles,
-// and two thirds of a street scene's triangles end up with no ray inside their bounds at all.  k_sc_verts computes, once
-// per vertex and scan, the vertex's continuous bin-grid coordinates (gx, gy) as seen from the scan's origin and its two
-// paddings in bins; a triangle that is SMALL as seen from the origin (<= 0.1 rad in azimuth and elevation: everything but
-// the near field) gets its bin rectangle from the three records with a few min / max (sc_fast_rect).  Why that is
-// conservative -- the projection of a triangle onto the unit sphere is the spherical triangle of its vertex directions:
-//   azimuth    the projection of the triangle into the xy plane is a convex polygon; its vertices lie within 0.1 rad of
-//              azimuth of each other, so it does not contain the axis and its angular extent is spanned by two vertices;
-//   elevation  sin(elevation) is the cosine of the angle to the pole: over a geodesically convex region that does not
-//              hold the pole its extremes lie on the boundary, i.e. on a great-circle arc between two vertices.  Along an
-//              arc of length W, z(s) = sin(elevation) obeys z'' = -z, so it leaves the chord by at most W^2 / 8 * max|z|,
-//              and d(elevation) = dz / cos(elevation): with |elevation| <= 1.1 rad at the vertices (k_sc_verts) the bulge is
-//              below 0.25 W^2 (0.3 is used), and W^2 <= d_azimuth^2 + d_elevation^2;
-//   padding    the positional slop of the float triangle test subtends slop / distance (elevation) and slop / rho
-//              (azimuth) from the closest point of the triangle, which is at least cos(0.14) of the closest VERTEX
-//              away: the records carry 3e-4 + 2e-4 / (0.95 d) and 3e-4 + 2e-4 / (0.95 rho), in bins.
-// Everything else -- a vertex closer than 5 cm to the vertical axis or steeper than 1.1 rad, NaN / huge coordinates,
-// triangles wider than 0.1 rad, degenerate grids -- takes tri_bins as before (the record's padding is infinite, or the extent test
-// fails), wave-uniformly skipped when no lane needs it.  The rectangles differ from tri_bins' (both are supersets of the
-// rays the triangle test can accept); the images cannot, they are the minimum over ACCEPTED (t, face).
-struct vang_rec { float gx, gy, pa, pe; };
-
-__device__ __forceinline__ float4 sc_vertex_record(const rs_params& P, float x, float y, float z) {
-#pragma clang fp contract(fast)
-  const float q = x * x + y * y, d2 = q + z * z;
-  const float rho = f_sqrt(q);
-  const float phi = f_atan2(y, x), th = f_atan2(z, rho);
-  // |z| <= 1.96 rho <=> |elevation| <= 1.1 rad; q >= (5 cm)^2; finite (NaN fails every comparison)
-  const bool ok = q >= 0.0025f && d2 < 1e30f && fabsf(z) <= 1.96f * rho;
-  const float gx = phi * P.az_scale + P.az_mid, gy = th * P.el_scale + P.el_mid;
-  const float pa = (3e-4f + 2e-4f * __builtin_amdgcn_rsqf(0.9f * q)) * P.az_scale;
-  const float pe = (3e-4f + 2e-4f * __builtin_amdgcn_rsqf(0.9f * d2)) * P.el_scale;
-  // a vertex that may not take the fast path is marked by an INFINITE azimuth padding, not by a NaN coordinate: the min /
-  // max instructions of sc_fast_rect drop NaN operands (a NaN gx simply vanished from the extent -- found by
-  // tools/stress_scatter.py on meshes with a vertex flung to 1e30), an infinity survives every maximum
-  return ok ? make_float4(gx, gy, pa, pe) : make_float4(0.f, 0.f, INFINITY, 0.f);
-}
-
-// bin rectangle of a small triangle from its three vertex records; false = take tri_bins (R is then meaningless).
-// Branch-free: the early exits of a lane save nothing while its wave goes on, and with branches the compiler split the
-// 16-byte record loads into an (x, y) half and a dependent second load of the paddings.
-__device__ __forceinline__ bool sc_fast_rect(const rs_params& P, const float4 A, const float4 B, const float4 C,
-                                             bin_rect& R) {
-#pragma clang fp contract(fast)
-  // azimuth differences to vertex A, wrapped into [-nb/2, nb/2]
-  float d1 = B.x - A.x, d2 = C.x - A.x;
-  d1 -= P.nbf * rintf(d1 * P.inv_nb);
-  d2 -= P.nbf * rintf(d2 * P.inv_nb);
-  const float lo = fminf(0.f, fminf(d1, d2)), hi = fmaxf(0.f, fmaxf(d1, d2));
-  const float ylo = fminf(A.y, fminf(B.y, C.y)), yhi = fmaxf(A.y, fmaxf(B.y, C.y));
-  const float wx = hi - lo, wy = yhi - ylo;
-  const float pa_max = fmaxf(A.z, fmaxf(B.z, C.z));
-  const bool small = wx <= P.lim_x && wy <= P.lim_y && pa_max < 1e30f;  // false when too wide, or a vertex is marked
-  const float pa = pa_max + P.pad_dev_az;
-  const float pe = fmaxf(A.w, fmaxf(B.w, C.w)) + P.pad_dev_el + (P.kx * (wx * wx) + P.ky * (wy * wy));
-  const float e0f = fmaxf(ceilf(ylo - pe), 0.f), e1f = fminf(floorf(yhi + pe), (float)(P.nb_el - 1));
-  const float fa0 = ceilf(A.x + lo - pa), fa1 = floorf(A.x + hi + pa);
-  const float naf = (fa1 - fa0) + 1.0f;
-  const bool any = e0f <= e1f && naf >= 1.0f;  // a row and a ray column inside the bounds
-  const int na = (int)fminf(naf, P.nbf);
-  int a0 = (int)fa0;  // gx in [-0.5, nb_az + 0.5], the extent <= lim_x + pads << nb_az: at most one wrap either way
-  a0 = a0 < 0 ? a0 + P.nb_az : (a0 >= P.nb_az ? a0 - P.nb_az : a0);
-  R.e0 = (int)e0f;
-  R.e1 = (int)e1f;
-  R.a0 = na >= P.nb_az ? 0 : a0;
-  R.na = any ? na : 0;
-  return small;
-}
-
 // grid[bin] = the bin's ray when it holds exactly one (direction, ray index in .w), a zero direction with
 // .w = -1 when it is empty (Moller-Trumbore rejects it at the determinant test), or (.x, .y) = the bin's slot
 // range in sdirs with .w = -2 when it holds several rays (irregular ray sets; a sensor grid has one per bin).
@@ -560,48 +482,29 @@ struct sc_shared {
 };
 
 // Phase A: thread tid sets up triangle first_face + tid (record + bin rectangle) in LDS; returns its number
-// of candidate bins (0 for none / invalid / big; big triangles are queued when PUSH).  The rectangle comes from the
-// three per-vertex records (sc_fast_rect) whenever the triangle is small as seen from the origin; the vertex POSITIONS
-// are then gathered only by the lanes that have candidates (a third of them on a street scene).
+// of candidate bins (0 for none / invalid / big; big triangles are queued when PUSH)
 template <bool PUSH, bool WIDE>
 __device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
-                                        const float4* __restrict__ vang, int n_verts, int n_faces, int f, float ox,
-                                        float oy, float oz, const rs_params& P, int* __restrict__ large,
-                                        int* __restrict__ large_count, unsigned* __restrict__ flags) {
+                                        int n_verts, int n_faces, int f, float ox, float oy, float oz,
+                                        const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
+                                        unsigned* __restrict__ flags) {
   const int tid = threadIdx.x;
   int cnt = 0;
   if (f < n_faces) {
     const i3 idx = *at<WIDE>((const i3*)faces, (unsigned)f);
     const int a = idx.x, b = idx.y, c = idx.z;
     if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
-      bin_rect R;
-      R.na = 0;
-      bool fast = false;
-#if !defined(LT_SC_NO_FAST)
-      if (P.fast_ok) {
-        const float4 RA = *at<WIDE>(vang, (unsigned)a), RB = *at<WIDE>(vang, (unsigned)b), RC = *at<WIDE>(vang, (unsigned)c);
-        fast = sc_fast_rect(P, RA, RB, RC, R);
-      }
+      const f3 A = *at<WIDE>((const f3*)verts, (unsigned)a);
+      const f3 B = *at<WIDE>((const f3*)verts, (unsigned)b);
+      const f3 C = *at<WIDE>((const f3*)verts, (unsigned)c);
+      const float v0x = A.x, v0y = A.y, v0z = A.z, v1x = B.x, v1y = B.y, v1z = B.z;
+      const float v2x = C.x, v2y = C.y, v2z = C.z;
+#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads only
+      return (v0x + v1y + v2z == 12345.f) ? 1 : 0;
 #endif
-#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads + fast rectangle
-      return (fast && R.na == 12345) ? 1 : 0;
-#endif
-      float v0x = 0.f, v0y = 0.f, v0z = 0.f, v1x = 0.f, v1y = 0.f, v1z = 0.f, v2x = 0.f, v2y = 0.f, v2z = 0.f;
-#if defined(LT_SC_EARLY_POS)  // A/B: every lane gathers its positions at once (shorter dependent chain, more bytes)
-      const bool need_pos = true;
-#else
-      const bool need_pos = !fast || R.na > 0;
-#endif
-      if (need_pos) {
-        const f3 A = *at<WIDE>((const f3*)verts, (unsigned)a);
-        const f3 B = *at<WIDE>((const f3*)verts, (unsigned)b);
-        const f3 C = *at<WIDE>((const f3*)verts, (unsigned)c);
-        v0x = A.x; v0y = A.y; v0z = A.z; v1x = B.x; v1y = B.y; v1z = B.z; v2x = C.x; v2y = C.y; v2z = C.z;
-      }
       const float e1x = v1x - v0x, e1y = v1y - v0y, e2x = v2x - v0x, e2y = v2y - v0y;
-      if (!fast)  // near field, steep or broken geometry, degenerate grid: the per-triangle bounds
-        R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy, v2z - oz, e1x, e1y,
-                     e2x, e2y);
+      const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
+                                  v2z - oz, e1x, e1y, e2x, e2y);
       if (R.na > 0) {  // (rows e0..e1 are non-empty whenever na > 0)
         const int c32 = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
         if (c32 > LT_SC_BIG) {
@@ -731,7 +634,6 @@ struct sc_job {
   const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
   rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
   unsigned long long* cell; int* large; int* large_count; int2* slices;
-  float4* vang;  // per-vertex records of this scan (k_sc_verts)
   unsigned* flags; unsigned long long* counters;
   float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
   float ox, oy, oz;
@@ -739,26 +641,13 @@ struct sc_job {
   unsigned out_flags;
   int tris_block0;     // first workgroup of this scan in k_sc_tris
   int resolve_block0;  // ... in k_sc_resolve
-  int verts_block0;    // ... in k_sc_verts
 };
 struct sc_batch {
   int n;
-  int tris_blocks, resolve_blocks, verts_blocks;  // grid sizes
+  int tris_blocks, resolve_blocks;  // grid sizes
   int cap;                          // LT_SC_CAP_SINGLE / LT_SC_CAP_BATCH
   sc_job job[LT_SC_MAX_BATCH];
 };
-
-// One thread per vertex of a scan: its angular record as seen from the scan's origin (sc_vertex_record)
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_sc_verts(const sc_batch B) {
-  int j = 0;
-  while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].verts_block0) ++j;
-  const sc_job& J = B.job[j];
-  const int v = ((int)blockIdx.x - J.verts_block0) * 256 + (int)threadIdx.x;
-  if (v >= J.n_verts) return;
-  const f3 p = *at<WIDE>((const f3*)J.verts, (unsigned)v);
-  *at<WIDE>(J.vang, (unsigned)v) = sc_vertex_record(J.P, p.x - J.ox, p.y - J.oy, p.z - J.oz);
-}
 
 // One workgroup = 256 consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~B.cap
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
@@ -773,8 +662,8 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   const int first = lb * 256;
   const rs_params P = J.P;
   const float ox = J.ox, oy = J.oy, oz = J.oz;
-  const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.vang, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P,
-                                       J.large, J.large_count, J.flags);
+  const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P, J.large,
+                                       J.large_count, J.flags);
 #if defined(LT_SC_STOP) && LT_SC_STOP <= 2  // ... up to the angular bounds and the LDS record
   if (cnt == 0x7fffffff) J.counters[7] = 1;
   return;
@@ -833,8 +722,8 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
     const int2 sl = J.slices[q];
     const int first = sl.x * 256;
-    const int cnt = sc_setup<false, WIDE>(S, verts, faces, J.vang, J.n_verts, J.n_faces, first + (int)threadIdx.x, ox, oy,
-                                          oz, P, nullptr, nullptr, nullptr);
+    const int cnt = sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first + (int)threadIdx.x, ox, oy, oz, P,
+                                          nullptr, nullptr, nullptr);
     int total;
     (void)sc_prefix(S, cnt, total);
     __syncthreads();
@@ -949,18 +838,6 @@ static void rs_derive(rs_params& p) {
   p.el_c1 = -p.el_lo * p.el_scale + de;
   p.az_c0 = LT_PI_F * p.az_scale - p.az_off - da;
   p.az_c1 = LT_PI_F * p.az_scale - p.az_off + da;
-  // the per-vertex path (sc_fast_rect)
-  p.fast_ok = (p.nb_az >= 4 && p.el_scale > 0.f && p.az_scale > 0.f) ? 1 : 0;
-  p.az_mid = LT_PI_F * p.az_scale - p.az_off;
-  p.el_mid = -p.el_lo * p.el_scale;
-  p.lim_x = 0.1f * p.az_scale;
-  p.lim_y = 0.1f * p.el_scale;
-  p.kx = p.fast_ok ? 0.3f * p.el_scale / (p.az_scale * p.az_scale) : 0.f;  // bulge (rad) = 0.3 (dphi^2 + dth^2), in row bins
-  p.ky = p.fast_ok ? 0.3f / p.el_scale : 0.f;
-  p.pad_dev_az = da;
-  p.pad_dev_el = de;
-  p.nbf = (float)p.nb_az;
-  p.inv_nb = 1.0f / (float)p.nb_az;
 }
 
 struct lt_rayset {
@@ -1092,17 +969,6 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
 // "big", and a block of 256 triangles with <= LT_SC_BIG candidates each leaves at most
 // 256 * LT_SC_BIG / LT_SC_SLICE = 256 slices.
 static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) {
-  if (s->n_verts > s->sc_cap_vang) {
-    if (s->sc_vang) {
-      LT_HIP(hipDeviceSynchronize());
-      (void)hipFree(s->sc_vang);
-      s->sc_vang = nullptr;
-      s->sc_cap_vang = 0;
-    }
-    const size_t cap = (size_t)s->n_verts + s->n_verts / 4 + 1024;
-    LT_HIP(hipMalloc((void**)&s->sc_vang, cap * sizeof(float4)));
-    s->sc_cap_vang = (int)min(cap, (size_t)2147483647);
-  }
   if (!s->sc_large_count) {
     LT_HIP(hipMalloc((void**)&s->sc_large_count, 4 * sizeof(int)));
     LT_HIP(hipMemsetAsync(s->sc_large_count, 0, 4 * sizeof(int), stream));
@@ -1153,7 +1019,7 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
   // with > 357 M triangles): a test hook
   static const bool force_wide = getenv("LIDARHIP_FORCE_WIDE") != nullptr;
   bool wide = force_wide;
-  int tb = 0, rb = 0, vb = 0;
+  int tb = 0, rb = 0;
   for (int i = 0; i < n_items; ++i) {
     lt_scene* s = it[i].s;
     lt_rayset* r = it[i].r;
@@ -1164,7 +1030,6 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     J.verts = s->verts; J.faces = s->faces; J.colors = s->colors; J.rem = s->rem;
     J.P = r->prm_host; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
     J.cell = s->sc_cell; J.large = s->sc_large; J.large_count = s->sc_large_count; J.slices = s->sc_slices;
-    J.vang = s->sc_vang;
     J.flags = s->flags; J.counters = s->counters;
     J.endpoints = it[i].endpoints; J.endcolors = it[i].endcolors; J.range = it[i].range; J.endrem = it[i].endrem;
     J.tri = it[i].tri;
@@ -1173,18 +1038,15 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     J.out_flags = flags;
     J.tris_block0 = tb;
     J.resolve_block0 = rb;
-    J.verts_block0 = vb;
     tb += (n + 255) / 256;
     rb += (R + 255) / 256;
-    if (n > 0 && r->prm_host.fast_ok) vb += (s->n_verts + 255) / 256;  // (no triangles or no fast path: no records needed)
-    // 32-bit byte offsets unless an array of the launch reaches 4 GB (> 357 M triangles, > 268 M vertices / rays)
-    wide = wide || (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 16 >= (1ull << 32) ||
+    // 32-bit byte offsets unless an array of the launch reaches 4 GB (> 357 M triangles / vertices, > 268 M rays)
+    wide = wide || (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 12 >= (1ull << 32) ||
            (size_t)R * 16 >= (1ull << 32);
   }
   if (B.n == 0) return LT_OK;
   B.tris_blocks = tb;
   B.resolve_blocks = rb;
-  B.verts_blocks = vb;
   static const int env_cap = []() {
     const char* e = getenv("LIDARHIP_SC_CAP");
     return e ? atoi(e) : 0;
@@ -1199,10 +1061,6 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     else hipLaunchKernelGGL((KERNEL<false, false>), GRID, b, 0, stream, B); \
   } while (0)
   if (tb > 0) {
-    if (vb > 0) {
-      if (wide) hipLaunchKernelGGL(k_sc_verts<true>, dim3(vb), b, 0, stream, B);
-      else hipLaunchKernelGGL(k_sc_verts<false>, dim3(vb), b, 0, stream, B);
-    }
     if (probe && probe->probe[0]) LT_HIP(hipEventRecord(probe->probe[0], stream));
     SC_LAUNCH(k_sc_tris, dim3(tb));
     if (probe) {

@@ -58,8 +58,6 @@ def make_case(rng):
     return H, W, up, down, kind, v, f, c, r, origin, rays, rk
 
 
-if __name__ != "__main__":  # imported (tools/debug_fast_rect.py): make_case() only, nothing below needs to run
-    sys.exit = lambda *a: None
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=100); ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--batch", type=int, default=0, help="also render groups of up to this many cases with one lt_scene_render_batch_dev call")
 ap.add_argument("--first", type=int, default=0, help="skip the GPU work of the cases before this one (same random draws)")
@@ -103,7 +101,7 @@ for case in range(a.cases):
         bad += 1
         nd = int((A["tri"] != B["tri"]).sum())
         print(f"MISMATCH case {case}: H={H} W={W} fov=({up:.2f},{down:.2f}) kind={kind} tris={f.shape[0]} origin={origin} differing rays={nd}")
-        if os.environ.get("LT_STRESS_DUMP"):  # for tools/debug_fast_rect.py: which rays, and the triangle each path found
+        if os.environ.get("LT_STRESS_DUMP"):  # which rays, and the triangle each path found (numpy dump for a CPU post-mortem)
             os.makedirs(os.environ["LT_STRESS_DUMP"], exist_ok=True)
             ids = torch.nonzero(A["tri"] != B["tri"]).reshape(-1)
             np.savez(os.path.join(os.environ["LT_STRESS_DUMP"], f"case{case}.npz"), rays=ids.cpu().numpy(),
