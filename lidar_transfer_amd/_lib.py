@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("ms_gather", C.c_float), ("ms_segtree", C.c_float), ("ms_hierarchy", C.c_float),
                 ("ms_build", C.c_float), ("ms_trace", C.c_float), ("n_faces", C.c_int), ("n_nodes", C.c_int),
                 ("n_rays", C.c_int), ("n_hits", C.c_int), ("nodes_visited", C.c_ulonglong),
-                ("tris_tested", C.c_ulonglong), ("stack_overflows", C.c_ulonglong)]
+                ("tris_tested", C.c_ulonglong), ("stack_overflows", C.c_ulonglong), ("entries_culled", C.c_ulonglong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -124,6 +124,19 @@ struct lt_tsdf {
   int cap_w;
   float2* dct;          // [cap_dct] per integrate call: (depth, colour) of pixel (row, px) at [px * im_h + row] -- the voxels of
   size_t cap_dct;       // a column walk read consecutive rows of ONE image column: contiguous here, a line apart in the image
+  // the pixel-centric integrate of a fresh volume (k_tsdf_integrate_pix, lt_tsdf.hip)
+  int n_obs;            // observations integrated since the last reset (0: every voxel holds its initial value)
+  int wd_w;             // image width the wedge table was built for (0: none yet)
+  int wd_rho_bits, wd_n_quirk;
+  float wd_qscale;
+  int* wd_px;           // [dim_x * dim_y] image column of every voxel column (geometry + image width only)
+  int* wd_start;        // [wd_w + 1] first table entry of every image column's wedge
+  int2* wd_ent;         // [dim_x * dim_y] (voxel column, rho^2 bits) sorted by (image column, rho); column -1: quirk tail
+  unsigned* wd_key;     // [dim_x * dim_y] rho quantum of every entry (the binary searches compare these)
+  unsigned* wd_qcols;   // [wd_n_quirk] the columns k_tsdf_integrate_quirk evaluates voxel by voxel
+  float4* rowtab;       // [rowtab_h] per image row: tan / cos of its pitch range with margins (host, double)
+  int rowtab_h;         // capacity
+  int rowtab_for_h;     // image height the table holds (the field of view is fixed per volume)
 };
 
 #define LT_BOUNDS_BLOCKS 256

@@ -1112,6 +1112,7 @@ extern "C" int lt_scene_render_dev(lt_scene* s, lt_rayset* r, const float* origi
       s->stats.tris_tested = c[1];    // Moller-Trumbore evaluations
       s->stats.n_hits = (int)c[2];
       s->stats.stack_overflows = 0;
+      s->stats.entries_culled = 0;
     }
     if (stats) *stats = s->stats;
   }

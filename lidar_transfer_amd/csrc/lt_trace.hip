@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256) void k_trace4(
     float* __restrict__ range, float* __restrict__ endrem, int* __restrict__ tri_out, unsigned flags,
     int* __restrict__ overflow, unsigned long long* __restrict__ counters, int step_cap, tail_args tail) {
   __shared__ int stack[4][LT_STACK4_LDS][16];
+  // entry distance of every deferred child, upper 16 bits of the float (tn >= 0: truncation rounds DOWN): a popped entry
+  // whose box begins behind the best hit found since it was pushed is dropped without fetching its node -- BVH.cpp:41
+  // ("if (near > intersection->t) continue"); a 128-byte node line and ~70 vector instructions per culled entry
+  __shared__ unsigned short stack_tn[4][LT_STACK4_LDS][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 3, q = lane >> 2;
   const bool dbg_times = COUNT || (flags & LT_TRACE_DEBUG_TIMES);
@@ -388,6 +392,25 @@ __global__ __launch_bounds__(256) void k_trace4(
     if (s >= LT_STACK4_LDS) v = spill[s - LT_STACK4_LDS];
     return v;
   };
+  unsigned n_culled = 0;
+  // next reference to visit: the top of the stack, skipping entries that lie behind the best hit by now (spilled entries
+  // carry no distance and are never culled).  sp, best_t are uniform within a quad: all four lanes take the same trips.
+  auto pop_next = [&]() {
+    int r = LT_DONE;
+    while (sp > 0) {
+      --sp;
+#ifndef LT_TRACE_NO_CULL
+      const float tnp = sp < LT_STACK4_LDS ? __uint_as_float((unsigned)stack_tn[wave][sp][q] << 16) : 0.f;
+      if (tnp > best_t) {
+        if (COUNT && j == 0) ++n_culled;
+        continue;
+      }
+#endif
+      r = pop(sp);
+      break;
+    }
+    return r;
+  };
 
   // ONE loop whose trips are steps of either kind ("if-if" traversal): a wave needs max-over-its-quads trips.  The
   // nested form (inner loop over nodes, leaf step outside) makes a quad that has reached a leaf wait for every other
@@ -413,12 +436,7 @@ __global__ __launch_bounds__(256) void k_trace4(
       const unsigned long long hm = __ballot(hit != 0);
       const int nh = __popc((unsigned)(hm >> (lane & ~3)) & 15u);
       if (nh == 0) {
-        if (sp > 0) {
-          --sp;
-          cur = pop(sp);
-        } else {
-          cur = LT_DONE;
-        }
+        cur = pop_next();
       } else {
         // nearest child -> next node (OR-reduce the single rank-0 reference over the quad)
         int nxt = (hit && rank == 0) ? ref : 0;
@@ -428,6 +446,7 @@ __global__ __launch_bounds__(256) void k_trace4(
           const int slot = sp + (nh - 1 - rank);
           if (slot < LT_STACK4_LDS) {
             stack[wave][slot][q] = ref;
+            stack_tn[wave][slot][q] = (unsigned short)(__float_as_uint(tn) >> 16);
           } else {
             spill[slot - LT_STACK4_LDS] = ref;
             if (COUNT) ++n_ovf;
@@ -461,12 +480,7 @@ __global__ __launch_bounds__(256) void k_trace4(
         best_t = t;
         best_face = f;
       }
-      if (sp > 0) {
-        --sp;
-        cur = pop(sp);
-      } else {
-        cur = LT_DONE;
-      }
+      cur = pop_next();
     }
   }
   handed_over = cur != LT_DONE;  // left by the step cap: cur is the node / leaf reference still to be visited
@@ -500,19 +514,21 @@ __global__ __launch_bounds__(256) void k_trace4(
                     endrem, tri_out, flags);
   }
   if (COUNT) {
-    unsigned long long vn = n_nodes, vt = n_tris, vh = (active && hit && j == 0) ? 1u : 0u, vo = n_ovf;
+    unsigned long long vn = n_nodes, vt = n_tris, vh = (active && hit && j == 0) ? 1u : 0u, vo = n_ovf, vc = n_culled;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       vn += __shfl_xor(vn, o, 64);
       vt += __shfl_xor(vt, o, 64);
       vh += __shfl_xor(vh, o, 64);
       vo += __shfl_xor(vo, o, 64);
+      vc += __shfl_xor(vc, o, 64);
     }
     if (lane == 0) {
       atomicAdd(&counters[0], vn);
       atomicAdd(&counters[1], vt);
       atomicAdd(&counters[2], vh);
       atomicAdd(&counters[3], vo);
+      atomicAdd(&counters[4], vc);  // stack entries dropped at pop (behind the best hit)
     }
   }
   if (dbg_times && lane == 0) {  // debug (tools/wave_times.py --quad): start / duration at 100 MHz, steps of quad 0
@@ -629,9 +645,10 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
   const bool timed = stats != nullptr;
   const bool count = (flags & LT_TRACE_COUNT) != 0;
   s->stats.n_rays = W * H;
+  const bool binary_path_used = lt_binary_path();
   if (W > 0) {
     LT_CHECK(lt_scene_reserve_rays(s, W * H));
-    if (count) LT_HIP(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
+    if (count) LT_HIP(hipMemsetAsync(s->counters, 0, 5 * sizeof(unsigned long long), stream));
     const bool binary_path = lt_binary_path();
     if (timed) LT_HIP(hipEventRecord(s->ev[7], stream));
     if (binary_path) {
@@ -685,12 +702,13 @@ int lt_trace_launch(lt_scene* s, const float* rays, const float* origin, int n_r
     LT_HIP(hipStreamSynchronize(stream));
     if (timed && W > 0) LT_HIP(hipEventElapsedTime(&s->stats.ms_trace, s->ev[7], s->ev[8]));
     if (count && W > 0) {
-      unsigned long long c[4];
+      unsigned long long c[5];
       LT_HIP(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
       s->stats.nodes_visited = c[0];
       s->stats.tris_tested = c[1];
       s->stats.n_hits = (int)c[2];
       s->stats.stack_overflows = c[3];
+      s->stats.entries_culled = binary_path_used ? 0 : c[4];
     }
     if (stats) *stats = s->stats;
   }

@@ -31,12 +31,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #define LT_PI_D 3.14159265358979323846
 #ifndef LT_TSDF_WAVES_ATTR
 #define LT_TSDF_WAVES_ATTR
 #endif
 #define LT_TSDF_DBG_WAVES (1 << 18)  // debug stamps: 65 536 workgroups (the default volume has 62 500 chunks)
+#define LT_ZW_EMPTY 0x00007FFFu      // col_zw of a clean column: lo = 0x7fff, hi = 0 (z < 2^15, lt_tsdf_create)
 
 __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, float* __restrict__ weight,
                                                    float* __restrict__ color, float* __restrict__ rem, size_t n) {
@@ -165,7 +167,7 @@ __device__ __forceinline__ int tsdf_voxel(
     float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
-    unsigned epoch, bool fresh, const col_plain& C, int z_plain, const float2* __restrict__ dct) {
+    unsigned epoch, bool fresh, const col_plain& C, int z_plain, const float2* __restrict__ dct, int want_py = -1) {
   int px = -2;
   float rho2, pt_z;
   if (C.plain) {
@@ -210,6 +212,9 @@ __device__ __forceinline__ int tsdf_voxel(
   int py = (int)floorf(proj_y);
   py = min(im_h - 1, py);
   py = max(0, py);
+  // (the pixel-centric integrate, k_tsdf_integrate_pix: a voxel is evaluated by the visitor of ITS OWN pixel only -- the
+  // conservative candidate sets of neighbouring rows overlap, and the update is not idempotent)
+  if (want_py >= 0 && py != want_py) return 0;
   const float2 dc = dct[px * im_h + py];  // (depth_im, color_im)[py * im_w + px], transposed copy (lt_tsdf::dct)
   const float new_rem = rem_im[py * im_w + px];  // (issued with it: one round trip, not two)
   const float depth_value = dc.x;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
                                                          float* __restrict__ color, float* __restrict__ rem,
                                                          int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
                                                          unsigned epoch, unsigned long long* __restrict__ sign_bits,
-                                                         const unsigned* __restrict__ col_zw) {
+                                                         unsigned* __restrict__ col_zw) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_chunks = (n_cols + 63) / 64;
   const int words_z = (dim_z + 63) / 64;
@@ -515,8 +520,10 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
     const int c = chunk * 64 + lane;
     const bool dirty = c < n_cols && col_epoch[c] == epoch;
     const unsigned zw = dirty ? col_zw[c] : 0u;
-    if (dirty)
+    if (dirty) {
       for (int k = 0; k < words_z; ++k) sign_bits[(size_t)c * words_z + k] = 0ull;
+      col_zw[c] = LT_ZW_EMPTY;  // (a clean column holds the empty range: k_tsdf_integrate_pix merges into it atomically)
+    }
     unsigned long long m = __ballot(dirty);
     while (m) {
       const int bit = nth_set_bit(m, grp);
@@ -535,11 +542,290 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
   }
 }
 
+// =========================================================================================================================
+// The pixel-centric integrate of a FRESH volume (the reference builds a new TSDFVolume per output scan and, by default,
+// fuses ONE observation into it: laserscan.py:886-899, config `number_of_scans: 1`).
+//
+// k_tsdf_integrate_cols asks, for every voxel inside the field of view of every live column (48 M on the default volume),
+// whether its pixel's depth puts it into the truncation band; what is finally written is 0.8 M voxels.  On a fresh volume the
+// class-aware update (fusion_lidar.py:177-213) writes a voxel only if its pixel carries a depth D != 0 and
+//     the voxel lies in the band behind the surface,  D < depth <= D + trunc_margin                 (dist < 0 = dist_old), or
+//     the pixel's colour is 0, the fresh volume's own ("same class"), and depth <= D + trunc_margin (anywhere in front).
+// So the work can be driven by the 131 072 PIXELS instead: the voxel columns (x, y) that project into image column px --
+// a property of the volume's geometry and the image width alone -- are kept sorted by their horizontal distance rho (the
+// WEDGE TABLE, built once per volume and image width: k_wd_keys -> radix sort of lt_build.hip -> k_wd_finish); the visitor of
+// pixel (row, px) finds, by two binary searches, the columns whose rho can hold a voxel of that row at a depth in the band
+// [rho = depth cos(pitch)], and for each of them the short z interval (row's pitch range x band's depth range, both with
+// margins far above the float error of the reference's expressions).  Every voxel of that SUPERSET runs the reference's own
+// expressions (tsdf_voxel), which decide -- and which evaluate a voxel only for the visitor of its own exact row (want_py):
+// neighbouring rows' supersets overlap and the update must happen exactly once.  Lanes own pixels (a wave = 64 consecutive
+// rows of one image column: they walk the same wedge); colour-0 pixels, whose candidates are the whole ray, are worked off by
+// the whole wave, columns across the lanes.  Columns whose voxels the reference's float index arithmetic can misplace
+// (y = dim_y - 1 beyond 2^24 voxels, col_plain) are not in the table: k_tsdf_integrate_quirk evaluates them voxel by voxel.
+// Bit-identical to the column walk and to the one-thread-per-voxel restatement (tests/test_tsdf_gpu.py).
+struct wd_geom {
+  int dim_x, dim_y, dim_z;
+  float ox, oy, oz, vs;
+  int im_w, rho_bits;
+  float qscale;
+};
+#define LT_WD_QUIRK_KEY 0x3FFFFFFFu
+
+__global__ __launch_bounds__(256) void k_wd_keys(wd_geom G, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                 int* __restrict__ wd_px, int* __restrict__ n_quirk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= G.dim_x * G.dim_y) return;
+  const int x = c / G.dim_y, y = c - x * G.dim_y;
+  const float pt_x = __fmaf_rn((float)x, G.vs, G.ox), pt_y = __fmaf_rn((float)y, G.vs, G.oy);
+  const float yaw = -atan2f(pt_y, pt_x);  // the very expressions of the reference kernel (:132-141), as k_tsdf_columns
+  float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
+  proj_x *= (float)G.im_w;
+  int px = (int)floorf(proj_x);
+  px = min(G.im_w - 1, px);
+  px = max(0, px);
+  wd_px[c] = px;
+  // every voxel index of the column decomposes, by the reference's float division (:95-98), to this column's x?
+  const float dyz = (float)(G.dim_y * G.dim_z);
+  const int i0 = c * G.dim_z, i1 = c * G.dim_z + G.dim_z - 1;
+  const bool plain = floorf(((float)i0) / dyz) == (float)x && floorf(((float)i1) / dyz) == (float)x;
+  const bool quirk = !plain || y == G.dim_y - 1;
+  const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
+  const unsigned qmax = (1u << G.rho_bits) - 2u;  // (all-ones is left to LT_WD_QUIRK_KEY)
+  const unsigned q = (unsigned)fminf(rho * G.qscale, (float)qmax);
+  keys[c] = quirk ? LT_WD_QUIRK_KEY : (((unsigned)px << G.rho_bits) | q);
+  vals[c] = (uint32_t)c;
+  if (quirk) atomicAdd(n_quirk, 1);
+}
+
+// sorted (key, column) -> table entries (column, rho^2 bits; column -1 for the quirk tail), the rho quantum of every entry
+// (what the binary searches compare), the first entry of every image column's wedge
+__global__ __launch_bounds__(256) void k_wd_finish(wd_geom G, const uint32_t* __restrict__ keys,
+                                                   const uint32_t* __restrict__ vals, int n, int2* __restrict__ ent,
+                                                   uint32_t* __restrict__ wkey, int* __restrict__ wd_start) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p > n) return;
+  auto bin = [&](uint32_t k) { return (int)min(k >> G.rho_bits, (uint32_t)G.im_w); };
+  const int lo = p == 0 ? 0 : bin(keys[p - 1]) + 1;
+  const int hi = p == n ? G.im_w : bin(keys[p]);
+  for (int b = lo; b <= hi; ++b) wd_start[b] = p;
+  if (p < n) {
+    const uint32_t k = keys[p];
+    const int c = (int)vals[p];
+    const int x = c / G.dim_y, y = c - x * G.dim_y;
+    const float pt_x = __fmaf_rn((float)x, G.vs, G.ox), pt_y = __fmaf_rn((float)y, G.vs, G.oy);
+    ent[p] = make_int2(k == LT_WD_QUIRK_KEY ? -1 : c, __float_as_int(__fmaf_rn(pt_y, pt_y, pt_x * pt_x)));
+    wkey[p] = k == LT_WD_QUIRK_KEY ? 0xFFFFFFFFu : (k & ((1u << G.rho_bits) - 1u));
+  }
+}
+
+// merge z into the written range of column c (lo | hi << 16), stamp the column; any number of concurrent writers
+__device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, unsigned* __restrict__ col_epoch,
+                                                 unsigned epoch, int c, int z) {
+  unsigned old = col_zw[c];
+  for (;;) {
+    const unsigned lo = min(old & 0xFFFFu, (unsigned)z), hi = max(old >> 16, (unsigned)z);
+    const unsigned want = lo | (hi << 16);
+    if (want == old) break;
+    const unsigned seen = atomicCAS(&col_zw[c], old, want);
+    if (seen == old) break;
+    old = seen;
+  }
+  col_epoch[c] = epoch;
+}
+
+struct pix_rows { const float4* tab; };  // per image row: (tan_lo, tan_hi, cos_min, cos_max) of its pitch range, margins in
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, float inv_vs, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up,
+    float fov_down, float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im,
+    const float* __restrict__ depth_im, const float* __restrict__ rem_im, const int* __restrict__ wd_px,
+    unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
+    unsigned* __restrict__ col_zw, const float2* __restrict__ dct, const float4* __restrict__ rowtab,
+    const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
+    float qscale) {
+  __shared__ int q_col[4][128], q_z[4][128], q_px[4][128], q_r[4][128];
+  __shared__ float q_rho2[4][128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  int qn = 0;  // (wave-uniform)
+  auto flush = [&](int n) {  // exact evaluation + update of the queue's last n (<= 64) candidates, one per lane
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      const int e = qn - n + lane;
+      const int col = q_col[wv][e], z = q_z[wv][e];
+      col_plain Cq;
+      Cq.plain = true; Cq.px = q_px[wv][e]; Cq.rho2 = q_rho2[wv][e];
+      const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
+                                         vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight,
+                                         fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, wd_px,
+                                         col_epoch, epoch, true, Cq, z, dct, q_r[wv][e]);
+      if (code) {
+        unsigned long long* w = sign_bits + (size_t)col * words_z + (z >> 6);
+        const unsigned long long bit = 1ull << (z & 63);
+        if (code == 2) atomicOr(w, bit);
+        else atomicAnd(w, ~bit);
+        col_mark_written(col_zw, col_epoch, epoch, col, z);
+      }
+    }
+    qn -= n;
+    __builtin_amdgcn_wave_barrier();
+  };
+  // z interval [z, zend] of table entry (c, rho2) for a row (tan_lo, tan_hi) and depths in [d_lo, d_hi] (d_lo <= 0: none)
+  auto z_range = [&](int2 e, float tan_lo, float tan_hi, float d_lo, float d_hi, int& z, int& zend) {
+    z = 1; zend = 0;  // empty
+    if (e.x < 0) return;
+    const float rho2 = __int_as_float(e.y), rho = sqrtf(rho2);
+    const float hi2 = d_hi * d_hi - rho2;
+    if (!(hi2 >= 0.f)) return;  // the whole column lies beyond the band (false also for NaN)
+    const float zmax = sqrtf(hi2) * 1.000001f + 1e-6f;
+    const float lo2 = d_lo > 0.f ? d_lo * d_lo - rho2 : -1.f;
+    const float zmin = lo2 > 0.f ? fmaxf(sqrtf(lo2) * 0.999999f - 1e-6f, 0.f) : 0.f;
+    const float za = rho * tan_lo, zb = rho * tan_hi;  // pt_z of the row in this column
+    float lo, hi;
+    if (za >= 0.f) { lo = fmaxf(za, zmin); hi = fminf(zb, zmax); }
+    else if (zb <= 0.f) { lo = fmaxf(za, -zmax); hi = fminf(zb, -zmin); }
+    else { lo = fmaxf(za, -zmax); hi = fminf(zb, zmax); }
+    if (!(lo <= hi)) return;
+    const float fz0 = ceilf((lo - oz) * inv_vs - 0.02f), fz1 = floorf((hi - oz) * inv_vs + 0.02f);
+    z = (int)fmaxf(fz0, 0.f);
+    zend = (int)fminf(fz1, (float)(vol_dim_z - 1));
+  };
+  // first table index in [a, b) whose rho quantum is >= q (b if none): the wedges are sorted by it
+  auto lower = [&](int a, int b, uint32_t q) {
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (wd_key[m] < q) a = m + 1;
+      else b = m;
+    }
+    return a;
+  };
+  const uint32_t qmax = (1u << rho_bits) - 2u;
+  const int n_pix = im_h * im_w;
+  for (int p0 = (blockIdx.x * 4 + wv) * 64; p0 < n_pix; p0 += gridDim.x * 256) {  // (wave-uniform)
+    const int p = p0 + lane;  // pixel (row r, column px) at dct[px * im_h + r]
+    const bool in = p < n_pix;
+    const int px = in ? p / im_h : 0, r = in ? p - px * im_h : 0;
+    const float2 dc = in ? dct[p] : make_float2(0.f, 1.f);
+    const float D = dc.x;
+    const float4 row = rowtab[r];  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
+    const bool row_ok = row.x <= row.y;
+    const bool finite = D == D && fabsf(D) < 1e30f;
+    // the reference leaves at depth_value == 0; with another colour than 0 only the band is written (and nothing at all
+    // through a NaN / infinite depth: dist = 1); colour 0: everything in front of D + trunc (all of it for NaN / inf)
+    const bool zero_class = in && row_ok && D != 0.f && dc.y == 0.0f;
+    const bool normal = in && row_ok && D != 0.f && dc.y != 0.0f && finite;
+    const float eps = __fmaf_rn(4e-6f, fabsf(D) + trunc_margin, 1e-6f);
+    const float d_hi = finite ? D + trunc_margin + eps : 3e38f;
+    const float d_lo = D - eps;
+    const int s0 = wd_start[px], s1 = wd_start[px + 1];
+    // ---- lane = pixel: the columns between the two binary searches, one after the other ------------------------------
+    int k = 0, kend = 0, z = 1, zend = 0, ccol = 0;
+    float crho2 = 0.f;
+    if (normal && d_hi > 0.f) {
+      const float rho1 = fmaxf(d_lo, 0.f) * row.z * 0.999999f, rho2 = d_hi * row.w * 1.000001f;
+      const float f1 = floorf(rho1 * qscale) - 2.f, f2 = floorf(rho2 * qscale) + 2.f;
+      const uint32_t q1 = (uint32_t)fminf(fmaxf(f1, 0.f), (float)qmax), q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
+      k = lower(s0, s1, q1);
+      kend = lower(k, s1, q2 + 1u);
+    }
+    while (__ballot(k < kend || z <= zend) != 0ull) {
+      if (z > zend && k < kend) {  // next column of this lane's pixel
+        const int2 e = wd_ent[k++];
+        z_range(e, row.x, row.y, d_lo, d_hi, z, zend);
+        ccol = e.x; crho2 = __int_as_float(e.y);
+      }
+      const bool cand = z <= zend;
+      const unsigned long long cw = __ballot(cand);
+      if (cw) {  // (wave-uniform)
+        if (cand) {
+          const int e = qn + __popcll(cw & lanes_below);
+          q_col[wv][e] = ccol; q_z[wv][e] = z; q_px[wv][e] = px; q_rho2[wv][e] = crho2; q_r[wv][e] = r;
+          ++z;
+        }
+        qn += __popcll(cw);
+        if (qn >= 64) flush(64);
+      }
+    }
+    // ---- colour-0 pixels: the whole ray up to the band; the wave works them off one by one, columns across the lanes ---
+    unsigned long long zm = __ballot(zero_class);
+    while (zm) {
+      const int src = __ffsll((long long)zm) - 1;
+      zm &= zm - 1;
+      const int zpx = __shfl(px, src, 64), zr = __shfl(r, src, 64);
+      const float zd_hi = __shfl(d_hi, src, 64);
+      const float t_lo = __shfl(row.x, src, 64), t_hi = __shfl(row.y, src, 64), c_max = __shfl(row.w, src, 64);
+      const int zs0 = __shfl(s0, src, 64), zs1 = __shfl(s1, src, 64);
+      int ke = zs1;
+      if (zd_hi < 3e38f) {  // (wave-uniform)
+        const float f2 = floorf(zd_hi * c_max * 1.000001f * qscale) + 2.f;
+        const uint32_t q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
+        ke = zd_hi > 0.f ? lower(zs0, zs1, q2 + 1u) : zs0;
+      }
+      int kk = zs0 + lane;
+      z = 1; zend = 0;
+      while (__ballot(kk < ke || z <= zend) != 0ull) {
+        if (z > zend && kk < ke) {
+          const int2 e = wd_ent[kk];
+          kk += 64;
+          z_range(e, t_lo, t_hi, 0.f, zd_hi, z, zend);
+          ccol = e.x; crho2 = __int_as_float(e.y);
+        }
+        const bool cand = z <= zend;
+        const unsigned long long cw = __ballot(cand);
+        if (cw) {
+          if (cand) {
+            const int e = qn + __popcll(cw & lanes_below);
+            q_col[wv][e] = ccol; q_z[wv][e] = z; q_px[wv][e] = zpx; q_rho2[wv][e] = crho2; q_r[wv][e] = zr;
+            ++z;
+          }
+          qn += __popcll(cw);
+          if (qn >= 64) flush(64);
+        }
+      }
+    }
+  }
+  if (qn > 0) flush(qn);
+}
+
+// the columns that are not in the wedge table (k_wd_keys: quirk), one thread per voxel, by the reference's own
+// decomposition of the voxel index (tsdf_voxel's general path; a decomposed (x, y) inside the table finds its image
+// column in wd_px, one outside -- the "(x + 1, -1)" voxels -- computes it)
+template <bool MERGE>
+__global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
+    const float* __restrict__ rem_im, const int* __restrict__ wd_px, unsigned* __restrict__ col_epoch, unsigned epoch,
+    unsigned long long* __restrict__ sign_bits, int words_z, unsigned* __restrict__ col_zw,
+    const float2* __restrict__ dct, const uint32_t* __restrict__ qcols, int n_q) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_q * vol_dim_z) return;
+  const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
+  col_plain C;
+  C.plain = false; C.px = -2; C.rho2 = 0.f;
+  const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
+                                     vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
+                                     fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, wd_px, col_epoch, epoch,
+                                     true, C, z, dct);
+  if (code) {
+    unsigned long long* w = sign_bits + (size_t)col * words_z + (z >> 6);
+    const unsigned long long bit = 1ull << (z & 63);
+    if (code == 2) atomicOr(w, bit);
+    else atomicAnd(w, ~bit);
+    col_mark_written(col_zw, col_epoch, epoch, col, z);
+  }
+}
+
 extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct};
+  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
+                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -568,9 +854,11 @@ static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
   LT_HIP(hipMemsetAsync(t->col_epoch, 0, (size_t)t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
   LT_HIP(hipMemsetAsync(t->bits, 0, (size_t)t->dim[0] * t->dim[1] * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long),
                         stream));
+  LT_HIP(hipMemsetD32Async((hipDeviceptr_t)t->col_zw, (int)LT_ZW_EMPTY, (size_t)t->dim[0] * t->dim[1], stream));
   LT_HIP(hipGetLastError());
   t->epoch = 1;
   t->all_dirty = 0;
+  t->n_obs = 0;
   return LT_OK;
 }
 
@@ -588,6 +876,7 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
                      t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits, t->col_zw);
   LT_HIP(hipGetLastError());
   t->epoch += 1;  // every stamp is stale now: nothing to clear
+  t->n_obs = 0;
   return LT_OK;
 }
 
@@ -656,6 +945,151 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   return LT_OK;
 }
 
+// sort kernels of lt_build.hip
+void lt_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, int n, int key_bits, hipStream_t stream,
+                   int* out_buffer);
+
+// the wedge table of (volume geometry, image width): built on first use, once (a few hundred microseconds + temporary
+// sort buffers); rebuilt when an integrate comes with another image width
+static int tsdf_wedge_build(lt_tsdf* t, int im_w, int rho_bits, hipStream_t stream) {
+  const int n = t->dim[0] * t->dim[1];
+  if (!t->wd_px) {
+    LT_HIP(hipMalloc((void**)&t->wd_px, (size_t)n * sizeof(int)));
+    LT_HIP(hipMalloc((void**)&t->wd_ent, (size_t)n * sizeof(int2)));
+    LT_HIP(hipMalloc((void**)&t->wd_key, (size_t)n * sizeof(unsigned)));
+  }
+  if (t->wd_start) { LT_HIP(hipStreamSynchronize(stream)); (void)hipFree(t->wd_start); t->wd_start = nullptr; }
+  if (t->wd_qcols) { (void)hipFree(t->wd_qcols); t->wd_qcols = nullptr; }
+  t->wd_w = 0;
+  LT_HIP(hipMalloc((void**)&t->wd_start, (size_t)(im_w + 2) * sizeof(int)));
+  // largest horizontal distance of a voxel column from the sensor (the world origin: the kernel's pt_x, pt_y)
+  double rmax = 0.0;
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy) {
+      const double x = (double)t->origin[0] + (ix ? t->dim[0] : 0) * (double)t->voxel_size;
+      const double y = (double)t->origin[1] + (iy ? t->dim[1] : 0) * (double)t->voxel_size;
+      rmax = fmax(rmax, sqrt(x * x + y * y));
+    }
+  wd_geom G;
+  G.dim_x = t->dim[0]; G.dim_y = t->dim[1]; G.dim_z = t->dim[2];
+  G.ox = t->origin[0]; G.oy = t->origin[1]; G.oz = t->origin[2]; G.vs = t->voxel_size;
+  G.im_w = im_w; G.rho_bits = rho_bits;
+  G.qscale = (float)(((double)((1u << rho_bits) - 2u)) / fmax(rmax * 1.001, 1e-6));
+  uint32_t* keys[2] = {nullptr, nullptr};
+  uint32_t* vals[2] = {nullptr, nullptr};
+  uint32_t* hist = nullptr;
+  int* n_quirk = nullptr;
+  const int nb = (n + LT_SORT_TILE - 1) / LT_SORT_TILE;
+  int rc = LT_OK;
+  auto release = [&]() {
+    for (int k = 0; k < 2; ++k) { if (keys[k]) (void)hipFree(keys[k]); if (vals[k]) (void)hipFree(vals[k]); }
+    if (hist) (void)hipFree(hist);
+    if (n_quirk) (void)hipFree(n_quirk);
+  };
+  for (int k = 0; k < 2 && rc == LT_OK; ++k)
+    if (hipMalloc((void**)&keys[k], (size_t)n * 4) != hipSuccess || hipMalloc((void**)&vals[k], (size_t)n * 4) != hipSuccess)
+      rc = LT_ERR_NO_MEMORY;
+  if (rc == LT_OK && (hipMalloc((void**)&hist, ((size_t)1024 * nb + 1024) * 4) != hipSuccess ||
+                      hipMalloc((void**)&n_quirk, sizeof(int)) != hipSuccess))
+    rc = LT_ERR_NO_MEMORY;
+  if (rc != LT_OK) {
+    (void)hipGetLastError();
+    release();
+    lt_set_error("lt_tsdf_integrate_dev: hipMalloc of the wedge-table sort buffers failed");
+    return rc;
+  }
+  int nq = 0, buf = 0;
+  bool ok = hipMemsetAsync(n_quirk, 0, sizeof(int), stream) == hipSuccess;
+  hipLaunchKernelGGL(k_wd_keys, dim3((n + 255) / 256), dim3(256), 0, stream, G, keys[0], vals[0], t->wd_px, n_quirk);
+  lt_sort_pairs(keys, vals, hist, n, 30, stream, &buf);
+  hipLaunchKernelGGL(k_wd_finish, dim3((n + 1 + 255) / 256), dim3(256), 0, stream, G, keys[buf], vals[buf], n, t->wd_ent,
+                     t->wd_key, t->wd_start);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess &&
+       hipMemcpy(&nq, n_quirk, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok && nq > 0) {  // the quirk columns are the tail of the sorted order
+    ok = hipMalloc((void**)&t->wd_qcols, (size_t)nq * 4) == hipSuccess &&
+         hipMemcpy(t->wd_qcols, vals[buf] + (n - nq), (size_t)nq * 4, hipMemcpyDeviceToDevice) == hipSuccess;
+  }
+  release();
+  if (!ok) {
+    lt_set_error("lt_tsdf_integrate_dev: building the wedge table failed: %s", hipGetErrorString(hipGetLastError()));
+    return LT_ERR_HIP;
+  }
+  t->wd_n_quirk = nq;
+  t->wd_rho_bits = rho_bits;
+  t->wd_qscale = G.qscale;
+  t->wd_w = im_w;
+  return LT_OK;
+}
+
+// per image row r: the pitch range whose voxels the reference's projection (:143-146) puts into row r, cut to the field of
+// view, +- 3e-5 rad (asinf, the float row arithmetic: < 1e-6) -> (tan_lo, tan_hi, cos_min, cos_max), rounded outwards
+static int tsdf_rowtab(lt_tsdf* t, int im_h, float fu, float fd, hipStream_t stream) {
+  std::vector<float4> tab((size_t)im_h);
+  const double fov = (double)(fabsf(fu) + fabsf(fd)), afd = (double)fabsf(fd), m = 3e-5;
+  for (int r = 0; r < im_h; ++r) {
+    double hi = r == 0 ? 1.5 : fov * (1.0 - (double)r / im_h) - afd;             // (row 0 also takes proj_y < 0: clamped)
+    double lo = r == im_h - 1 ? -1.5 : fov * (1.0 - (double)(r + 1) / im_h) - afd;  // (the last row proj_y >= im_h)
+    hi = fmin(hi, (double)fu) + m;   // pitch > fov_up and pitch < fov_down leave the kernel (:128)
+    lo = fmax(lo, (double)fd) - m;
+    if (lo > hi) { tab[r] = make_float4(1.f, -1.f, 0.f, 0.f); continue; }
+    const double ca = cos(lo), cb = cos(hi);
+    const double cmax = (lo <= 0.0 && hi >= 0.0) ? 1.0 : fmax(ca, cb), cmin = fmax(fmin(ca, cb), 0.0);
+    tab[r] = make_float4(nextafterf((float)tan(lo), -INFINITY), nextafterf((float)tan(hi), INFINITY),
+                         nextafterf((float)cmin, 0.f), nextafterf((float)cmax, 2.f));
+  }
+  if (im_h > t->rowtab_h) {
+    if (t->rowtab) { LT_HIP(hipStreamSynchronize(stream)); (void)hipFree(t->rowtab); t->rowtab = nullptr; }
+    LT_HIP(hipMalloc((void**)&t->rowtab, (size_t)im_h * sizeof(float4)));
+    t->rowtab_h = im_h;
+  }
+  // (a blocking copy from pageable memory: the vector may go out of scope when this returns)
+  LT_HIP(hipMemcpyAsync(t->rowtab, tab.data(), (size_t)im_h * sizeof(float4), hipMemcpyHostToDevice, stream));
+  LT_HIP(hipStreamSynchronize(stream));
+  return LT_OK;
+}
+
+static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im, int im_h,
+                              int im_w, float obs_weight, float fu, float fd, int rho_bits, hipStream_t stream) {
+  if (t->wd_w != im_w || t->wd_rho_bits != rho_bits) LT_CHECK(tsdf_wedge_build(t, im_w, rho_bits, stream));
+  // the row table depends on (im_h, fov): both fixed for a sensor model; keyed by im_h and re-made when it changes
+  if (t->rowtab_for_h != im_h || !t->rowtab) {
+    t->rowtab_for_h = 0;
+    LT_CHECK(tsdf_rowtab(t, im_h, fu, fd, stream));
+    t->rowtab_for_h = im_h;
+  }
+  if (im_w > t->cap_w) {
+    if (t->colmax) { LT_HIP(hipDeviceSynchronize()); (void)hipFree(t->colmax); t->colmax = nullptr; }
+    LT_HIP(hipMalloc((void**)&t->colmax, (size_t)im_w * sizeof(float)));
+    t->cap_w = im_w;
+  }
+  if ((size_t)im_w * im_h > t->cap_dct) {
+    if (t->dct) { LT_HIP(hipDeviceSynchronize()); (void)hipFree(t->dct); t->dct = nullptr; t->cap_dct = 0; }
+    LT_HIP(hipMalloc((void**)&t->dct, (size_t)im_w * im_h * sizeof(float2)));
+    t->cap_dct = (size_t)im_w * im_h;
+  }
+  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->colmax,
+                     t->dct);
+  const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
+  const int words_z = (t->dim[2] + 63) / 64;
+  const int n_pix = im_h * im_w;
+  const unsigned nb = (unsigned)((n_pix + 255) / 256);
+  hipLaunchKernelGGL(k_tsdf_integrate_pix<true>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem, t->dim[0],
+                     t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, 1.0f / t->voxel_size, im_h,
+                     im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->wd_px, t->col_epoch,
+                     t->epoch, t->bits, words_z, t->col_zw, t->dct, t->rowtab, t->wd_start, t->wd_ent, t->wd_key,
+                     t->wd_rho_bits, t->wd_qscale);
+  if (t->wd_n_quirk > 0) {
+    const long long nv = (long long)t->wd_n_quirk * t->dim[2];
+    hipLaunchKernelGGL(k_tsdf_integrate_quirk<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->tsdf, t->weight,
+                       t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
+                       t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im,
+                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->wd_qcols, t->wd_n_quirk);
+  }
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
 extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im,
                                      int im_h, int im_w, float obs_weight, unsigned flags, void* stream_) {
   if (!t || !color_im || !depth_im || !rem_im || im_h <= 0 || im_w <= 0) {
@@ -668,6 +1102,15 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   // degrees as float32 (:278-280)
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
   const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
+  // ---- a fresh volume, the class-aware update: driven by the pixels (k_tsdf_integrate_pix) --------------------------------
+  static const bool pix_off = []() { const char* e = getenv("LIDARHIP_TSDF_PIX"); return e && strcmp(e, "0") == 0; }();
+  const bool tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
+  int px_bits = 1;
+  while ((1 << px_bits) < im_w) ++px_bits;
+  const bool use_pix = !pix_off && (flags & LT_TSDF_MERGE) && t->n_obs == 0 && !t->all_dirty && tan_ok && 30 - px_bits >= 12 &&
+                       fabsf(fu) + fabsf(fd) > 0.f;
+  t->n_obs += 1;
+  if (use_pix) return tsdf_integrate_pix(t, color_im, depth_im, rem_im, im_h, im_w, obs_weight, fu, fd, 30 - px_bits, stream);
   if (im_w > t->cap_w) {
     if (t->colmax) {
       LT_HIP(hipDeviceSynchronize());
