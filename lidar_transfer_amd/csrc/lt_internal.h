@@ -114,7 +114,7 @@ struct lt_tsdf {
   // reset wrote into it -- col_epoch[c] == epoch.  Reset re-initialises dirty columns only and then bumps `epoch`
   // (nothing is cleared); marching cubes skips clean columns (their tsdf is the initial 1 everywhere).
   unsigned* col_epoch;  // [dim_x * dim_y]
-  unsigned* col_zw;     // [dim_x * dim_y] z range written in the column since the last reset: lo | hi << 16 (valid when dirty)
+  unsigned* col_zw;     // [2][dim_x * dim_y] z range written in the column since the last reset: 0x7fff - lo, hi + 1 (lt_tsdf.hip)
   unsigned epoch;
   int all_dirty;        // the fields were written without column stamps (lt_tsdf_touch): every column counts as written
   unsigned long long* bits;  // [dim_x * dim_y][ceil(dim_z / 64)] sign bit of every voxel's tsdf (the layout of lt_mc.hip),

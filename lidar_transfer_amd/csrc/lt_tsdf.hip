@@ -38,7 +38,12 @@
 #define LT_TSDF_WAVES_ATTR
 #endif
 #define LT_TSDF_DBG_WAVES (1 << 18)  // debug stamps: 65 536 workgroups (the default volume has 62 500 chunks)
-#define LT_ZW_EMPTY 0x00007FFFu      // col_zw of a clean column: lo = 0x7fff, hi = 0 (z < 2^15, lt_tsdf_create)
+// col_zw: the z range written in a column since the last reset, as TWO words that only ever grow -- [c] = 0x7fff - lo,
+// [n_cols + c] = hi + 1; a clean column holds (0, 0) -- so that any number of writers can merge into it with two
+// non-returning atomicMax (k_tsdf_integrate_pix: a wall's column is visited by dozens of image rows at once; a
+// compare-and-swap loop on one packed word serialised them, 95 us per workgroup)
+#define LT_ZW_LO(a) (0x7FFF - (int)(a))
+#define LT_ZW_HI(b) ((int)(b) - 1)
 
 __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, float* __restrict__ weight,
                                                    float* __restrict__ color, float* __restrict__ rem, size_t n) {
@@ -488,11 +493,11 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
       // reset has to re-initialise); this quarter wave owns the column, no atomics
       if (bit >= 0 && wz_hi >= 0 && gl == 0) {
         if (!fresh) {
-          const unsigned old = col_zw[cc];
-          wz_lo = min(wz_lo, (int)(old & 0xFFFFu));
-          wz_hi = max(wz_hi, (int)(old >> 16));
+          wz_lo = min(wz_lo, LT_ZW_LO(col_zw[cc]));
+          wz_hi = max(wz_hi, LT_ZW_HI(col_zw[n_cols + cc]));
         }
-        col_zw[cc] = (unsigned)wz_lo | ((unsigned)wz_hi << 16);
+        col_zw[cc] = (unsigned)(0x7FFF - wz_lo);
+        col_zw[n_cols + cc] = (unsigned)(wz_hi + 1);
         col_epoch[cc] = epoch;
       }
     }
@@ -519,10 +524,13 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
     const int c = chunk * 64 + lane;
     const bool dirty = c < n_cols && col_epoch[c] == epoch;
-    const unsigned zw = dirty ? col_zw[c] : 0u;
+    unsigned zw = 0x7FFFu;  // (lo | hi << 16; empty)
     if (dirty) {
+      const int hi = LT_ZW_HI(col_zw[n_cols + c]);
+      if (hi >= 0) zw = (unsigned)LT_ZW_LO(col_zw[c]) | ((unsigned)hi << 16);
       for (int k = 0; k < words_z; ++k) sign_bits[(size_t)c * words_z + k] = 0ull;
-      col_zw[c] = LT_ZW_EMPTY;  // (a clean column holds the empty range: k_tsdf_integrate_pix merges into it atomically)
+      col_zw[c] = 0u;  // (a clean column holds the empty range)
+      col_zw[n_cols + c] = 0u;
     }
     unsigned long long m = __ballot(dirty);
     while (m) {
@@ -620,22 +628,24 @@ __global__ __launch_bounds__(256) void k_wd_finish(wd_geom G, const uint32_t* __
 
 // merge z into the written range of column c (lo | hi << 16), stamp the column; any number of concurrent writers
 __device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, unsigned* __restrict__ col_epoch,
-                                                 unsigned epoch, int c, int z) {
-  unsigned old = col_zw[c];
-  for (;;) {
-    const unsigned lo = min(old & 0xFFFFu, (unsigned)z), hi = max(old >> 16, (unsigned)z);
-    const unsigned want = lo | (hi << 16);
-    if (want == old) break;
-    const unsigned seen = atomicCAS(&col_zw[c], old, want);
-    if (seen == old) break;
-    old = seen;
-  }
+                                                 unsigned epoch, int n_cols, int c, int z, int z_last) {
+  atomicMax(&col_zw[c], (unsigned)(0x7FFF - z));       // (results unused: fire and forget)
+  atomicMax(&col_zw[n_cols + c], (unsigned)(z_last + 1));
   col_epoch[c] = epoch;
 }
 
-struct pix_rows { const float4* tab; };  // per image row: (tan_lo, tan_hi, cos_min, cos_max) of its pitch range, margins in
-
-template <bool MERGE>
+// One workgroup = 64 consecutive pixels of the transposed image (rows of one image column: they walk the same wedge), its
+// four waves share the work, which is flattened twice so that no lane waits for a far pixel's long lists:
+//   A  wave 0, lane = pixel: the two binary searches -> the pixel's run of table entries [k0, k0 + n); prefix sum of n
+//   B  per chunk of 512 (pixel, column) PAIRS, two per thread: the pair's z interval (z_range) -> prefix sum of the
+//      interval lengths; then the chunk's VOXELS, one per thread and round: the reference's expressions (tsdf_voxel with
+//      want_py), the sign bit, the column's written range
+// (the first version gave every lane its own pixel from start to end: a pixel at 60 m has 30 columns x 10 voxels, one at
+// 5 m four voxels altogether -- 368 us with two waves per SIMD, most lanes idle; colour-0 pixels, whose run is the wedge up
+// to the band, are simply long runs here)
+#define LT_PIX_CHUNK 512    // pairs per chunk (two per thread)
+#define LT_PIX_STAGE 4096   // rho quanta staged in LDS for the binary searches (a wedge of the default volume: 2000 - 3900)
+template <bool MERGE, bool VCOUNT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
     float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
@@ -645,149 +655,206 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, const float4* __restrict__ rowtab,
     const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
-    float qscale) {
-  __shared__ int q_col[4][128], q_z[4][128], q_px[4][128], q_r[4][128];
-  __shared__ float q_rho2[4][128];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned long long lanes_below = (1ull << lane) - 1ull;
-  int qn = 0;  // (wave-uniform)
-  auto flush = [&](int n) {  // exact evaluation + update of the queue's last n (<= 64) candidates, one per lane
-    __builtin_amdgcn_wave_barrier();
-    if (lane < n) {
-      const int e = qn - n + lane;
-      const int col = q_col[wv][e], z = q_z[wv][e];
-      col_plain Cq;
-      Cq.plain = true; Cq.px = q_px[wv][e]; Cq.rho2 = q_rho2[wv][e];
-      const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
-                                         vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight,
-                                         fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, wd_px,
-                                         col_epoch, epoch, true, Cq, z, dct, q_r[wv][e]);
-      if (code) {
-        unsigned long long* w = sign_bits + (size_t)col * words_z + (z >> 6);
-        const unsigned long long bit = 1ull << (z & 63);
-        if (code == 2) atomicOr(w, bit);
-        else atomicAnd(w, ~bit);
-        col_mark_written(col_zw, col_epoch, epoch, col, z);
-      }
-    }
-    qn -= n;
-    __builtin_amdgcn_wave_barrier();
-  };
-  // z interval [z, zend] of table entry (c, rho2) for a row (tan_lo, tan_hi) and depths in [d_lo, d_hi] (d_lo <= 0: none)
-  auto z_range = [&](int2 e, float tan_lo, float tan_hi, float d_lo, float d_hi, int& z, int& zend) {
-    z = 1; zend = 0;  // empty
-    if (e.x < 0) return;
-    const float rho2 = __int_as_float(e.y), rho = sqrtf(rho2);
-    const float hi2 = d_hi * d_hi - rho2;
-    if (!(hi2 >= 0.f)) return;  // the whole column lies beyond the band (false also for NaN)
-    const float zmax = sqrtf(hi2) * 1.000001f + 1e-6f;
-    const float lo2 = d_lo > 0.f ? d_lo * d_lo - rho2 : -1.f;
-    const float zmin = lo2 > 0.f ? fmaxf(sqrtf(lo2) * 0.999999f - 1e-6f, 0.f) : 0.f;
-    const float za = rho * tan_lo, zb = rho * tan_hi;  // pt_z of the row in this column
-    float lo, hi;
-    if (za >= 0.f) { lo = fmaxf(za, zmin); hi = fminf(zb, zmax); }
-    else if (zb <= 0.f) { lo = fmaxf(za, -zmax); hi = fminf(zb, -zmin); }
-    else { lo = fmaxf(za, -zmax); hi = fminf(zb, zmax); }
-    if (!(lo <= hi)) return;
-    const float fz0 = ceilf((lo - oz) * inv_vs - 0.02f), fz1 = floorf((hi - oz) * inv_vs + 0.02f);
-    z = (int)fmaxf(fz0, 0.f);
-    zend = (int)fminf(fz1, (float)(vol_dim_z - 1));
-  };
-  // first table index in [a, b) whose rho quantum is >= q (b if none): the wedges are sorted by it
+    float qscale, unsigned long long* __restrict__ dbg) {
+  // per pixel of the workgroup
+  __shared__ int p_k0[64], p_pre[65], p_r[64], p_px[64];
+  __shared__ float p_tlo[64], p_thi[64], p_dlo[64], p_dhi[64];
+  // per pair of the chunk (one block: phase A borrows it as the staging area of the wedge's rho quanta)
+  __shared__ int c_buf[LT_PIX_STAGE > 4 * LT_PIX_CHUNK + 1 ? LT_PIX_STAGE : 4 * LT_PIX_CHUNK + 1];
+  int* const c_col = c_buf;
+  int* const c_z0 = c_buf + LT_PIX_CHUNK;
+  int* const c_src = c_buf + 2 * LT_PIX_CHUNK;
+  int* const c_pre = c_buf + 3 * LT_PIX_CHUNK;  // [LT_PIX_CHUNK + 1]
+  __shared__ float c_rho2[LT_PIX_CHUNK];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t qmax = (1u << rho_bits) - 2u;
+  const int n_pix = im_h * im_w;
+  const uint32_t* const skey = (const uint32_t*)c_buf;  // staged quanta of [stage0, stage0 + n_stage)
+  int stage0 = 0, n_stage = 0;
+  // first table index in [a, b) whose rho quantum is >= q (b if none): the wedges are sorted by it.  The 64 pixels of a
+  // workgroup search the SAME wedge(s): 22 dependent global loads per pixel became one coalesced copy into LDS
+  bool staged = false;  // (workgroup-uniform: the whole search range is in LDS)
   auto lower = [&](int a, int b, uint32_t q) {
-    while (a < b) {
-      const int m = (a + b) >> 1;
-      if (wd_key[m] < q) a = m + 1;
-      else b = m;
+    if (staged) {
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (skey[m - stage0] < q) a = m + 1;
+        else b = m;
+      }
+    } else {
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (wd_key[m] < q) a = m + 1;
+        else b = m;
+      }
     }
     return a;
   };
-  const uint32_t qmax = (1u << rho_bits) - 2u;
-  const int n_pix = im_h * im_w;
-  for (int p0 = (blockIdx.x * 4 + wv) * 64; p0 < n_pix; p0 += gridDim.x * 256) {  // (wave-uniform)
-    const int p = p0 + lane;  // pixel (row r, column px) at dct[px * im_h + r]
-    const bool in = p < n_pix;
-    const int px = in ? p / im_h : 0, r = in ? p - px * im_h : 0;
-    const float2 dc = in ? dct[p] : make_float2(0.f, 1.f);
-    const float D = dc.x;
-    const float4 row = rowtab[r];  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
-    const bool row_ok = row.x <= row.y;
-    const bool finite = D == D && fabsf(D) < 1e30f;
-    // the reference leaves at depth_value == 0; with another colour than 0 only the band is written (and nothing at all
-    // through a NaN / infinite depth: dist = 1); colour 0: everything in front of D + trunc (all of it for NaN / inf)
-    const bool zero_class = in && row_ok && D != 0.f && dc.y == 0.0f;
-    const bool normal = in && row_ok && D != 0.f && dc.y != 0.0f && finite;
-    const float eps = __fmaf_rn(4e-6f, fabsf(D) + trunc_margin, 1e-6f);
-    const float d_hi = finite ? D + trunc_margin + eps : 3e38f;
-    const float d_lo = D - eps;
-    const int s0 = wd_start[px], s1 = wd_start[px + 1];
-    // ---- lane = pixel: the columns between the two binary searches, one after the other ------------------------------
-    int k = 0, kend = 0, z = 1, zend = 0, ccol = 0;
-    float crho2 = 0.f;
-    if (normal && d_hi > 0.f) {
-      const float rho1 = fmaxf(d_lo, 0.f) * row.z * 0.999999f, rho2 = d_hi * row.w * 1.000001f;
-      const float f1 = floorf(rho1 * qscale) - 2.f, f2 = floorf(rho2 * qscale) + 2.f;
-      const uint32_t q1 = (uint32_t)fminf(fmaxf(f1, 0.f), (float)qmax), q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
-      k = lower(s0, s1, q1);
-      kend = lower(k, s1, q2 + 1u);
+  for (int p0 = blockIdx.x * 64; p0 < n_pix; p0 += gridDim.x * 64) {  // (workgroup-uniform)
+    const unsigned long long tm0 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;  // (100 MHz; debug)
+    // ---- A: the pixels' runs of table entries ------------------------------------------------------------------------
+    {  // stage the quanta of the wedges these 64 pixels search (one image column when im_h is a multiple of 64)
+      const int px_a = p0 / im_h, px_b = min(p0 + 63, n_pix - 1) / im_h;
+      stage0 = wd_start[px_a];
+      n_stage = wd_start[px_b + 1] - stage0;
+      staged = n_stage <= LT_PIX_STAGE;  // (a longer run of wedges is searched in global memory)
+      if (staged)
+        for (int i = tid; i < n_stage; i += 256) c_buf[i] = (int)wd_key[stage0 + i];
+      __syncthreads();
     }
-    while (__ballot(k < kend || z <= zend) != 0ull) {
-      if (z > zend && k < kend) {  // next column of this lane's pixel
-        const int2 e = wd_ent[k++];
-        z_range(e, row.x, row.y, d_lo, d_hi, z, zend);
-        ccol = e.x; crho2 = __int_as_float(e.y);
-      }
-      const bool cand = z <= zend;
-      const unsigned long long cw = __ballot(cand);
-      if (cw) {  // (wave-uniform)
-        if (cand) {
-          const int e = qn + __popcll(cw & lanes_below);
-          q_col[wv][e] = ccol; q_z[wv][e] = z; q_px[wv][e] = px; q_rho2[wv][e] = crho2; q_r[wv][e] = r;
-          ++z;
+    if (wave == 0) {
+      const int p = p0 + lane;  // pixel (row r, column px) at dct[px * im_h + r]
+      const bool in = p < n_pix;
+      const int px = in ? p / im_h : 0, r = in ? p - px * im_h : 0;
+      const float2 dc = in ? dct[p] : make_float2(0.f, 1.f);
+      const float D = dc.x;
+      const float4 row = rowtab[r];  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
+      const bool row_ok = row.x <= row.y;
+      const bool finite = D == D && fabsf(D) < 1e30f;
+      // the reference leaves at depth_value == 0; with another colour than 0 only the band is written (and nothing at all
+      // through a NaN / infinite depth: dist = 1); colour 0: everything in front of D + trunc (all of it for NaN / inf)
+      const bool zero_class = in && row_ok && D != 0.f && dc.y == 0.0f;
+      const bool normal = in && row_ok && D != 0.f && dc.y != 0.0f && finite;
+      const float eps = __fmaf_rn(4e-6f, fabsf(D) + trunc_margin, 1e-6f);
+      const float d_hi = finite ? D + trunc_margin + eps : 3e38f;
+      const float d_lo = zero_class ? 0.f : D - eps;
+      const int s0 = wd_start[px], s1 = wd_start[px + 1];
+      int k = 0, kend = 0;
+      if ((normal || zero_class) && d_hi > 0.f) {
+        const float rho1 = fmaxf(d_lo, 0.f) * row.z * 0.999999f;
+        const float f1 = floorf(rho1 * qscale) - 2.f;
+        const uint32_t q1 = (uint32_t)fminf(fmaxf(f1, 0.f), (float)qmax);
+        k = lower(s0, s1, q1);
+        kend = s1;
+        if (d_hi < 3e38f) {
+          const float f2 = floorf(d_hi * row.w * 1.000001f * qscale) + 2.f;
+          const uint32_t q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
+          kend = lower(k, s1, q2 + 1u);
         }
-        qn += __popcll(cw);
-        if (qn >= 64) flush(64);
       }
+      const int cnt = kend - k;
+      int inc = cnt;  // inclusive wave scan
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      p_k0[lane] = k; p_pre[lane] = inc - cnt; p_r[lane] = r; p_px[lane] = px;
+      p_tlo[lane] = row.x; p_thi[lane] = row.y; p_dlo[lane] = d_lo; p_dhi[lane] = d_hi;
+      if (lane == 63) p_pre[64] = inc;
     }
-    // ---- colour-0 pixels: the whole ray up to the band; the wave works them off one by one, columns across the lanes ---
-    unsigned long long zm = __ballot(zero_class);
-    while (zm) {
-      const int src = __ffsll((long long)zm) - 1;
-      zm &= zm - 1;
-      const int zpx = __shfl(px, src, 64), zr = __shfl(r, src, 64);
-      const float zd_hi = __shfl(d_hi, src, 64);
-      const float t_lo = __shfl(row.x, src, 64), t_hi = __shfl(row.y, src, 64), c_max = __shfl(row.w, src, 64);
-      const int zs0 = __shfl(s0, src, 64), zs1 = __shfl(s1, src, 64);
-      int ke = zs1;
-      if (zd_hi < 3e38f) {  // (wave-uniform)
-        const float f2 = floorf(zd_hi * c_max * 1.000001f * qscale) + 2.f;
-        const uint32_t q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
-        ke = zd_hi > 0.f ? lower(zs0, zs1, q2 + 1u) : zs0;
-      }
-      int kk = zs0 + lane;
-      z = 1; zend = 0;
-      while (__ballot(kk < ke || z <= zend) != 0ull) {
-        if (z > zend && kk < ke) {
-          const int2 e = wd_ent[kk];
-          kk += 64;
-          z_range(e, t_lo, t_hi, 0.f, zd_hi, z, zend);
-          ccol = e.x; crho2 = __int_as_float(e.y);
-        }
-        const bool cand = z <= zend;
-        const unsigned long long cw = __ballot(cand);
-        if (cw) {
-          if (cand) {
-            const int e = qn + __popcll(cw & lanes_below);
-            q_col[wv][e] = ccol; q_z[wv][e] = z; q_px[wv][e] = zpx; q_rho2[wv][e] = crho2; q_r[wv][e] = zr;
-            ++z;
+    __syncthreads();
+    const int T = p_pre[64];
+    if (VCOUNT && tid == 0) atomicAdd(&dbg[4], (unsigned long long)wall_clock64() - tm0);  // phase A
+    // ---- B: chunks of pairs ---------------------------------------------------------------------------------------------
+    for (int base = 0; base < T; base += LT_PIX_CHUNK) {
+      constexpr int PPT = LT_PIX_CHUNK / 256;  // pairs per thread
+      int len[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int slot = u * 256 + tid, i = base + slot;
+        len[u] = 0;
+        if (i < T) {
+          int sidx = 0;  // largest s with p_pre[s] <= i
+#pragma unroll
+          for (int st = 32; st >= 1; st >>= 1)
+            if (p_pre[sidx + st] <= i) sidx += st;
+          const int2 e = wd_ent[p_k0[sidx] + (i - p_pre[sidx])];
+          int z = 1, zend = 0;
+          if (e.x >= 0) {  // (the quirk tail of the last wedge carries column -1)
+            const float rho2 = __int_as_float(e.y), rho = sqrtf(rho2);
+            const float d_lo = p_dlo[sidx], d_hi = p_dhi[sidx];
+            const float hi2 = d_hi * d_hi - rho2;
+            if (hi2 >= 0.f) {  // (else the whole column lies beyond the band; false also for NaN)
+              const float zmax = sqrtf(hi2) * 1.000001f + 1e-6f;
+              const float lo2 = d_lo > 0.f ? d_lo * d_lo - rho2 : -1.f;
+              const float zmin = lo2 > 0.f ? fmaxf(sqrtf(lo2) * 0.999999f - 1e-6f, 0.f) : 0.f;
+              const float za = rho * p_tlo[sidx], zb = rho * p_thi[sidx];  // pt_z of the row in this column
+              float lo, hi;
+              if (za >= 0.f) { lo = fmaxf(za, zmin); hi = fminf(zb, zmax); }
+              else if (zb <= 0.f) { lo = fmaxf(za, -zmax); hi = fminf(zb, -zmin); }
+              else { lo = fmaxf(za, -zmax); hi = fminf(zb, zmax); }
+              if (lo <= hi) {
+                const float fz0 = ceilf((lo - oz) * inv_vs - 0.02f), fz1 = floorf((hi - oz) * inv_vs + 0.02f);
+                z = (int)fmaxf(fz0, 0.f);
+                zend = (int)fminf(fz1, (float)(vol_dim_z - 1));
+              }
+            }
           }
-          qn += __popcll(cw);
-          if (qn >= 64) flush(64);
+          len[u] = max(zend - z + 1, 0);
+          c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx;
+          // the column's written range and stamp once per PAIR, for the whole candidate interval (a superset is safe, as in
+          // the column walk) -- per written voxel, the ten threads holding one column's band voxels fought over one word
+          if (len[u] > 0) col_mark_written(col_zw, col_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
         }
       }
+      // exclusive prefix of the interval lengths over the chunk's slots (slot = u * 256 + tid: strided passes)
+      int run = 0;  // voxels of the passes before
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        int inc = len[u];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        c_pre[u * 256 + tid] = run + woff + inc - len[u];
+        run += tot;
+        __syncthreads();
+      }
+      if (tid == 0) c_pre[LT_PIX_CHUNK] = run;
+      __syncthreads();
+      const int V = run, n_slots = min(T - base, LT_PIX_CHUNK);
+      const unsigned long long tm1 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;
+      if (VCOUNT && tid == 0 && base == 0) atomicAdd(&dbg[5], tm1 - tm0);  // ... + first chunk's pairs and scan
+      // the chunk's voxels, one per thread and round
+      for (int jb = 0; jb < V; jb += 256) {  // (workgroup-uniform trips: the run aggregation below shuffles)
+        const int j = jb + tid;
+        int code = 0, col = 0, z = 0;
+        if (j < V) {
+        int sl = 0;  // largest slot < n_slots with c_pre[slot] <= j
+#pragma unroll
+        for (int st = LT_PIX_CHUNK / 2; st >= 1; st >>= 1)
+          if (sl + st < n_slots && c_pre[sl + st] <= j) sl += st;
+        const int sidx = c_src[sl];
+        col = c_col[sl]; z = c_z0[sl] + (j - c_pre[sl]);
+        col_plain Cq;
+        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+        code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
+                                           vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin,
+                                           obs_weight, fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im,
+                                           rem_im, wd_px, col_epoch, epoch, true, Cq, z, dct, p_r[sidx]);
+        }
+        // sign bits: the volume is fresh, every bit is 0 -- only negative values need a write; the voxels of a pair sit in
+        // neighbouring lanes and (mostly) in one 64-bit word: OR them together over the run, one atomic per run
+        const int wkey = code == 2 ? col * words_z + (z >> 6) : -1 - lane;  // (unique when there is nothing to write)
+        unsigned long long bits = code == 2 ? 1ull << (z & 63) : 0ull;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // runs of up to 16 lanes (a run is one column's interval: ~10 voxels)
+          const unsigned long long ob = __shfl_down(bits, o, 64);
+          const int ok = __shfl_down(wkey, o, 64);
+          if (lane + o < 64 && ok == wkey) bits |= ob;
+        }
+        const int prev = __shfl_up(wkey, 1, 64);
+        if (code == 2 && (lane == 0 || prev != wkey)) atomicOr(sign_bits + (size_t)wkey, bits);
+        else if (code == 2 && (lane & 15) == 0) atomicOr(sign_bits + (size_t)wkey, bits);  // (a run longer than 16 lanes)
+        if (VCOUNT && code) atomicAdd(&dbg[2], 1ull);
+      }
+      if (VCOUNT && tid == 0) {
+        atomicAdd(&dbg[0], (unsigned long long)n_slots); atomicAdd(&dbg[1], (unsigned long long)V);
+        atomicAdd(&dbg[6], (unsigned long long)wall_clock64() - tm1);  // the voxel rounds
+        atomicAdd(&dbg[7], 1ull);
+      }
+      __syncthreads();  // the chunk's arrays are reused
     }
+    __syncthreads();  // ... and the pixels'
   }
-  if (qn > 0) flush(qn);
 }
 
 // the columns that are not in the wedge table (k_wd_keys: quirk), one thread per voxel, by the reference's own
@@ -816,7 +883,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
     const unsigned long long bit = 1ull << (z & 63);
     if (code == 2) atomicOr(w, bit);
     else atomicAnd(w, ~bit);
-    col_mark_written(col_zw, col_epoch, epoch, col, z);
+    col_mark_written(col_zw, col_epoch, epoch, vol_dim_x * vol_dim_y, col, z, z);
   }
 }
 
@@ -835,6 +902,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
 // geometry of the per-column z range: slopes of the field of view with the 1e-5 margin of the sine test on the angles;
 // off for fields of view beyond +-80 degrees
 static unsigned long long* g_tsdf_dbg = nullptr;  // LIDARHIP_DEBUG_TSDF: per-wave stamps of k_tsdf_integrate_cols
+static unsigned long long* g_pix_dbg = nullptr;   // ... and {pairs, candidate voxels, written voxels} of k_tsdf_integrate_pix
 
 static col_geom tsdf_geom(const lt_tsdf* t) {
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
@@ -854,7 +922,7 @@ static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
   LT_HIP(hipMemsetAsync(t->col_epoch, 0, (size_t)t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
   LT_HIP(hipMemsetAsync(t->bits, 0, (size_t)t->dim[0] * t->dim[1] * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long),
                         stream));
-  LT_HIP(hipMemsetD32Async((hipDeviceptr_t)t->col_zw, (int)LT_ZW_EMPTY, (size_t)t->dim[0] * t->dim[1], stream));
+  LT_HIP(hipMemsetAsync(t->col_zw, 0, (size_t)2 * t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
   LT_HIP(hipGetLastError());
   t->epoch = 1;
   t->all_dirty = 0;
@@ -929,7 +997,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->colinfo, (3 * n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk, colz, colrho2
-      hipMalloc((void**)&t->col_zw, n_cols * sizeof(unsigned)) != hipSuccess ||
+      hipMalloc((void**)&t->col_zw, 2 * n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
     lt_tsdf_destroy(t);
@@ -1073,12 +1141,19 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
   const int words_z = (t->dim[2] + 63) / 64;
   const int n_pix = im_h * im_w;
-  const unsigned nb = (unsigned)((n_pix + 255) / 256);
-  hipLaunchKernelGGL(k_tsdf_integrate_pix<true>, dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem, t->dim[0],
-                     t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, 1.0f / t->voxel_size, im_h,
-                     im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->wd_px, t->col_epoch,
-                     t->epoch, t->bits, words_z, t->col_zw, t->dct, t->rowtab, t->wd_start, t->wd_ent, t->wd_key,
-                     t->wd_rho_bits, t->wd_qscale);
+  const unsigned nb = (unsigned)min((n_pix + 63) / 64, 1 << 20);  // a workgroup per 64 pixels
+  // LIDARHIP_DEBUG_TSDF=1: pairs / candidate voxels / written voxels of the launch (lt_debug_tsdf_pix_counts)
+  static const bool want_cnt = getenv("LIDARHIP_DEBUG_TSDF") != nullptr;
+  if (want_cnt && !g_pix_dbg) LT_HIP(hipMalloc((void**)&g_pix_dbg, 8 * sizeof(unsigned long long)));
+  if (want_cnt) LT_HIP(hipMemsetAsync(g_pix_dbg, 0, 8 * sizeof(unsigned long long), stream));
+#define LT_PIX_ARGS                                                                                                          \
+  t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],           \
+      t->voxel_size, 1.0f / t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, \
+      t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->rowtab, t->wd_start, t->wd_ent, t->wd_key,   \
+      t->wd_rho_bits, t->wd_qscale, g_pix_dbg
+  if (want_cnt) hipLaunchKernelGGL((k_tsdf_integrate_pix<true, true>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
+  else hipLaunchKernelGGL((k_tsdf_integrate_pix<true, false>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
+#undef LT_PIX_ARGS
   if (t->wd_n_quirk > 0) {
     const long long nv = (long long)t->wd_n_quirk * t->dim[2];
     hipLaunchKernelGGL(k_tsdf_integrate_quirk<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->tsdf, t->weight,
@@ -1194,6 +1269,15 @@ extern "C" int lt_tsdf_volumes(lt_tsdf* t, int* dims, float* origin, float** tsd
   if (weight) *weight = t->weight;
   if (color) *color = t->color;
   if (rem) *rem = t->rem;
+  return LT_OK;
+}
+
+// debug helper (not part of the documented ABI): {pairs, candidate voxels, written voxels} of the last pixel-centric
+// integrate (LIDARHIP_DEBUG_TSDF=1)
+extern "C" int lt_debug_tsdf_pix_counts(unsigned long long* out8) {
+  if (!out8 || !g_pix_dbg) return LT_ERR_INVALID_ARG;
+  LT_HIP(hipDeviceSynchronize());
+  LT_HIP(hipMemcpy(out8, g_pix_dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return LT_OK;
 }
 

@@ -16,7 +16,7 @@ rays = torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev)
 sc = Scene(0); rs = RaySet(rays, H); sc.set_mesh(*mesh0)
 o = sc.render(rs, (0, 0, 0)); torch.cuda.synchronize()
 folded = (o["endcolors"][:, 2].reshape(H, W).float() * 65536.0).contiguous()
-depth = o["range"].reshape(H, W).contiguous(); remi = o["endrem"].reshape(H, W).contiguous()
+depth = o["range"].reshape(H, W).clone(); remi = o["endrem"].reshape(H, W).clone()   # (clones: `o` is rendered into again below)
 vol = TSDFVolume(np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]]), 0.05, wl["fov_up"], wl["fov_down"])
 mesh = DeviceMesh(0)
 sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream); org = (C.c_float * 3)(0, 0, 0)
@@ -30,6 +30,13 @@ for i in range(n):
 torch.cuda.synchronize()
 dirty = None
 print("verts", mesh.n_verts, "faces", mesh.n_faces)
+if os.environ.get("LIDARHIP_DEBUG_TSDF"):
+    c3 = (C.c_ulonglong * 8)()
+    if lib.lt_debug_tsdf_pix_counts(c3) == 0:
+        print("k_tsdf_integrate_pix: pairs %d, candidate voxels %d, written %d" % (c3[0], c3[1], c3[2]))
+        nwg = max(1, (H * W + 63) // 64)
+        print("  per workgroup (100 MHz wall clock, mean us): phase A %.2f, A + first chunk's pairs + scan %.2f, voxel rounds %.2f (%d chunks)"
+              % (c3[4] / nwg / 100.0, c3[5] / nwg / 100.0, c3[6] / max(1, c3[7]) / 100.0, c3[7]))
 if "--count" in sys.argv:
     sc.set_device_mesh(mesh)
     st = sc.render(rs, (0, 0, 0), count=True)["stats"]
