@@ -221,7 +221,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} declared in lidarhip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
     assert b"gfx950" in lib.lt_version()
-    assert ctypes.sizeof(_lib.Stats) == 72  # lt_stats layout
+    assert ctypes.sizeof(_lib.Stats) == 80  # lt_stats layout (entries_culled added in round 3)
 
 
 def test_c_trace_argument_checks_raise_before_any_device_work():
