@@ -137,6 +137,7 @@ struct lt_tsdf {
   float4* rowtab;       // [rowtab_h] per image row: tan / cos of its pitch range with margins (host, double)
   int rowtab_h;         // capacity
   int rowtab_for_h;     // image height the table holds (the field of view is fixed per volume)
+  unsigned* zw_snap;    // [2][dim_x * dim_y] col_zw as it stood before the observation being integrated (non-fresh volumes)
 };
 
 #define LT_BOUNDS_BLOCKS 256

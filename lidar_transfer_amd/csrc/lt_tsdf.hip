@@ -134,6 +134,16 @@ __global__ __launch_bounds__(256) void k_tsdf_colmax(const float* __restrict__ d
   if (ty == 0 && x < im_w) colmax[x] = fmaxf(fmaxf(part[0][tx], part[1][tx]), fmaxf(part[2][tx], part[3][tx]));
 }
 
+// the transposed, packed copy alone (the pixel-centric integrate has no use for the column maxima): one thread per pixel,
+// reads coalesced along the image rows, 512 workgroups for a 64 x 2048 image (k_tsdf_colmax: 32, 18 us)
+__global__ __launch_bounds__(256) void k_tsdf_dct(const float* __restrict__ depth_im, const float* __restrict__ color_im,
+                                                  int im_h, int im_w, float2* __restrict__ dct) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= im_h * im_w) return;
+  const int y = i / im_w, x = i - y * im_w;
+  dct[(size_t)x * im_h + y] = make_float2(depth_im[i], color_im[i]);
+}
+
 // A walk over z in [z0, z1) of the table column (cx, cy) is PLAIN when the reference's float decomposition of every voxel
 // index in it (:95-98) yields (cx, cy, z): (float)voxel_idx is monotone in voxel_idx and so is the quotient's floor, hence
 // it is enough that both ends of the walk decompose to cx -- voxel_y and voxel_z then follow in exact integer / small-float
@@ -192,6 +202,7 @@ __device__ __forceinline__ int tsdf_voxel(
     if (in_table) {
       px = colinfo[ix * vol_dim_y + iy];
       if (px == -1) return 0;
+      if (px >= 0) px &= 0x3FFFFFFF;  // (the wedge table's per-column image column carries a flag bit: LT_WD_QUIRK_FLAG)
     }
     const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
     const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
@@ -578,6 +589,7 @@ struct wd_geom {
   float qscale;
 };
 #define LT_WD_QUIRK_KEY 0x3FFFFFFFu
+#define LT_WD_QUIRK_FLAG 0x40000000  // in wd_px[c]: the column is evaluated by k_tsdf_integrate_quirk, voxel by voxel
 
 __global__ __launch_bounds__(256) void k_wd_keys(wd_geom G, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                  int* __restrict__ wd_px, int* __restrict__ n_quirk) {
@@ -591,12 +603,12 @@ __global__ __launch_bounds__(256) void k_wd_keys(wd_geom G, uint32_t* __restrict
   int px = (int)floorf(proj_x);
   px = min(G.im_w - 1, px);
   px = max(0, px);
-  wd_px[c] = px;
   // every voxel index of the column decomposes, by the reference's float division (:95-98), to this column's x?
   const float dyz = (float)(G.dim_y * G.dim_z);
   const int i0 = c * G.dim_z, i1 = c * G.dim_z + G.dim_z - 1;
   const bool plain = floorf(((float)i0) / dyz) == (float)x && floorf(((float)i1) / dyz) == (float)x;
   const bool quirk = !plain || y == G.dim_y - 1;
+  wd_px[c] = px | (quirk ? LT_WD_QUIRK_FLAG : 0);
   const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
   const unsigned qmax = (1u << G.rho_bits) - 2u;  // (all-ones is left to LT_WD_QUIRK_KEY)
   const unsigned q = (unsigned)fminf(rho * G.qscale, (float)qmax);
@@ -655,7 +667,11 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, const float4* __restrict__ rowtab,
     const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
-    float qscale, unsigned long long* __restrict__ dbg) {
+    float qscale, const unsigned* __restrict__ zw_snap, unsigned long long* __restrict__ dbg) {
+  // zw_snap (NULL on a fresh volume): the columns' written z ranges as they were BEFORE this observation.  The voxels inside
+  // them may hold anything -- k_tsdf_integrate_written has evaluated every one of them -- and are skipped here; everything
+  // else still holds the initial values, so this kernel's superset argument (and `fresh` = true) stands.
+  const int n_cols_all = vol_dim_x * vol_dim_y;
   // per pixel of the workgroup
   __shared__ int p_k0[64], p_pre[65], p_r[64], p_px[64];
   __shared__ float p_tlo[64], p_thi[64], p_dlo[64], p_dhi[64];
@@ -782,8 +798,18 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
               }
             }
           }
+          int partial = 0;
+          if (zw_snap && zend >= z) {  // the part of the interval the column pass has done already
+            const int olo = LT_ZW_LO(zw_snap[e.x]), ohi = LT_ZW_HI(zw_snap[n_cols_all + e.x]);
+            if (ohi >= olo) {
+              if (z >= olo && zend <= ohi) zend = z - 1;      // all of it (the usual case of a repeated observation)
+              else if (z >= olo && z <= ohi) z = ohi + 1;     // its lower end
+              else if (zend >= olo && zend <= ohi) zend = olo - 1;  // its upper end
+              else if (z < olo && zend > ohi) partial = 0x40000000;  // a hole in the middle: decided per voxel
+            }
+          }
           len[u] = max(zend - z + 1, 0);
-          c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx;
+          c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx | partial;
           // the column's written range and stamp once per PAIR, for the whole candidate interval (a superset is safe, as in
           // the column walk) -- per written voxel, the ten threads holding one column's band voxels fought over one word
           if (len[u] > 0) col_mark_written(col_zw, col_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
@@ -822,10 +848,13 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
 #pragma unroll
         for (int st = LT_PIX_CHUNK / 2; st >= 1; st >>= 1)
           if (sl + st < n_slots && c_pre[sl + st] <= j) sl += st;
-        const int sidx = c_src[sl];
+        const int sflag = c_src[sl], sidx = sflag & 63;
         col = c_col[sl]; z = c_z0[sl] + (j - c_pre[sl]);
+        bool mine = true;
+        if (sflag & 0x40000000) mine = z < LT_ZW_LO(zw_snap[col]) || z > LT_ZW_HI(zw_snap[n_cols_all + col]);
         col_plain Cq;
         Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+        if (mine)
         code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
                                            vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin,
                                            obs_weight, fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im,
@@ -857,6 +886,70 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
   }
 }
 
+// A volume that already holds observations: every voxel inside a column's written range [lo, hi] -- as it stood before this
+// observation (zw_snap) -- runs the reference's expressions with its stored values loaded (`fresh` = false): a voxel written
+// earlier can be written again anywhere in front of the band (same class: the running average; another class: the closer
+// observation wins, fusion_lidar.py:191-213), which the pixel pass, built for voxels in their initial state, does not cover.
+// Four columns per wave iteration, 16 lanes each, z in 16-aligned steps (one sign word per step, owned by the group).
+template <bool MERGE>
+__global__ __launch_bounds__(256) void k_tsdf_integrate_written(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
+    const float* __restrict__ rem_im, const int* __restrict__ wd_px, unsigned* __restrict__ col_epoch, unsigned epoch,
+    unsigned long long* __restrict__ sign_bits, int words_z, const unsigned* __restrict__ zw_snap,
+    const float2* __restrict__ dct) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+  const int n_cols = vol_dim_x * vol_dim_y, n_chunks = (n_cols + 63) / 64;
+  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    const int c = chunk * 64 + lane;
+    unsigned zw = 0x7FFFu;  // lo | hi << 16, empty
+    int pxq = 0;
+    if (c < n_cols) {
+      const int hi = LT_ZW_HI(zw_snap[n_cols + c]);
+      if (hi >= 0) {
+        pxq = wd_px[c];
+        if (!(pxq & LT_WD_QUIRK_FLAG)) zw = (unsigned)LT_ZW_LO(zw_snap[c]) | ((unsigned)hi << 16);
+      }
+    }
+    unsigned long long m = __ballot((zw >> 16) >= (zw & 0xFFFFu));
+    while (m) {
+      const int bit = nth_set_bit(m, grp);
+      m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
+      const unsigned r = __shfl(zw, max(bit, 0), 64);
+      const int px = __shfl(pxq, max(bit, 0), 64);
+      const int z0 = bit >= 0 ? (int)(r & 0xFFFFu) : 1, z1 = bit >= 0 ? min((int)(r >> 16), vol_dim_z - 1) : 0;
+      const int cc = chunk * 64 + max(bit, 0);
+      const int cx = cc / vol_dim_y, cy = cc - cx * vol_dim_y;
+      col_plain C;
+      C.plain = true; C.px = px;
+      {
+        const float pt_x = __fmaf_rn((float)cx, voxel_size, ox), pt_y = __fmaf_rn((float)cy, voxel_size, oy);
+        C.rho2 = __fmaf_rn(pt_y, pt_y, pt_x * pt_x);
+      }
+      int trips = z1 >= z0 ? ((z1 - (z0 & ~15)) >> 4) + 1 : 0;
+      trips = max(trips, __shfl_xor(trips, 16, 64));
+      trips = max(trips, __shfl_xor(trips, 32, 64));
+      for (int k = 0; k < trips; ++k) {  // (wave-uniform: the ballots need every lane)
+        const int zc = (z0 & ~15) + 16 * k, z = zc + gl;
+        int code = 0;
+        if (z >= z0 && z <= z1)
+          code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y, vol_dim_z,
+                                   ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down, sin_up_hi,
+                                   sin_down_lo, color_im, depth_im, rem_im, wd_px, col_epoch, epoch, false, C, z, dct);
+        const unsigned long long wrote_w = __ballot(code != 0), neg_w = __ballot(code == 2);
+        const unsigned long long wrote = (wrote_w >> (16 * grp)) & 0xFFFFull, neg = (neg_w >> (16 * grp)) & 0xFFFFull;
+        if (wrote && gl == 0 && zc < vol_dim_z) {
+          unsigned long long* w = sign_bits + (size_t)cc * words_z + (zc >> 6);
+          const int sh = zc & 63;
+          *w = (*w & ~(wrote << sh)) | (neg << sh);
+        }
+      }
+    }
+  }
+}
+
 // the columns that are not in the wedge table (k_wd_keys: quirk), one thread per voxel, by the reference's own
 // decomposition of the voxel index (tsdf_voxel's general path; a decomposed (x, y) inside the table finds its image
 // column in wd_px, one outside -- the "(x + 1, -1)" voxels -- computes it)
@@ -868,7 +961,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ wd_px, unsigned* __restrict__ col_epoch, unsigned epoch,
     unsigned long long* __restrict__ sign_bits, int words_z, unsigned* __restrict__ col_zw,
-    const float2* __restrict__ dct, const uint32_t* __restrict__ qcols, int n_q) {
+    const float2* __restrict__ dct, const uint32_t* __restrict__ qcols, int n_q, int fresh) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)n_q * vol_dim_z) return;
   const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
@@ -877,7 +970,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
   const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
                                      vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
                                      fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, wd_px, col_epoch, epoch,
-                                     true, C, z, dct);
+                                     fresh != 0, C, z, dct);
   if (code) {
     unsigned long long* w = sign_bits + (size_t)col * words_z + (z >> 6);
     const unsigned long long bit = 1ull << (z & 63);
@@ -892,7 +985,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
-                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab};
+                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -1118,7 +1211,8 @@ static int tsdf_rowtab(lt_tsdf* t, int im_h, float fu, float fd, hipStream_t str
 }
 
 static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im, int im_h,
-                              int im_w, float obs_weight, float fu, float fd, int rho_bits, hipStream_t stream) {
+                              int im_w, float obs_weight, float fu, float fd, int rho_bits, bool fresh_volume,
+                              hipStream_t stream) {
   if (t->wd_w != im_w || t->wd_rho_bits != rho_bits) LT_CHECK(tsdf_wedge_build(t, im_w, rho_bits, stream));
   // the row table depends on (im_h, fov): both fixed for a sensor model; keyed by im_h and re-made when it changes
   if (t->rowtab_for_h != im_h || !t->rowtab) {
@@ -1126,22 +1220,29 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
     LT_CHECK(tsdf_rowtab(t, im_h, fu, fd, stream));
     t->rowtab_for_h = im_h;
   }
-  if (im_w > t->cap_w) {
-    if (t->colmax) { LT_HIP(hipDeviceSynchronize()); (void)hipFree(t->colmax); t->colmax = nullptr; }
-    LT_HIP(hipMalloc((void**)&t->colmax, (size_t)im_w * sizeof(float)));
-    t->cap_w = im_w;
-  }
   if ((size_t)im_w * im_h > t->cap_dct) {
     if (t->dct) { LT_HIP(hipDeviceSynchronize()); (void)hipFree(t->dct); t->dct = nullptr; t->cap_dct = 0; }
     LT_HIP(hipMalloc((void**)&t->dct, (size_t)im_w * im_h * sizeof(float2)));
     t->cap_dct = (size_t)im_w * im_h;
   }
-  hipLaunchKernelGGL(k_tsdf_colmax, dim3((im_w + 63) / 64), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->colmax,
-                     t->dct);
+  hipLaunchKernelGGL(k_tsdf_dct, dim3((im_h * im_w + 255) / 256), dim3(256), 0, stream, depth_im, color_im, im_h, im_w, t->dct);
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
   const int words_z = (t->dim[2] + 63) / 64;
   const int n_pix = im_h * im_w;
   const unsigned nb = (unsigned)min((n_pix + 63) / 64, 1 << 20);  // a workgroup per 64 pixels
+  const unsigned* zw_snap = nullptr;
+  if (!fresh_volume) {
+    // the written ranges as they stand before this observation (32 MB on the default volume: a device copy), then every
+    // voxel inside them by the reference's expressions; the pixel pass below takes the rest
+    const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
+    if (!t->zw_snap) LT_HIP(hipMalloc((void**)&t->zw_snap, 2 * n_cols * sizeof(unsigned)));
+    LT_HIP(hipMemcpyAsync(t->zw_snap, t->col_zw, 2 * n_cols * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
+    zw_snap = t->zw_snap;
+    hipLaunchKernelGGL(k_tsdf_integrate_written<true>, dim3((unsigned)min((int)((n_cols + 255) / 256), 8192)), dim3(256), 0,
+                       stream, t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1],
+                       t->origin[2], t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im,
+                       rem_im, t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, zw_snap, t->dct);
+  }
   // LIDARHIP_DEBUG_TSDF=1: pairs / candidate voxels / written voxels of the launch (lt_debug_tsdf_pix_counts)
   static const bool want_cnt = getenv("LIDARHIP_DEBUG_TSDF") != nullptr;
   if (want_cnt && !g_pix_dbg) LT_HIP(hipMalloc((void**)&g_pix_dbg, 8 * sizeof(unsigned long long)));
@@ -1150,7 +1251,7 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],           \
       t->voxel_size, 1.0f / t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, \
       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->rowtab, t->wd_start, t->wd_ent, t->wd_key,   \
-      t->wd_rho_bits, t->wd_qscale, g_pix_dbg
+      t->wd_rho_bits, t->wd_qscale, zw_snap, g_pix_dbg
   if (want_cnt) hipLaunchKernelGGL((k_tsdf_integrate_pix<true, true>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
   else hipLaunchKernelGGL((k_tsdf_integrate_pix<true, false>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
 #undef LT_PIX_ARGS
@@ -1159,7 +1260,8 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
     hipLaunchKernelGGL(k_tsdf_integrate_quirk<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->tsdf, t->weight,
                        t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
                        t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im,
-                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->wd_qcols, t->wd_n_quirk);
+                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->wd_qcols, t->wd_n_quirk,
+                       fresh_volume ? 1 : 0);
   }
   LT_HIP(hipGetLastError());
   return LT_OK;
@@ -1182,10 +1284,14 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   const bool tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
   int px_bits = 1;
   while ((1 << px_bits) < im_w) ++px_bits;
-  const bool use_pix = !pix_off && (flags & LT_TSDF_MERGE) && t->n_obs == 0 && !t->all_dirty && tan_ok && 30 - px_bits >= 12 &&
-                       fabsf(fu) + fabsf(fd) > 0.f;
+  // (LIDARHIP_TSDF_PIX=1: only the first observation of a fresh volume; default: every observation)
+  static const bool pix_fresh_only = []() { const char* e = getenv("LIDARHIP_TSDF_PIX"); return e && strcmp(e, "1") == 0; }();
+  const bool use_pix = !pix_off && (flags & LT_TSDF_MERGE) && (t->n_obs == 0 || !pix_fresh_only) && !t->all_dirty && tan_ok &&
+                       30 - px_bits >= 12 && fabsf(fu) + fabsf(fd) > 0.f;
+  const bool fresh_volume = t->n_obs == 0;
   t->n_obs += 1;
-  if (use_pix) return tsdf_integrate_pix(t, color_im, depth_im, rem_im, im_h, im_w, obs_weight, fu, fd, 30 - px_bits, stream);
+  if (use_pix)
+    return tsdf_integrate_pix(t, color_im, depth_im, rem_im, im_h, im_w, obs_weight, fu, fd, 30 - px_bits, fresh_volume, stream);
   if (im_w > t->cap_w) {
     if (t->colmax) {
       LT_HIP(hipDeviceSynchronize());

@@ -188,8 +188,10 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
     voxels, where the reference's float voxel index misplaces voxels next to x boundaries -- two observations, a
     reset, the same two observations again: all four fields bit-identical, and the volume after the reset round equals
     the first round.  The first observation of a round is driven by the pixels (k_tsdf_integrate_pix: wedge table, rows'
-    z intervals, colour-0 pixels by the whole wave, the y = dim_y - 1 columns voxel by voxel) -- or, with LIDARHIP_TSDF_PIX=0
-    ("walk"), by the column walk's band test + candidate queue --, the second through the exact evaluation of every voxel; (40, -50) degrees is a field of view for which the band test is
+    z intervals, colour-0 pixels as long runs, the y = dim_y - 1 columns voxel by voxel) and so is the second, after a pass
+    over the voxels inside the columns' previously written ranges (k_tsdf_integrate_written) -- or, with LIDARHIP_TSDF_PIX=0
+    ("walk"), both by the column walk (band test + candidate queue, then the exact evaluation of every voxel), with =1
+    ("pix1") the first by the pixels and the second by the walk; (40, -50) degrees is a field of view for which the band test is
     switched off; zero, NaN and infinite depth pixels and colour 0 (the fresh volume's own) are in the images, and image
     columns holding only the reference's "no data" depth -1 -- with voxel_size 0.25 the truncation margin is 1.25 m, so the
     voxels within 0.25 m of the sensor ARE written through such pixels (depth_diff = -1 - depth >= -trunc_margin)."""
@@ -197,14 +199,16 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("cols", "walk", "dense"):
+    for mode in ("cols", "walk", "pix1", "dense"):
         env = dict(os.environ)
         env.pop("LT_TEST_TSDF", None)
         env.pop("LIDARHIP_TSDF_PIX", None)
         if mode == "dense":
             env["LT_TEST_TSDF"] = "dense"
-        elif mode == "walk":   # the column walk also for the first observation of a fresh volume (default: pixel-centric)
+        elif mode == "walk":   # the column walk for every observation (default: driven by the pixels)
             env["LIDARHIP_TSDF_PIX"] = "0"
+        elif mode == "pix1":   # by the pixels on a fresh volume, the column walk for the observations after the first
+            env["LIDARHIP_TSDF_PIX"] = "1"
         path = str(tmp_path / f"{mode}.npz")
         r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd), str(voxel)],
                            env=env,
@@ -212,7 +216,7 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = np.load(path)
     for key in res["cols"].files:
-        for other in ("dense", "walk"):
+        for other in ("dense", "walk", "pix1"):
             a, b = res["cols"][key], res[other][key]
             assert np.array_equal(a.view(np.int32), b.view(np.int32)), (key, other)
     for i in range(4):
