@@ -138,6 +138,7 @@ struct lt_tsdf {
   int rowtab_h;         // capacity
   int rowtab_for_h;     // image height the table holds (the field of view is fixed per volume)
   unsigned* zw_snap;    // [2][dim_x * dim_y] col_zw as it stood before the observation being integrated (non-fresh volumes)
+  unsigned* chunk_epoch;  // [ceil(dim_x * dim_y / 64)] == epoch: a column of this chunk of 64 was written since the last reset
 };
 
 #define LT_BOUNDS_BLOCKS 256

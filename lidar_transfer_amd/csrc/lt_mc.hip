@@ -65,6 +65,11 @@ struct lt_mesh {
   int* blk; size_t cap_blocks;          // 3 ints per workgroup of 256 words, then 4 totals
   int* totals_host;                     // pinned: {active words, vertices, triangles, -}
   mc_rec* rec; size_t cap_rec;
+  // cnt / cmap hold 0 / -1 for every word that is not an active word of the LAST extraction (k_mc_clear undoes those
+  // before the next one): the 2 x 64 MB of the default volume are never swept again.  n_prev: active words of the last
+  // extraction (their records are still in `rec`); state_dirty: an extraction did not finish -- sweep everything once
+  int n_prev, state_dirty;
+  int* wave_na; size_t cap_wave_na;     // active words per wave of 64 rows (k_mc_words -> k_mc_compact)
   float ms_signs, ms_rest;              // last extraction (when timed)
   hipEvent_t ev[3];
 };
@@ -200,16 +205,38 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
 // row share their stamps.
 __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
-                                                  unsigned epoch) {
+                                                  unsigned epoch, const unsigned* __restrict__ chunk_epoch,
+                                                  int* __restrict__ wave_na) {
+  const int n_rows = D.nx * D.ny;
+  if (chunk_epoch) {
+    // the volume stamps every CHUNK of 64 columns it writes into (lt_tsdf.hip): a workgroup's 256 rows depend on the
+    // chunks of the rows r, r + 1, r + ny, r + ny + 1 -- ten flags through the scalar cache; three workgroups in four
+    // of a street scene leave here without a vector load (cnt already holds 0 for their words, see lt_mesh)
+    const int n_chunks = (n_rows + 63) / 64;
+    const int r0 = blockIdx.x * 256;
+    bool any = false;
+    for (int base = r0; base <= r0 + D.ny; base += D.ny)
+      for (int k = 0; k < 5; ++k) {
+        const int ch = (base >> 6) + k;
+        any = any || (ch < n_chunks && chunk_epoch[ch] == epoch);
+      }
+    if (!any) {  // (workgroup-uniform)
+      if ((threadIdx.x & 63) == 0) {
+        const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
+        blk[3 * blkid] = 0; blk[3 * blkid + 1] = 0; blk[3 * blkid + 2] = 0;
+        wave_na[blkid] = 0;
+      }
+      return;
+    }
+  }
   __shared__ unsigned char s_nt[256];  // triangles per case: the loops below look it up once per active cell, a chain of
   s_nt[threadIdx.x] = LT_MC_NTRIS[threadIdx.x];  // dependent loads that is three times shorter through LDS
   __syncthreads();
   const int row = blockIdx.x * 256 + threadIdx.x;
-  const int n_rows = D.nx * D.ny;
   unsigned na = 0, nv = 0, nt = 0;
   if (row < n_rows) {
     if (!mc_rows_dirty(col_epoch, epoch, D, row)) {
-      for (int k = 0; k < D.wz; ++k) cnt[(size_t)row * D.wz + k] = 0u;
+      // (nothing to write: the words of a clean row hold 0 -- no active word of the last extraction is left, k_mc_clear)
     } else {
       const int x = row / D.ny, y = row - x * D.ny;
       if (D.wz <= 4) {
@@ -258,7 +285,18 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
     blk[3 * blkid] = (int)(p & 0xFFFFF);
     blk[3 * blkid + 1] = (int)((p >> 20) & 0xFFFFF);
     blk[3 * blkid + 2] = (int)((p >> 40) & 0xFFFFF);
+    wave_na[blkid] = (int)(p & 0xFFFFF);
   }
+}
+
+// undo the last extraction's entries of cnt / cmap (its records are still there): both arrays are back to 0 / -1
+__global__ __launch_bounds__(256) void k_mc_clear(const mc_rec* __restrict__ rec, int n, unsigned* __restrict__ cnt,
+                                                  int* __restrict__ cmap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int w = rec[i].w;
+  cnt[w] = 0u;
+  cmap[w] = -1;
 }
 
 // ---- k_mc_scan1 / k_mc_scan2: exclusive scan of the per-workgroup totals in two levels -------------------------------
@@ -314,21 +352,19 @@ __global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_
 __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits, mc_dims D,
                                                     const unsigned* __restrict__ cnt, const int* __restrict__ blk,
                                                     const int* __restrict__ seg, int* __restrict__ cmap,
-                                                    mc_rec* __restrict__ rec, int cap_rec) {
+                                                    mc_rec* __restrict__ rec, int cap_rec,
+                                                    const int* __restrict__ wave_na) {
   // thread = row, scan block = wave (as in k_mc_words); compact order = word order
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int n_rows = D.nx * D.ny;
+  // no active word in these 64 rows (most waves): nothing to rank, and their cmap entries are -1 already (lt_mesh)
+  if (wave_na[blockIdx.x * 4 + (threadIdx.x >> 6)] == 0) return;
   unsigned na = 0, nv = 0, nt = 0;
   if (row < n_rows)
     for (int k = 0; k < D.wz; ++k) {
       const unsigned c = cnt[(size_t)row * D.wz + k];
       na += c ? 1u : 0u; nv += c & 0xFFFFu; nt += c >> 16;
     }
-  if (__ballot(na != 0u) == 0ull) {  // no active word in these 64 rows (most waves): nothing to rank
-    if (row < n_rows)
-      for (int k = 0; k < D.wz; ++k) cmap[(size_t)row * D.wz + k] = -1;
-    return;
-  }
   const u64 mine = pack3(na, nv, nt);
   const u64 ex = wave_incl_scan(mine) - mine;
   if (row >= n_rows) return;
@@ -801,7 +837,7 @@ extern "C" int lt_mesh_destroy(lt_mesh* m) {
   if (!m) return LT_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec};
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   if (m->totals_host) (void)hipHostFree(m->totals_host);
@@ -843,7 +879,7 @@ static int mc_grow(T** p, size_t* cap, size_t need) {
 
 static int mc_extract(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny, int nz,
                       float voxel_size, const float* origin, lt_mesh* m, void* stream_, float* ms,
-                      const unsigned* col_epoch, unsigned epoch, const u64* ext_bits) {
+                      const unsigned* col_epoch, unsigned epoch, const u64* ext_bits, const unsigned* chunk_epoch) {
   if (!tsdf || !color_vol || !rem_vol || !origin || !m || nx <= 0 || ny <= 0 || nz <= 0) {
     lt_set_error("lt_marching_cubes_dev: invalid argument");
     return LT_ERR_INVALID_ARG;
@@ -886,7 +922,18 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     LT_HIP(hipMalloc((void**)&m->cnt, n_words * sizeof(unsigned)));
     LT_HIP(hipMalloc((void**)&m->cmap, n_words * sizeof(int)));
     m->cap_words = n_words;
+    m->state_dirty = 1;  // (fresh buffers: swept below)
   }
+  if (m->state_dirty) {  // new buffers, or an extraction that did not finish: cnt = 0, cmap = -1 everywhere, once
+    LT_HIP(hipMemsetAsync(m->cnt, 0, m->cap_words * sizeof(unsigned), stream));
+    LT_HIP(hipMemsetAsync(m->cmap, 0xFF, m->cap_words * sizeof(int), stream));
+    m->n_prev = 0;
+  } else if (m->n_prev > 0) {
+    hipLaunchKernelGGL(k_mc_clear, dim3((m->n_prev + 255) / 256), dim3(256), 0, stream, m->rec, m->n_prev, m->cnt, m->cmap);
+  }
+  m->state_dirty = 1;  // until this extraction has finished
+  m->n_prev = 0;
+  LT_CHECK(mc_grow(&m->wave_na, &m->cap_wave_na, (size_t)n_blocks));
   const int n_seg = (n_blocks + 255) / 256;
   if (n_seg > 1024) {
     lt_set_error("lt_marching_cubes_dev: volume too large (%d words)", D.n_words);
@@ -903,7 +950,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
                        tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
   hipLaunchKernelGGL(k_mc_words, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
-                     epoch);
+                     epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -950,7 +997,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }
   hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
-                     (int)min(m->cap_rec, (size_t)2147483647));
+                     (int)min(m->cap_rec, (size_t)2147483647), m->wave_na);
   static const bool emit_waves = []() {  // A/B: LIDARHIP_MC_EMIT=waves -> one wave per active word (k_mc_emit)
     const char* e = getenv("LIDARHIP_MC_EMIT");
     return e && strcmp(e, "waves") == 0;
@@ -971,6 +1018,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   LT_HIP(hipGetLastError());
   m->n_verts = nv;
   m->n_faces = nf;
+  m->n_prev = n_active;  // (the records k_mc_clear will undo before the next extraction)
+  m->state_dirty = 0;
   if (ms) {
     LT_HIP(hipEventRecord(m->ev[2], stream));
     LT_HIP(hipStreamSynchronize(stream));
@@ -994,13 +1043,14 @@ extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, fl
   }
   // the volume knows which columns were written since its last reset: the others are not read
   return mc_extract(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m, stream, ms,
-                    t->all_dirty ? nullptr : t->col_epoch, t->epoch, t->all_dirty ? nullptr : t->bits);
+                    t->all_dirty ? nullptr : t->col_epoch, t->epoch, t->all_dirty ? nullptr : t->bits,
+                    t->all_dirty ? nullptr : t->chunk_epoch);
 }
 
 extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
                                      int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
                                      float* ms) {
-  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u, nullptr);
+  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u, nullptr, nullptr);
 }
 
 extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
     unsigned epoch, col_geom G, unsigned long long* __restrict__ sign_bits, int words_z,
     unsigned* __restrict__ col_zw, const float2* __restrict__ dct, float kA, float kB,
     const int* __restrict__ chunk_live, const unsigned* __restrict__ colz, const float* __restrict__ colrho2,
-    int all_written, unsigned long long* __restrict__ dbg) {
+    int all_written, unsigned long long* __restrict__ dbg, unsigned* __restrict__ chunk_epoch) {
   const unsigned long long t_dbg = dbg ? (unsigned long long)wall_clock64() : 0ull;  // (LIDARHIP_DEBUG_TSDF: per-wave stamps)
   // candidates of the band test (fresh plain columns, class-aware update) wait here, per wave, until 64 are together:
   // then lane j evaluates candidate j exactly
@@ -510,6 +510,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
         col_zw[cc] = (unsigned)(0x7FFF - wz_lo);
         col_zw[n_cols + cc] = (unsigned)(wz_hi + 1);
         col_epoch[cc] = epoch;
+        chunk_epoch[cc >> 6] = epoch;  // (what reset and marching cubes look at first)
       }
     }
   }
@@ -528,11 +529,13 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
                                                          float* __restrict__ color, float* __restrict__ rem,
                                                          int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
                                                          unsigned epoch, unsigned long long* __restrict__ sign_bits,
-                                                         unsigned* __restrict__ col_zw) {
+                                                         unsigned* __restrict__ col_zw,
+                                                         const unsigned* __restrict__ chunk_epoch) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_chunks = (n_cols + 63) / 64;
   const int words_z = (dim_z + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    if (chunk_epoch[chunk] != epoch) continue;  // (wave-uniform: no column of this chunk was written)
     const int c = chunk * 64 + lane;
     const bool dirty = c < n_cols && col_epoch[c] == epoch;
     unsigned zw = 0x7FFFu;  // (lo | hi << 16; empty)
@@ -640,10 +643,12 @@ __global__ __launch_bounds__(256) void k_wd_finish(wd_geom G, const uint32_t* __
 
 // merge z into the written range of column c (lo | hi << 16), stamp the column; any number of concurrent writers
 __device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, unsigned* __restrict__ col_epoch,
-                                                 unsigned epoch, int n_cols, int c, int z, int z_last) {
+                                                 unsigned* __restrict__ chunk_epoch, unsigned epoch, int n_cols, int c,
+                                                 int z, int z_last) {
   atomicMax(&col_zw[c], (unsigned)(0x7FFF - z));       // (results unused: fire and forget)
   atomicMax(&col_zw[n_cols + c], (unsigned)(z_last + 1));
   col_epoch[c] = epoch;
+  chunk_epoch[c >> 6] = epoch;
 }
 
 // One workgroup = 64 consecutive pixels of the transposed image (rows of one image column: they walk the same wedge), its
@@ -665,8 +670,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     float fov_down, float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im,
     const float* __restrict__ depth_im, const float* __restrict__ rem_im, const int* __restrict__ wd_px,
     unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
-    unsigned* __restrict__ col_zw, const float2* __restrict__ dct, const float4* __restrict__ rowtab,
-    const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
+    unsigned* __restrict__ col_zw, unsigned* __restrict__ chunk_epoch, const float2* __restrict__ dct,
+    const float4* __restrict__ rowtab, const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
     float qscale, const unsigned* __restrict__ zw_snap, unsigned long long* __restrict__ dbg) {
   // zw_snap (NULL on a fresh volume): the columns' written z ranges as they were BEFORE this observation.  The voxels inside
   // them may hold anything -- k_tsdf_integrate_written has evaluated every one of them -- and are skipped here; everything
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
           c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx | partial;
           // the column's written range and stamp once per PAIR, for the whole candidate interval (a superset is safe, as in
           // the column walk) -- per written voxel, the ten threads holding one column's band voxels fought over one word
-          if (len[u] > 0) col_mark_written(col_zw, col_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
+          if (len[u] > 0) col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
         }
       }
       // exclusive prefix of the interval lengths over the chunk's slots (slot = u * 256 + tid: strided passes)
@@ -899,10 +904,11 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ wd_px, unsigned* __restrict__ col_epoch, unsigned epoch,
     unsigned long long* __restrict__ sign_bits, int words_z, const unsigned* __restrict__ zw_snap,
-    const float2* __restrict__ dct) {
+    const float2* __restrict__ dct, const unsigned* __restrict__ chunk_epoch) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_cols = vol_dim_x * vol_dim_y, n_chunks = (n_cols + 63) / 64;
   for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+    if (chunk_epoch[chunk] != epoch) continue;  // (wave-uniform: nothing of this chunk has been written)
     const int c = chunk * 64 + lane;
     unsigned zw = 0x7FFFu;  // lo | hi << 16, empty
     int pxq = 0;
@@ -961,7 +967,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
     float sin_up_hi, float sin_down_lo, const float* __restrict__ color_im, const float* __restrict__ depth_im,
     const float* __restrict__ rem_im, const int* __restrict__ wd_px, unsigned* __restrict__ col_epoch, unsigned epoch,
     unsigned long long* __restrict__ sign_bits, int words_z, unsigned* __restrict__ col_zw,
-    const float2* __restrict__ dct, const uint32_t* __restrict__ qcols, int n_q, int fresh) {
+    unsigned* __restrict__ chunk_epoch, const float2* __restrict__ dct, const uint32_t* __restrict__ qcols, int n_q,
+    int fresh) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)n_q * vol_dim_z) return;
   const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
     const unsigned long long bit = 1ull << (z & 63);
     if (code == 2) atomicOr(w, bit);
     else atomicAnd(w, ~bit);
-    col_mark_written(col_zw, col_epoch, epoch, vol_dim_x * vol_dim_y, col, z, z);
+    col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, col, z, z);
   }
 }
 
@@ -985,7 +992,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
-                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap};
+                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap, t->chunk_epoch};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -1016,6 +1023,7 @@ static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
   LT_HIP(hipMemsetAsync(t->bits, 0, (size_t)t->dim[0] * t->dim[1] * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long),
                         stream));
   LT_HIP(hipMemsetAsync(t->col_zw, 0, (size_t)2 * t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
+  LT_HIP(hipMemsetAsync(t->chunk_epoch, 0, (((size_t)t->dim[0] * t->dim[1] + 63) / 64) * sizeof(unsigned), stream));
   LT_HIP(hipGetLastError());
   t->epoch = 1;
   t->all_dirty = 0;
@@ -1034,7 +1042,8 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
   const int n_cols = t->dim[0] * t->dim[1];
   hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits, t->col_zw);
+                     t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits, t->col_zw,
+                     t->chunk_epoch);
   LT_HIP(hipGetLastError());
   t->epoch += 1;  // every stamp is stale now: nothing to clear
   t->n_obs = 0;
@@ -1091,6 +1100,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->colinfo, (3 * n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk, colz, colrho2
       hipMalloc((void**)&t->col_zw, 2 * n_cols * sizeof(unsigned)) != hipSuccess ||
+      hipMalloc((void**)&t->chunk_epoch, ((n_cols + 63) / 64) * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->bits, n_cols * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long)) != hipSuccess) {
     lt_set_error("lt_tsdf_create: hipMalloc of the column tables failed");
     lt_tsdf_destroy(t);
@@ -1241,7 +1251,7 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
     hipLaunchKernelGGL(k_tsdf_integrate_written<true>, dim3((unsigned)min((int)((n_cols + 255) / 256), 8192)), dim3(256), 0,
                        stream, t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1],
                        t->origin[2], t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im,
-                       rem_im, t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, zw_snap, t->dct);
+                       rem_im, t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, zw_snap, t->dct, t->chunk_epoch);
   }
   // LIDARHIP_DEBUG_TSDF=1: pairs / candidate voxels / written voxels of the launch (lt_debug_tsdf_pix_counts)
   static const bool want_cnt = getenv("LIDARHIP_DEBUG_TSDF") != nullptr;
@@ -1250,7 +1260,8 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
 #define LT_PIX_ARGS                                                                                                          \
   t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],           \
       t->voxel_size, 1.0f / t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, \
-      t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->rowtab, t->wd_start, t->wd_ent, t->wd_key,   \
+      t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->chunk_epoch, t->dct, t->rowtab, t->wd_start, t->wd_ent, \
+      t->wd_key,                                                                                                            \
       t->wd_rho_bits, t->wd_qscale, zw_snap, g_pix_dbg
   if (want_cnt) hipLaunchKernelGGL((k_tsdf_integrate_pix<true, true>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
   else hipLaunchKernelGGL((k_tsdf_integrate_pix<true, false>), dim3(nb), dim3(256), 0, stream, LT_PIX_ARGS);
@@ -1260,7 +1271,7 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
     hipLaunchKernelGGL(k_tsdf_integrate_quirk<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->tsdf, t->weight,
                        t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
                        t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im,
-                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->dct, t->wd_qcols, t->wd_n_quirk,
+                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->chunk_epoch, t->dct, t->wd_qcols, t->wd_n_quirk,
                        fresh_volume ? 1 : 0);
   }
   LT_HIP(hipGetLastError());
@@ -1340,12 +1351,14 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     hipLaunchKernelGGL(k_tsdf_integrate_cols<true>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg,
+                       t->chunk_epoch);
   else
     hipLaunchKernelGGL(k_tsdf_integrate_cols<false>, dim3(nbc), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
                        t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size, im_h, im_w,
                        t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im, rem_im, t->colinfo, t->col_epoch,
-                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg);
+                       t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg,
+                       t->chunk_epoch);
   LT_HIP(hipGetLastError());
   return LT_OK;
 }
