@@ -941,11 +941,12 @@ def main():
                "phase_ms": {"reset": round(float(m[0]), 3), "integrate": round(float(m[1]), 3),
                             "marching_cubes": round(float(m[2]), 3), "render": round(float(m[3]), 3)},
                "roofline": {
-                   "integrate": chain_roofline(["k_tsdf_integrate_cols", "k_tsdf_columns", "k_tsdf_colmax"], comp_int,
+                   "integrate": chain_roofline(["k_tsdf_integrate_pix", "k_tsdf_integrate_written", "k_tsdf_integrate_quirk",
+                                                "k_tsdf_dct"], comp_int,
                                                float(m[1]), "written voxels x 16 B out (+ in again after the first "
                                                "observation) + 3 images per observation"),
-                   "marching_cubes": chain_roofline(["k_mc_emit_batch", "k_mc_words", "k_mc_compact", "k_mc_scan1",
-                                                     "k_mc_scan2"], comp_mc, float(m[2]),
+                   "marching_cubes": chain_roofline(["k_mc_emit_batch", "k_mc_words", "k_mc_compact", "k_mc_clear",
+                                                     "k_mc_scan1", "k_mc_scan2"], comp_mc, float(m[2]),
                                                     "mesh out (28 B per vertex, 12 B per face) + 16 B of field samples "
                                                     "in per vertex")}}
         return rec

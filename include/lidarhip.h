@@ -67,8 +67,9 @@ typedef struct lt_stats {
   unsigned long long nodes_visited; /* 4-wide nodes fetched (lbvh) / candidate bins (scatter) */
   unsigned long long tris_tested;   /* Moller-Trumbore evaluations, summed over rays    */
   unsigned long long stack_overflows; /* rays that spilled past the LDS stack           */
-  unsigned long long entries_culled;  /* lbvh: stack entries dropped at pop because their box begins behind the best
-                                         hit found since they were pushed (BVH.cpp:41); 0 for the scatter strategy */
+  unsigned long long entries_culled;  /* lbvh built with -DLT_TRACE_CULL (an A/B, not the default): stack entries dropped
+                                         at pop because their box begins behind the best hit found since they were pushed
+                                         (BVH.cpp:41); otherwise 0 */
 } lt_stats;
 
 typedef struct lt_scene lt_scene; /* opaque: device workspace + BVH of one mesh */

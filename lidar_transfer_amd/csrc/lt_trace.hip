@@ -352,10 +352,14 @@ __global__ __launch_bounds__(256) void k_trace4(
     float* __restrict__ range, float* __restrict__ endrem, int* __restrict__ tri_out, unsigned flags,
     int* __restrict__ overflow, unsigned long long* __restrict__ counters, int step_cap, tail_args tail) {
   __shared__ int stack[4][LT_STACK4_LDS][16];
-  // entry distance of every deferred child, upper 16 bits of the float (tn >= 0: truncation rounds DOWN): a popped entry
-  // whose box begins behind the best hit found since it was pushed is dropped without fetching its node -- BVH.cpp:41
-  // ("if (near > intersection->t) continue"); a 128-byte node line and ~70 vector instructions per culled entry
+#ifdef LT_TRACE_CULL
+  // A/B (LIDARHIP_EXTRA_FLAGS=-DLT_TRACE_CULL), measured and NOT the default: the entry distance of every deferred child, upper
+  // 16 bits of the float (tn >= 0: truncation rounds DOWN) -- a popped entry whose box begins behind the best hit found since
+  // it was pushed is dropped without fetching its node, BVH.cpp:41 ("if (near > intersection->t) continue").  C2: 27.2 -> 25.3
+  // node visits per ray (7 % culled), and k_trace4 57 -> 73 us: the 16-bit LDS store per push and load per pop sit on the
+  // dependent chain of EVERY step of a kernel that is bound by exactly that chain.
   __shared__ unsigned short stack_tn[4][LT_STACK4_LDS][16];
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 3, q = lane >> 2;
   const bool dbg_times = COUNT || (flags & LT_TRACE_DEBUG_TIMES);
@@ -393,13 +397,13 @@ __global__ __launch_bounds__(256) void k_trace4(
     return v;
   };
   unsigned n_culled = 0;
-  // next reference to visit: the top of the stack, skipping entries that lie behind the best hit by now (spilled entries
-  // carry no distance and are never culled).  sp, best_t are uniform within a quad: all four lanes take the same trips.
+  // next reference to visit: the top of the stack (with LT_TRACE_CULL: skipping entries that lie behind the best hit by now;
+  // spilled entries carry no distance and are never culled).  sp, best_t are uniform within a quad.
   auto pop_next = [&]() {
     int r = LT_DONE;
     while (sp > 0) {
       --sp;
-#ifndef LT_TRACE_NO_CULL
+#ifdef LT_TRACE_CULL
       const float tnp = sp < LT_STACK4_LDS ? __uint_as_float((unsigned)stack_tn[wave][sp][q] << 16) : 0.f;
       if (tnp > best_t) {
         if (COUNT && j == 0) ++n_culled;
@@ -446,7 +450,9 @@ __global__ __launch_bounds__(256) void k_trace4(
           const int slot = sp + (nh - 1 - rank);
           if (slot < LT_STACK4_LDS) {
             stack[wave][slot][q] = ref;
+#ifdef LT_TRACE_CULL
             stack_tn[wave][slot][q] = (unsigned short)(__float_as_uint(tn) >> 16);
+#endif
           } else {
             spill[slot - LT_STACK4_LDS] = ref;
             if (COUNT) ++n_ovf;

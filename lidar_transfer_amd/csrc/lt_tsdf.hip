@@ -661,7 +661,9 @@ __device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, 
 // 5 m four voxels altogether -- 368 us with two waves per SIMD, most lanes idle; colour-0 pixels, whose run is the wedge up
 // to the band, are simply long runs here)
 #define LT_PIX_CHUNK 512    // pairs per chunk (two per thread)
-#define LT_PIX_STAGE 4096   // rho quanta staged in LDS for the binary searches (a wedge of the default volume: 2000 - 3900)
+#define LT_PIX_STAGE 3840   // rho quanta staged in LDS for the binary searches (a wedge of the default volume: 2000 - 3900);
+                            // 15 KB: with the other arrays 19.5 KB per workgroup = EIGHT per CU -- the 2048 workgroups of a
+                            // 64 x 2048 image are resident at once (at 4096 entries, seven per CU: a second round)
 template <bool MERGE, bool VCOUNT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
