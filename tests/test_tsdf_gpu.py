@@ -54,6 +54,33 @@ def test_integrate_vs_c_restatement(oracle, merge):
     vol.close()
 
 
+def test_wedge_table_follows_the_image_shape(oracle):
+    """One volume, observations of three different image shapes in turn (reset between them, and two of the same shape in a
+    row without a reset): the pixel-centric integrate rebuilds its wedge table for a new width and its row table for a new
+    height; every state against the C restatement of the reference kernel."""
+    from lidar_transfer_amd.fusion import TSDFVolume
+    fu, fd = 3.0, -25.0
+    bnds = np.array([[-16.0, 16.0], [-16.0, 16.0], [-4.0, 4.0]])
+    vol = TSDFVolume(bnds, 0.25, fu, fd, merge=True)
+    dims = tuple(int(x) for x in vol._vol_dim)
+    n = int(np.prod(dims))
+    for k, (H, W, repeat) in enumerate([(32, 256, 1), (16, 100, 2), (48, 256, 1), (32, 256, 1)]):
+        vol.reset()
+        ref = [np.ones(dims, np.float32), np.zeros(dims, np.float32), np.zeros(dims, np.float32), np.zeros(dims, np.float32)]
+        for j in range(repeat):
+            label3, depth, remi = _images(30 + k + j, H, W, fu, fd)
+            vol.integrate(label3, depth, remi, np.eye(3), obs_weight=1.)
+            folded = np.floor(label3[:, :, 0] * 256 * 256 + label3[:, :, 1] * 256 + label3[:, :, 2]).astype(np.float32)
+            oracle.tsdf_integrate(ref, dims, vol._vol_origin, 0.25, fu, fd, folded, depth, remi, 1.0, merge=True)
+        got = [t.cpu().numpy() for t in vol.get_volume_tensors()]
+        bad = np.zeros(dims, bool)
+        for a, b in zip(got, ref):
+            bad |= a.view(np.int32) != b.view(np.int32)
+        assert (ref[0] != 1).sum() > 0.005 * n, "test volume barely touched"
+        assert bad.sum() <= 2e-4 * n, f"shape {H}x{W}: {bad.sum()} of {n} voxels differ"
+    vol.close()
+
+
 def test_plain_average_branch_vs_reference_numpy_cpu_mode():
     """`merge == false` against the reference's numpy CPU mode (float64 pixel maths, no remissions)."""
     from lidar_transfer_amd.fusion import TSDFVolume
@@ -116,8 +143,9 @@ sys.path.insert(0, %r)
 import torch
 from lidar_transfer_amd.fusion import TSDFVolume
 merge = sys.argv[2] == "1"
-H, W, fu, fd = 32, 256, float(sys.argv[3]), float(sys.argv[4])
+fu, fd = float(sys.argv[3]), float(sys.argv[4])
 voxel = float(sys.argv[5]) if len(sys.argv) > 5 else 0.05
+H, W = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (32, 256)
 rng = np.random.default_rng(5)
 yaw = np.linspace(-np.pi, np.pi, W)
 half = 15.0 if voxel < 0.1 else 20.0
@@ -150,8 +178,8 @@ for rnd in range(2):          # second round: after a reset the volume must equa
     for k in range(2):
         depth = (6.0 + 3.0 * np.sin(3 * yaw + k)[None, :] + 0.2 * rng.random((H, W))).astype(np.float32)
         depth[rng.random((H, W)) < 0.05] = 0.0
-        depth[:, 40:60] = 0.0                                  # image columns without any return
-        depth[:, 100:110] = -1.0                               # ... and with the reference's "no data" value (laserscan.py:38)
+        depth[:, 40 * W // 256:60 * W // 256] = 0.0            # image columns without any return
+        depth[:, 100 * W // 256:110 * W // 256] = -1.0         # ... and with the reference's "no data" value (laserscan.py:38)
         depth[rng.random((H, W)) < 0.003] = np.nan            # broken pixels: both kernels must treat them alike
         depth[rng.random((H, W)) < 0.003] = np.inf
         lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
@@ -179,9 +207,11 @@ np.savez(sys.argv[1], **{f"{k}{i}": a for k, v in out.items() for i, a in enumer
 """
 
 
-@pytest.mark.parametrize("merge,fu,fd,voxel", [(True, 10.0, -25.0, 0.05), (False, 10.0, -25.0, 0.05), (True, 40.0, -50.0, 0.05),
-                                                (True, 2.0, -24.8, 0.05), (True, 10.0, -25.0, 0.25), (False, 10.0, -25.0, 0.25)])
-def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd, voxel):
+@pytest.mark.parametrize("merge,fu,fd,voxel,hw", [(True, 10.0, -25.0, 0.05, (32, 256)), (False, 10.0, -25.0, 0.05, (32, 256)),
+                                                   (True, 40.0, -50.0, 0.05, (32, 256)), (True, 2.0, -24.8, 0.05, (32, 256)),
+                                                   (True, 10.0, -25.0, 0.25, (32, 256)), (False, 10.0, -25.0, 0.25, (32, 256)),
+                                                   (True, 15.0, -20.0, 0.25, (25, 301)), (True, 5.0, -30.0, 0.25, (70, 97))])
+def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd, voxel, hw):
     """The work-saving integrate (per-column image column and dead-column test, conservative sine test, dirty-column
     reset) against the plain one-thread-per-voxel restatement of the reference kernel (tests/csrc/lt_tsdf_dense.hip: a TEST
     library, not in liblidarhip.so) on a 72 M-voxel volume -- beyond 2^24
@@ -194,7 +224,9 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
     ("pix1") the first by the pixels and the second by the walk; (40, -50) degrees is a field of view for which the band test is
     switched off; zero, NaN and infinite depth pixels and colour 0 (the fresh volume's own) are in the images, and image
     columns holding only the reference's "no data" depth -1 -- with voxel_size 0.25 the truncation margin is 1.25 m, so the
-    voxels within 0.25 m of the sensor ARE written through such pixels (depth_diff = -1 - depth >= -trunc_margin)."""
+    voxels within 0.25 m of the sensor ARE written through such pixels (depth_diff = -1 - depth >= -trunc_margin).  Image
+    shapes 25 x 301 and 70 x 97: the pixel kernel's workgroups of 64 pixels then straddle image columns, and the wedge table
+    is built for a width that is not a power of two."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -210,7 +242,8 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
         elif mode == "pix1":   # by the pixels on a fresh volume, the column walk for the observations after the first
             env["LIDARHIP_TSDF_PIX"] = "1"
         path = str(tmp_path / f"{mode}.npz")
-        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd), str(voxel)],
+        r = subprocess.run([sys.executable, "-c", _AB_SCRIPT % root, path, "1" if merge else "0", str(fu), str(fd), str(voxel),
+                            str(hw[0]), str(hw[1])],
                            env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
