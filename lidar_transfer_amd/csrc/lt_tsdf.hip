@@ -661,6 +661,7 @@ __device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, 
 // 5 m four voxels altogether -- 368 us with two waves per SIMD, most lanes idle; colour-0 pixels, whose run is the wedge up
 // to the band, are simply long runs here)
 #define LT_PIX_CHUNK 512    // pairs per chunk (two per thread)
+#define LT_PIX_AGG 1024     // table entries whose written ranges a workgroup merges in LDS before it touches col_zw
 #define LT_PIX_STAGE 3840   // rho quanta staged in LDS for the binary searches (a wedge of the default volume: 2000 - 3900);
                             // 15 KB: with the other arrays 19.5 KB per workgroup = EIGHT per CU -- the 2048 workgroups of a
                             // 64 x 2048 image are resident at once (at 4096 entries, seven per CU: a second round)
@@ -690,6 +691,12 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
   int* const c_pre = c_buf + 3 * LT_PIX_CHUNK;  // [LT_PIX_CHUNK + 1]
   __shared__ float c_rho2[LT_PIX_CHUNK];
   __shared__ int wsum[4];
+  // the columns' written ranges, merged in LDS first: the pairs of a workgroup fall on a few dozen table entries of ONE
+  // wedge (a wall's column is visited by dozens of rows), and two global atomics + two stores per PAIR were 43 of the
+  // kernel's 92 us (tools/pix_sections.sh).  a_lo / a_hi are indexed by table entry - a_k0 and hold the col_zw encoding
+  // (0x7fff - lo, hi + 1; 0 = nothing); a workgroup whose pairs span more than LT_PIX_AGG entries marks directly.
+  __shared__ unsigned a_lo[LT_PIX_AGG], a_hi[LT_PIX_AGG];
+  __shared__ int a_k0, a_span;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t qmax = (1u << rho_bits) - 2u;
   const int n_pix = im_h * im_w;
@@ -722,9 +729,15 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       stage0 = wd_start[px_a];
       n_stage = wd_start[px_b + 1] - stage0;
       staged = n_stage <= LT_PIX_STAGE;  // (a longer run of wedges is searched in global memory)
+#ifdef LT_PIX_NO_STAGE  // (timing experiment)
+      staged = false;
+#endif
       if (staged)
         for (int i = tid; i < n_stage; i += 256) c_buf[i] = (int)wd_key[stage0 + i];
       __syncthreads();
+    }
+    if (wave != 0) {
+      for (int i = tid - 64; i < LT_PIX_AGG; i += 192) { a_lo[i] = 0u; a_hi[i] = 0u; }
     }
     if (wave == 0) {
       const int p = p0 + lane;  // pixel (row r, column px) at dct[px * im_h + r]
@@ -766,9 +779,19 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       p_k0[lane] = k; p_pre[lane] = inc - cnt; p_r[lane] = r; p_px[lane] = px;
       p_tlo[lane] = row.x; p_thi[lane] = row.y; p_dlo[lane] = d_lo; p_dhi[lane] = d_hi;
       if (lane == 63) p_pre[64] = inc;
+      // the span of table entries the workgroup's pairs fall on
+      int kmin = cnt > 0 ? k : 0x7fffffff, kmax = cnt > 0 ? kend : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, __shfl_xor(kmin, o, 64));
+        kmax = max(kmax, __shfl_xor(kmax, o, 64));
+      }
+      if (lane == 0) { a_k0 = kmin; a_span = kmax > kmin ? kmax - kmin : 0; }
     }
     __syncthreads();
     const int T = p_pre[64];
+    const int agg_k0 = a_k0, agg_span = a_span;
+    const bool agg = agg_span <= LT_PIX_AGG;  // (workgroup-uniform)
     if (VCOUNT && tid == 0) atomicAdd(&dbg[4], (unsigned long long)wall_clock64() - tm0);  // phase A
     // ---- B: chunks of pairs ---------------------------------------------------------------------------------------------
     for (int base = 0; base < T; base += LT_PIX_CHUNK) {
@@ -783,7 +806,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
 #pragma unroll
           for (int st = 32; st >= 1; st >>= 1)
             if (p_pre[sidx + st] <= i) sidx += st;
-          const int2 e = wd_ent[p_k0[sidx] + (i - p_pre[sidx])];
+          const int kk = p_k0[sidx] + (i - p_pre[sidx]);
+          const int2 e = wd_ent[kk];
           int z = 1, zend = 0;
           if (e.x >= 0) {  // (the quirk tail of the last wedge carries column -1)
             const float rho2 = __int_as_float(e.y), rho = sqrtf(rho2);
@@ -819,7 +843,16 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
           c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx | partial;
           // the column's written range and stamp once per PAIR, for the whole candidate interval (a superset is safe, as in
           // the column walk) -- per written voxel, the ten threads holding one column's band voxels fought over one word
-          if (len[u] > 0) col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
+#ifndef LT_PIX_NO_MARK  // (timing experiment)
+          if (len[u] > 0) {
+            if (agg) {
+              atomicMax(&a_lo[kk - agg_k0], (unsigned)(0x7FFF - z));
+              atomicMax(&a_hi[kk - agg_k0], (unsigned)(zend + 1));
+            } else {
+              col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
+            }
+          }
+#endif
         }
       }
       // exclusive prefix of the interval lengths over the chunk's slots (slot = u * 256 + tid: strided passes)
@@ -861,6 +894,9 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
         if (sflag & 0x40000000) mine = z < LT_ZW_LO(zw_snap[col]) || z > LT_ZW_HI(zw_snap[n_cols_all + col]);
         col_plain Cq;
         Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+#ifdef LT_PIX_NO_EVAL  // timing experiment: everything but the evaluation (nothing is written)
+        mine = false;
+#endif
         if (mine)
         code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
                                            vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin,
@@ -869,6 +905,9 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
         }
         // sign bits: the volume is fresh, every bit is 0 -- only negative values need a write; the voxels of a pair sit in
         // neighbouring lanes and (mostly) in one 64-bit word: OR them together over the run, one atomic per run
+#ifdef LT_PIX_NO_BITS  // timing experiment: no sign bits (marching cubes would see nothing)
+        code = 0;
+#endif
         const int wkey = code == 2 ? col * words_z + (z >> 6) : -1 - lane;  // (unique when there is nothing to write)
         unsigned long long bits = code == 2 ? 1ull << (z & 63) : 0ull;
 #pragma unroll
@@ -878,9 +917,12 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
           if (lane + o < 64 && ok == wkey) bits |= ob;
         }
         const int prev = __shfl_up(wkey, 1, 64);
-        if (code == 2 && (lane == 0 || prev != wkey)) atomicOr(sign_bits + (size_t)wkey, bits);
-        else if (code == 2 && (lane & 15) == 0) atomicOr(sign_bits + (size_t)wkey, bits);  // (a run longer than 16 lanes)
-        if (VCOUNT && code) atomicAdd(&dbg[2], 1ull);
+        if (code == 2 && (lane == 0 || prev != wkey || (lane & 15) == 0))  // (lane & 15: a run longer than 16 lanes)
+          atomicOr(sign_bits + (size_t)wkey, bits);
+        if (VCOUNT) {  // (one atomic per wave and round: a per-voxel atomic on one address would be the whole kernel)
+          const unsigned long long wr = __ballot(code != 0);
+          if (lane == 0 && wr) atomicAdd(&dbg[2], (unsigned long long)__popcll(wr));
+        }
       }
       if (VCOUNT && tid == 0) {
         atomicAdd(&dbg[0], (unsigned long long)n_slots); atomicAdd(&dbg[1], (unsigned long long)V);
@@ -889,6 +931,19 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       }
       __syncthreads();  // the chunk's arrays are reused
     }
+    // the merged ranges -> col_zw, stamps: once per column (all pairs of all chunks have merged: the barrier above)
+    if (agg)
+      for (int i = tid; i < agg_span; i += 256) {
+        const unsigned hi1 = a_hi[i];
+        if (hi1) {
+          const int c = wd_ent[agg_k0 + i].x;
+          const int n_cols = vol_dim_x * vol_dim_y;
+          atomicMax(&col_zw[c], a_lo[i]);  // (atomic: with an image height that does not divide 64 two workgroups share a wedge)
+          atomicMax(&col_zw[n_cols + c], hi1);
+          col_epoch[c] = epoch;
+          chunk_epoch[c >> 6] = epoch;
+        }
+      }
     __syncthreads();  // ... and the pixels'
   }
 }
