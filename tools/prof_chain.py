@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Driver for rocprofv3: the fusion chain (reset -> integrate -> marching cubes -> render) on the default volume, N times."""
+"""Driver for rocprofv3: the fusion chain (reset -> integrate -> marching cubes -> render) on the default volume, N times.
+    python tools/prof_chain.py [N [observations per output scan]]      (observations 2.. are noisy copies, as in bench.py)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +9,8 @@ from lidar_transfer_amd.fusion import DeviceMesh, TSDFVolume
 from lidar_transfer_amd.laserscan import create_rays
 from lidar_transfer_amd.raytracer import RaySet, Scene
 from lidar_transfer_amd.synth import WORKLOADS, synth_scene
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
+n_obs = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1
 wl = WORKLOADS["C2"]; H, W = wl["H"], wl["W"]; dev = torch.device("cuda", 0)
 lib = _lib.load()
 mesh0 = [torch.from_numpy(x).to(dev) for x in synth_scene(0, wl["tris"])]
@@ -20,9 +22,18 @@ depth = o["range"].reshape(H, W).clone(); remi = o["endrem"].reshape(H, W).clone
 vol = TSDFVolume(np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]]), 0.05, wl["fov_up"], wl["fov_down"])
 mesh = DeviceMesh(0)
 sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream); org = (C.c_float * 3)(0, 0, 0)
+gen = torch.Generator(device=dev); gen.manual_seed(1234)
+obs = [(folded, depth)]
+for k in range(1, n_obs):
+    noise = (torch.rand((H, W), device=dev, generator=gen) - 0.5) * 0.04
+    hole = torch.rand((H, W), device=dev, generator=gen) < 0.05
+    flip = torch.rand((H, W), device=dev, generator=gen) < 0.02
+    obs.append((torch.where(flip, torch.full_like(folded, 50.0 * 65536.0), folded).contiguous(),
+                torch.where(hole | (depth == 0), torch.zeros_like(depth), depth + noise).contiguous()))
 for i in range(n):
     assert lib.lt_tsdf_reset(vol._h, sp) == 0
-    assert lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), depth.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
+    for f_k, d_k in obs:
+        assert lib.lt_tsdf_integrate_dev(vol._h, f_k.data_ptr(), d_k.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
     assert lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None) == 0
     assert lib.lt_scene_set_mesh(sc._h, mesh._h) == 0
     assert lib.lt_scene_render_dev(sc._h, rs._h, org, o["endpoints"].data_ptr(), o["endcolors"].data_ptr(), o["range"].data_ptr(),
