@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, 
 // words, lists their vertices and triangles in LDS (in output order: the lists ARE the output ranges, a batch's words
 // are consecutive), and then lane j computes vertex j / triangle j: every lane live, every store coalesced.
 #define LT_MC_VCAP 256   // list windows; a batch with more vertices / triangles is emitted in several passes
-#define LT_MC_TCAP 512
+#define LT_MC_TCAP 256   // (LDS per wave decides how many batches a CU holds: 10.8 KB -> 8.2 KB = 14 -> 19 waves per CU)
 template <int K>
 __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
                                                       const float* __restrict__ rem_vol, const u64* __restrict__ bits,
@@ -559,13 +559,16 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   __shared__ u64 s_sg[K][8];        // sign words of the cell corners, [dx | dy << 1 | dw << 2]
   __shared__ mc_nb s_nb[K][8];      // records of the 8 words a cell's triangles can reference
   __shared__ u64 s_cm[K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
-  __shared__ unsigned s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10
+  __shared__ unsigned short s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10 (12 bits)
   __shared__ unsigned s_tl[LT_MC_TCAP];  // triangle j of the window: k | b << 4 | t << 10 | case << 13
   __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | case << 13
-  __shared__ int s_ct[K * 64];           // ... and the (batch-relative) index of their first triangle
+  __shared__ unsigned short s_ct[K * 64];  // ... and the (batch-relative) index of their first triangle (< 16 x 64 x 5)
   __shared__ int s_cpre[K + 1];          // active cells before word k
   const int lane = threadIdx.x;
-  const int ci0 = blockIdx.x * K;
+  // (a wave takes batches until none is left; by default the grid has a wave per batch -- see the launch)
+  const int n_batches = (n_active + K - 1) / K;
+  for (int bi = blockIdx.x; bi < n_batches; bi += gridDim.x) {
+  const int ci0 = bi * K;
   const int nw = min(K, n_active - ci0);
   const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
   if (lane < nw) {
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) - vbase0;
   const int ntt = last.tbase + last.pad - tbase0;
 #if defined(LT_MC_STOP) && LT_MC_STOP == 1  // instruction-count experiment (tools/mc_sections.sh): staging only
-  return;
+  continue;
 #endif
   // ---- vertices
   // Two ways to list them.  SPARSE batch (the usual one: a street scene's word owns 3.6 vertices): lane j finds vertex j --
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
           a_r -= fx;
           axis = (fy && a_r == 0) ? 1 : 2;
         }
-        s_vl[j] = (unsigned)k | ((unsigned)b << 4) | ((unsigned)axis << 10);
+        s_vl[j] = (unsigned short)((unsigned)k | ((unsigned)b << 4) | ((unsigned)axis << 10));
       }
     } else
     for (int k = 0; k < nw; ++k) {  // lane = voxel of word k: its (up to three) vertices into the list
@@ -669,13 +672,13 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       const int fx = (int)((R.ex >> lane) & 1ull), fy = (int)((R.ey >> lane) & 1ull), fz = (int)((R.ez >> lane) & 1ull);
       int j = R.vbase - vbase0 - vb + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
       const unsigned e = (unsigned)k | ((unsigned)lane << 4);
-      if (fx) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e; ++j; }
-      if (fy) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e | (1u << 10); ++j; }
-      if (fz) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = e | (2u << 10); }
+      if (fx) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)e; ++j; }
+      if (fy) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (1u << 10)); ++j; }
+      if (fz) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (2u << 10)); }
     }
     __syncthreads();
 #if defined(LT_MC_STOP) && LT_MC_STOP == 2  // ... + vertex list
-    return;
+    continue;
 #endif
     const int nwin = min(LT_MC_VCAP, nvt - vb);
     for (int j = lane; j < nwin; j += 64) {
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     __syncthreads();
   }
 #if defined(LT_MC_STOP) && LT_MC_STOP == 3  // ... + vertex pass
-  return;
+  continue;
 #endif
   // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
   // the batch's active cells in order (word, z), with their case; then one scan per 64 cells gives every cell the index
@@ -762,19 +765,19 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
         const int q = __shfl_up(inc, o, 64);
         if (lane >= o) inc += q;
       }
-      if (c < ncell) s_ct[c] = run + inc - nt;
+      if (c < ncell) s_ct[c] = (unsigned short)(run + inc - nt);
       run += __shfl(inc, 63, 64);
     }
   }
   __syncthreads();
 #if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
-  return;
+  continue;
 #endif
   for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
     for (int c = lane; c < ncell; c += 64) {  // a cell's (up to five) triangles into the window's list
       const unsigned e = s_cl[c];
       const int nt = LT_MC_NTRIS[(e >> 13) & 255];
-      const int j0 = s_ct[c] - tb;
+      const int j0 = (int)s_ct[c] - tb;
       for (int t = 0; t < nt; ++t)
         if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = e | ((unsigned)t << 10);
     }
@@ -808,6 +811,8 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       }
     }
     __syncthreads();
+  }
+    __syncthreads();  // the batch's arrays are reused
   }
 }
 
@@ -1009,10 +1014,16 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   else if (n_active > 0)
   {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
-    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, dim3((n_active + 15) / 16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, dim3((n_active + 7) / 8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, dim3((n_active + 3) / 4), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else hipLaunchKernelGGL(k_mc_emit_batch<2>, dim3((n_active + 1) / 2), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    // (A/B: LIDARHIP_MC_EMIT_WAVES=n caps the grid, the waves then take batches in turn.  Default: a wave per batch --
+    // 31 500 waves on the default volume's street scene: 101 us; 12 288 persistent waves: 97, 6144: 117, 3072: 130.  The
+    // kernel is neither launch-rate nor residency bound (LDS 10.8 -> 8.2 KB per wave: 105 -> 101 us): a batch is a chain of
+    // ~6 dependent memory round trips, ~15 us under load, and 31 500 of them over ~4 900 resident waves is the 100 us.)
+    static const int max_waves = []() { const char* e = getenv("LIDARHIP_MC_EMIT_WAVES"); return e && atoi(e) > 0 ? atoi(e) : (1 << 24); }();
+    auto grid = [&](int k) { return dim3((unsigned)min((n_active + k - 1) / k, max_waves)); };
+    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, grid(4), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    else hipLaunchKernelGGL(k_mc_emit_batch<2>, grid(2), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
   }
 #undef LT_MC_EMIT_ARGS
   LT_HIP(hipGetLastError());
