@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblidarhip.so")
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP vectoriser pairs fp32 operations into v_pk_* instructions and pays for them with as many
-# v_mov to line the operands up -- k_sc_tris (vector-issue bound) is 11 % faster without it.
+# v_mov to line the operands up -- k_sc_tris is 11 % faster without it.
 # LIDARHIP_EXTRA_FLAGS (space separated) is appended: compiler experiments on the GPU box.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
          "-fno-slp-vectorize", *os.environ.get("LIDARHIP_EXTRA_FLAGS", "").split()]

@@ -175,4 +175,22 @@ __device__ __forceinline__ float lt_rcp_ieee(float a) {
   e = __builtin_fmaf(-a, r, 1.0f);
   return __builtin_fmaf(e, r, r);
 }
+// Sweeps over the CHUNKS of a volume (64 consecutive columns (x, y) each; three in four of a street scene are clean): a
+// wave (or workgroup) takes `per` chunks, a stride apart -- chunk = k * n + id, k < per, n = the number of waves --, reads
+// their stamps with its first lanes and walks the written ones.  Written chunks come in clusters along x AND along y, so the
+// stride must not be a whole number of volume rows (dim_y / 64 chunks each): n is nudged upwards, in steps of `multiple`,
+// until the `per` chunks of a wave are spread over y (their y offsets advance by ~1 / per of a row).
+static inline int lt_deal_count(int n_chunks, int per, int dim_y, int multiple) {
+  int n = (n_chunks + per - 1) / per;
+  n = ((n + multiple - 1) / multiple) * multiple;
+  const double row = dim_y / 64.0;  // chunks per volume row
+  if (row > 1.0 && per > 1)
+    for (int tries = 0; tries < 256; ++tries, n += multiple) {
+      double f = n / row;
+      f -= (double)(long long)f;
+      if (f >= 0.75 / per && f <= 1.25 / per) break;
+    }
+  return n;
+}
+
 #endif

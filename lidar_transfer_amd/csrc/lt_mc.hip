@@ -35,6 +35,18 @@
 #define LT_TABLE_ATTR __device__
 #include "lt_mc_table.h"
 
+// debug (-DLT_MC_STAMP=1: k_mc_words, =2: k_mc_compact; tools/mc_wave_times.py): wall clock (100 MHz) at the start of a wave,
+// after its stamp ballot and at its end, and the number of blocks it walked
+#ifdef LT_MC_STAMP
+__device__ unsigned long long g_mc_stamp[4 << 16];
+extern "C" int lt_debug_mc_stamps(unsigned long long* out, int n_waves) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mc_stamp), (size_t)min(n_waves, 1 << 16) * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define LT_MC_STAMP_AT(which, w, i, v) do { if (LT_MC_STAMP == (which) && (threadIdx.x & 63) == 0 && (w) < (1 << 16)) g_mc_stamp[(w) * 4 + (i)] = (v); } while (0)
+#else
+#define LT_MC_STAMP_AT(which, w, i, v) do { } while (0)
+#endif
+
 typedef unsigned long long u64;
 
 struct mc_dims {
@@ -203,90 +215,137 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
 // One thread per ROW (x, y) of wz words, one block of the scan per WAVE (64 rows): a thread per word was 250 000 waves of
 // four stamp loads and a store -- 30 rounds of resident waves waiting for a load each, 103 us -- and the four words of a
 // row share their stamps.
+//
+// Which blocks a wave works on.  The volume stamps every CHUNK of 64 columns it writes into (lt_tsdf.hip), and a block of 64
+// rows r .. r + 63 depends on the chunks of the rows r, r + 1, r + ny, r + ny + 1: four flags.  Five blocks in six of a
+// street scene are clean (their counts already hold 0, see lt_mesh).  A wave takes LT_MC_BLOCKS_PER_WAVE blocks: its first
+// lanes read the flags of one block each, a ballot finds the live ones, and the wave walks those -- 7 816 waves instead of
+// 62 500, of which most loaded their flags and left.  The blocks of a wave are a stride apart (block = lane x number of
+// waves + wave, lt_deal_count): written chunks come in clusters, dealt this way every wave gets its share (1.4 live
+// blocks on average, 4 at most).  What the kernel's time is made of (per-wave wall-clock stamps, tools/mc_wave_times.py):
+// a live block is a chain of four dependent round trips to cold memory -- case table, chunk flags, the rows' stamps, the
+// sign words: ~1.7 us each -- plus the cell loops: 7.6 us for a wave with one block, 11 us with two; the slots are 0.2 busy.
+#define LT_MC_BLOCKS_PER_WAVE 8
+__device__ __forceinline__ bool mc_block_live(const unsigned* __restrict__ chunk_epoch, unsigned epoch, const mc_dims& D,
+                                              int b, int n_chunks) {
+  if (!chunk_epoch) return true;
+  const int q = (b * 64 + D.ny) >> 6;
+  bool any = false;
+  const int ch[4] = {b, b + 1, q, q + 1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) any = any || (ch[k] < n_chunks && chunk_epoch[min(ch[k], n_chunks - 1)] == epoch);
+  return any;
+}
+
 __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
                                                   unsigned epoch, const unsigned* __restrict__ chunk_epoch,
-                                                  int* __restrict__ wave_na) {
+                                                  int* __restrict__ wave_na, int n_blocks) {
   const int n_rows = D.nx * D.ny;
-  if (chunk_epoch) {
-    // the volume stamps every CHUNK of 64 columns it writes into (lt_tsdf.hip): a workgroup's 256 rows depend on the
-    // chunks of the rows r, r + 1, r + ny, r + ny + 1 -- ten flags through the scalar cache; three workgroups in four
-    // of a street scene leave here without a vector load (cnt already holds 0 for their words, see lt_mesh)
-    const int n_chunks = (n_rows + 63) / 64;
-    const int r0 = blockIdx.x * 256;
-    bool any = false;
-    for (int base = r0; base <= r0 + D.ny; base += D.ny)
-      for (int k = 0; k < 5; ++k) {
-        const int ch = (base >> 6) + k;
-        any = any || (ch < n_chunks && chunk_epoch[ch] == epoch);
-      }
-    if (!any) {  // (workgroup-uniform)
-      if ((threadIdx.x & 63) == 0) {
-        const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
-        blk[3 * blkid] = 0; blk[3 * blkid + 1] = 0; blk[3 * blkid + 2] = 0;
-        wave_na[blkid] = 0;
-      }
-      return;
-    }
-  }
+  const int n_chunks = (n_rows + 63) / 64;
   __shared__ unsigned char s_nt[256];  // triangles per case: the loops below look it up once per active cell, a chain of
   s_nt[threadIdx.x] = LT_MC_NTRIS[threadIdx.x];  // dependent loads that is three times shorter through LDS
   __syncthreads();
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  unsigned na = 0, nv = 0, nt = 0;
-  if (row < n_rows) {
-    if (!mc_rows_dirty(col_epoch, epoch, D, row)) {
-      // (nothing to write: the words of a clean row hold 0 -- no active word of the last extraction is left, k_mc_clear)
-    } else {
-      const int x = row / D.ny, y = row - x * D.ny;
-      if (D.wz <= 4) {
-        // the sign words of the four rows (x + dx, y + dy), ALL loaded before the first is used -- a word's masks need
-        // its row neighbours' words at k and k + 1, so a loop over k loaded every word twice, in wz dependent rounds
-        const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny;
-        u64 w[4][5];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int dx = q & 1, dy = q >> 1;
-          const bool have = (dx == 0 || hx) && (dy == 0 || hy);
-          const size_t base = (size_t)(row + dx * D.ny + dy) * D.wz;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[q][k] = (have && k < D.wz) ? bits[base + k] : 0ull;
-          w[q][4] = 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k >= D.wz) break;
-          u64 w8[8];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { w8[q] = w[q][k]; w8[q | 4] = w[q][k + 1]; }
-          const mc_masks M = mc_build(w8, D, x, y, k);
-          const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
-          unsigned t = 0;
-          for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
-          cnt[(size_t)row * D.wz + k] = v | (t << 16);
-          na += (v | t) ? 1u : 0u; nv += v; nt += t;
-        }
-      } else
-      for (int k = 0; k < D.wz; ++k) {
-        const mc_masks M = mc_load(bits, D, x, y, k);
-        const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
-        unsigned t = 0;
-        for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
-        cnt[(size_t)row * D.wz + k] = v | (t << 16);
-        na += (v | t) ? 1u : 0u; nv += v; nt += t;
-      }
+  const int lane = threadIdx.x & 63;
+  const int n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  LT_MC_STAMP_AT(1, wave, 0, wall_clock64());
+  u64 live;
+  {
+    const int b = lane * n_waves + wave;
+    const bool mine = lane < LT_MC_BLOCKS_PER_WAVE && b < n_blocks;
+    const bool act = mine && mc_block_live(chunk_epoch, epoch, D, b, n_chunks);
+    if (mine && !act) {  // (cnt already holds 0 for the words of a clean block)
+      blk[3 * b] = 0; blk[3 * b + 1] = 0; blk[3 * b + 2] = 0;
+      wave_na[b] = 0;
     }
+    live = __ballot(act);
+  }
+  LT_MC_STAMP_AT(1, wave, 1, wall_clock64());
+  LT_MC_STAMP_AT(1, wave, 3, (unsigned long long)__popcll(live));
+  while (live) {
+  const int blkid = (__ffsll((long long)live) - 1) * n_waves + wave;  // (wave-uniform)
+  live &= live - 1;
+  const int row = blkid * 64 + lane;
+  unsigned na = 0, nv = 0, nt = 0;
+  // (a clean row writes nothing: its words hold 0 -- no active word of the last extraction is left, k_mc_clear)
+  const bool rowlive = row < n_rows && mc_rows_dirty(col_epoch, epoch, D, row);
+  const int rowc = min(row, n_rows - 1);
+  const int x = rowc / D.ny, y = rowc - x * D.ny;
+  // Triangles of a word = sum over its active cells of the case's count.  A lane walking its own cells is a chain of
+  // ~60 instructions and an LDS look-up per cell, and a row through a wall along z has 60 active cells a word: its wave
+  // waits for that one lane, and the launch for its slowest waves.  Words with more than LT_MC_HEAVY cells are therefore
+  // counted by the WAVE, a lane per cell: the owner's eight corner masks are broadcast (v_readlane), every lane looks up
+  // its cell, three ballots add the counts up (42 -> 38 us on the default volume).
+#define LT_MC_HEAVY 6
+  auto count_tris = [&](const mc_masks& M) -> unsigned {  // (called by all 64 lanes)
+    unsigned t = 0;
+    const bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
+    if (!heavy)
+      for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
+    for (u64 hm = __ballot(heavy); hm; hm &= hm - 1) {
+      const int r = __ffsll((long long)hm) - 1;  // (wave-uniform)
+      int cs = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u64 m = (i & 4) ? M.s[i & 1][(i >> 1) & 1] : M.m[i & 1][(i >> 1) & 1];
+        const u64 mr = (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)m, r) |
+                       ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m >> 32), r) << 32);
+        cs |= (int)((mr >> lane) & 1ull) << i;
+      }
+      const u64 ac = (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)M.ac, r) |
+                     ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(M.ac >> 32), r) << 32);
+      const unsigned n = ((ac >> lane) & 1ull) ? s_nt[cs] : 0u;  // (<= 5)
+      const unsigned tot = __popcll(__ballot(n & 1u)) + 2u * __popcll(__ballot(n & 2u)) + 4u * __popcll(__ballot(n & 4u));
+      if (lane == r) t = tot;
+    }
+    return t;
+  };
+  if (D.wz <= 4) {
+    // the sign words of the four rows (x + dx, y + dy), ALL loaded before the first is used -- a word's masks need
+    // its row neighbours' words at k and k + 1, so a loop over k loaded every word twice, in wz dependent rounds
+    const bool hx = x + 1 < D.nx, hy = y + 1 < D.ny;
+    u64 w[4][5];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dx = q & 1, dy = q >> 1;
+      const bool have = rowlive && (dx == 0 || hx) && (dy == 0 || hy);
+      const size_t base = (size_t)(rowc + (have ? dx * D.ny + dy : 0)) * D.wz;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[q][k] = (have && k < D.wz) ? bits[base + k] : 0ull;
+      w[q][4] = 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= D.wz) break;  // (wave-uniform)
+      u64 w8[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { w8[q] = w[q][k]; w8[q | 4] = w[q][k + 1]; }
+      const mc_masks M = mc_build(w8, D, x, y, k);  // (a row that is not live holds zeros: no edge, no cell)
+      const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
+      const unsigned t = count_tris(M);
+      if (rowlive) cnt[(size_t)row * D.wz + k] = v | (t << 16);
+      na += (v | t) ? 1u : 0u; nv += v; nt += t;
+    }
+  } else
+  for (int k = 0; k < D.wz; ++k) {
+    mc_masks M = mc_load(bits, D, x, y, k);
+    if (!rowlive) { M.ex = M.ey = M.ez = M.ac = 0ull; }
+    const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
+    const unsigned t = count_tris(M);
+    if (rowlive) cnt[(size_t)row * D.wz + k] = v | (t << 16);
+    na += (v | t) ? 1u : 0u; nv += v; nt += t;
   }
   u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 320 triangles -- the host checks wz)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-  if ((threadIdx.x & 63) == 0) {
-    const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lane == 0) {
     blk[3 * blkid] = (int)(p & 0xFFFFF);
     blk[3 * blkid + 1] = (int)((p >> 20) & 0xFFFFF);
     blk[3 * blkid + 2] = (int)((p >> 40) & 0xFFFFF);
     wave_na[blkid] = (int)(p & 0xFFFFF);
   }
+  }
+  LT_MC_STAMP_AT(1, wave, 2, wall_clock64());
 }
 
 // undo the last extraction's entries of cnt / cmap (its records are still there): both arrays are back to 0 / -1
@@ -353,12 +412,23 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
                                                     const unsigned* __restrict__ cnt, const int* __restrict__ blk,
                                                     const int* __restrict__ seg, int* __restrict__ cmap,
                                                     mc_rec* __restrict__ rec, int cap_rec,
-                                                    const int* __restrict__ wave_na) {
-  // thread = row, scan block = wave (as in k_mc_words); compact order = word order
-  const int row = blockIdx.x * 256 + threadIdx.x;
+                                                    const int* __restrict__ wave_na, int n_blocks) {
+  // thread = row, scan block = a wave's turn (as in k_mc_words, and dealt the same way); compact order = word order
   const int n_rows = D.nx * D.ny;
-  // no active word in these 64 rows (most waves): nothing to rank, and their cmap entries are -1 already (lt_mesh)
-  if (wave_na[blockIdx.x * 4 + (threadIdx.x >> 6)] == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  LT_MC_STAMP_AT(2, wave, 0, wall_clock64());
+  u64 live;
+  {  // no active word in a block's 64 rows (most): nothing to rank, and their cmap entries are -1 already (lt_mesh)
+    const int b = lane * n_waves + wave;
+    live = __ballot(lane < LT_MC_BLOCKS_PER_WAVE && b < n_blocks && wave_na[min(b, n_blocks - 1)] != 0);
+  }
+  LT_MC_STAMP_AT(2, wave, 1, wall_clock64());
+  LT_MC_STAMP_AT(2, wave, 3, (unsigned long long)__popcll(live));
+  while (live) {
+  const int blkid = (__ffsll((long long)live) - 1) * n_waves + wave;  // (wave-uniform)
+  live &= live - 1;
+  const int row = blkid * 64 + lane;
   unsigned na = 0, nv = 0, nt = 0;
   if (row < n_rows)
     for (int k = 0; k < D.wz; ++k) {
@@ -367,8 +437,7 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
     }
   const u64 mine = pack3(na, nv, nt);
   const u64 ex = wave_incl_scan(mine) - mine;
-  if (row >= n_rows) return;
-  const int blkid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) continue;
   const int* sg = seg + 3 * (blkid >> 8);
   int ci = sg[0] + blk[3 * blkid] + (int)(ex & 0xFFFFF);
   int vb = sg[1] + blk[3 * blkid + 1] + (int)((ex >> 20) & 0xFFFFF);
@@ -394,6 +463,8 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
     }
     cmap[w] = mine_ci;
   }
+  }
+  LT_MC_STAMP_AT(2, wave, 2, wall_clock64());
 }
 
 // ---- k_mc_emit --------------------------------------------------------------------------------------------------------
@@ -954,8 +1025,10 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     hipLaunchKernelGGL(k_mc_signs, dim3((unsigned)min((size_t)16384, ((size_t)nx * ny + 255) / 256)), dim3(256), 0, stream,
                        tsdf, D, m->bits, col_epoch, epoch);
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
-  hipLaunchKernelGGL(k_mc_words, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
-                     epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na);
+  // (a wave takes LT_MC_BLOCKS_PER_WAVE blocks, see k_mc_words)
+  const int sweep_wgs = lt_deal_count(n_blocks, LT_MC_BLOCKS_PER_WAVE, ny, 4) / 4;
+  hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
+                     epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na, n_blocks);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1001,8 +1074,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     LT_HIP(hipMalloc((void**)&m->faces, cap * 12));
     m->cap_f = (int)min(cap, (size_t)2147483647);
   }
-  hipLaunchKernelGGL(k_mc_compact, dim3(n_blocks / 4), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
-                     (int)min(m->cap_rec, (size_t)2147483647), m->wave_na);
+  hipLaunchKernelGGL(k_mc_compact, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
+                     (int)min(m->cap_rec, (size_t)2147483647), m->wave_na, n_blocks);
   static const bool emit_waves = []() {  // A/B: LIDARHIP_MC_EMIT=waves -> one wave per active word (k_mc_emit)
     const char* e = getenv("LIDARHIP_MC_EMIT");
     return e && strcmp(e, "waves") == 0;

@@ -218,7 +218,7 @@ __device__ __forceinline__ float sc_mt(const tri_rec& T, float ox, float oy, flo
 
 // The angular bounds below only have to be CONSERVATIVE (they are padded by >= 3e-4 rad), so they use the
 // hardware approximations (1 ulp rcp / sqrt) and a degree-11 minimax arctangent (max error 2e-6 rad) instead
-// of the IEEE sequences the triangle test itself needs: k_sc_tris is VALU bound.
+// of the IEEE sequences the triangle test itself needs (fewer instructions on the dependent chain of a workgroup).
 __device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float f_atan2(float y, float x) {
@@ -262,7 +262,7 @@ __device__ __forceinline__ float seg_dist2d_sq(float ax, float ay, float bx, flo
 
 // Addressing: with WIDE == false every array of a launch is smaller than 4 GB (the host checks), so element
 // addresses are base + 32-bit byte offset -- one VALU multiply instead of quarter-rate 64-bit multiply-adds on
-// the gather addresses of a VALU-bound kernel.
+// the gather addresses.
 template <class T>
 __device__ __forceinline__ unsigned byte_off(unsigned elem) {
   if (sizeof(T) == 12) {  // v_mul_lo_u32 is quarter rate and the optimiser folds (e << 3) + (e << 2) back into it
@@ -596,7 +596,7 @@ __device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_para
       // prefetch of the next candidate (index clamped to the last one: no lane-level branch, the load stays in flight
       // across the test) -- unless NO lane of the wave has one: round-robin dealing makes that wave-uniform up to the
       // one wave holding c_end, and the search + bin arithmetic of a prefetch nobody uses were 9 % of the kernel's
-      // vector instructions (k_sc_tris is VALU-issue bound)
+      // vector instructions
       const int cn = c + 256;
       unsigned jn4 = 0;
       float4 q2n = make_float4(0.f, 0.f, 0.f, 0.f), gn = make_float4(0.f, 0.f, 0.f, 0.f);

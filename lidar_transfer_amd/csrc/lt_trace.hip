@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_trace(
 
 // (mov_dpp = update_dpp with an UNDEFINED old value: every source lane of a quad permutation exists, so nothing is kept
 // from it -- with old = 0 the compiler set the destination to 0 before each of the ten permutations of a node step,
-// 10 % of the vector instructions of a kernel that is vector-issue bound)
+// 10 % of the vector instructions on the dependent chain of every node step)
 template <int CTRL>
 __device__ __forceinline__ int qperm_i(int v) {
   return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_tsdf_dct(const float* __restrict__ dept
 // it is enough that both ends of the walk decompose to cx -- voxel_y and voxel_z then follow in exact integer / small-float
 // arithmetic.  (Not plain: walks touching an x boundary of a volume of more than 2^24 voxels.)  For a plain walk the
 // column's share of the per-voxel expressions is computed once: the two IEEE divisions, two fused multiply-adds, the
-// product and the table look-up were a quarter of the vector instructions of a kernel that is VALU-issue bound
+// product and the table look-up were a quarter of the vector instructions of the column walk
 // (SQ_ACTIVE_INST_VALU: 71 % of its time; 439 -> 352 us on the default volume).
 struct col_plain {
   bool plain;
@@ -524,7 +524,12 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
 
 // re-initialise the dirty columns -- the z range that was actually written (col_zw, kept by integrate) -- and their sign
 // words: a wave reads 64 stamps at once and walks the dirty columns, four at a time (16 lanes each: a written range is
-// typically the truncation band, ~10 voxels)
+// typically the truncation band, ~10 voxels).
+// Three chunks in four of a street scene are clean: a wave takes LT_RESET_CHUNKS_PER_WAVE chunks, a stride apart (written
+// chunks come in clusters, lt_deal_count) -- its first lanes read one stamp each, a ballot finds the written ones.  (Not
+// faster than a wave per chunk, 23 against 25 us: a written chunk is a chain of three dependent round trips -- chunk stamp,
+// column stamps, column ranges -- of ~1.7 us each, and the kernel is as long as its slowest waves; but an eighth of the waves.)
+#define LT_RESET_CHUNKS_PER_WAVE 8
 __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
                                                          float* __restrict__ color, float* __restrict__ rem,
                                                          int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
@@ -534,8 +539,15 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
   const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
   const int n_chunks = (n_cols + 63) / 64;
   const int words_z = (dim_z + 63) / 64;
-  for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
-    if (chunk_epoch[chunk] != epoch) continue;  // (wave-uniform: no column of this chunk was written)
+  const int n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned long long live;
+  {
+    const int ch = lane * n_waves + wave;
+    live = __ballot(lane < LT_RESET_CHUNKS_PER_WAVE && ch < n_chunks && chunk_epoch[min(ch, n_chunks - 1)] == epoch);
+  }
+  while (live) {
+    const int chunk = (__ffsll((long long)live) - 1) * n_waves + wave;  // (wave-uniform)
+    live &= live - 1;
     const int c = chunk * 64 + lane;
     const bool dirty = c < n_cols && col_epoch[c] == epoch;
     unsigned zw = 0x7FFFu;  // (lo | hi << 16; empty)
@@ -956,6 +968,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
 // (prefix sum of the range lengths in LDS), the signs of what was written go to the columns' sign words as one OR and
 // one AND-NOT per run of lanes holding one column's word.  (First version: a wave per chunk, four columns per iteration
 // with 16 lanes each -- a wall's chunk kept its wave for 16 rounds, 138 us; a wave per 16 columns: 86 us.)
+#define LT_WRITTEN_CHUNKS_PER_WG 32
 template <bool MERGE>
 __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
@@ -967,10 +980,20 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
     const float2* __restrict__ dct, const unsigned* __restrict__ chunk_epoch) {
   __shared__ int w_lo[64], w_px[64], w_pre[65];
   __shared__ float w_rho2[64];
+  __shared__ unsigned long long w_live;
   const int tid = threadIdx.x, lane = tid & 63;
   const int n_cols = vol_dim_x * vol_dim_y, n_chunks = (n_cols + 63) / 64;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    if (chunk_epoch[chunk] != epoch) continue;  // (workgroup-uniform: nothing of this chunk has been written)
+  // a workgroup takes LT_WRITTEN_CHUNKS_PER_WG chunks, a stride apart (lt_deal_count); its first lanes read one stamp each
+  // (a workgroup per chunk was 250 000 waves on the default volume, most of which read a stamp and left: 72 -> 64 us)
+  if (tid < 64) {
+    const int ch = lane * (int)gridDim.x + (int)blockIdx.x;
+    const unsigned long long m =
+        __ballot(lane < LT_WRITTEN_CHUNKS_PER_WG && ch < n_chunks && chunk_epoch[min(ch, n_chunks - 1)] == epoch);
+    if (lane == 0) w_live = m;
+  }
+  __syncthreads();
+  for (unsigned long long live = w_live; live; live &= live - 1) {  // (workgroup-uniform)
+    const int chunk = (__ffsll((long long)live) - 1) * (int)gridDim.x + (int)blockIdx.x;
     if (tid < 64) {
       const int c = chunk * 64 + lane;
       int lo = 0, len = 0, px = 0;
@@ -1121,7 +1144,9 @@ extern "C" int lt_tsdf_reset(lt_tsdf* t, void* stream) {
   LT_HIP(hipSetDevice(t->device));
   if (t->all_dirty || t->epoch == 0xFFFFFFFFu) return tsdf_full_reset(t, (hipStream_t)stream);
   const int n_cols = t->dim[0] * t->dim[1];
-  hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)min((n_cols + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  const int n_chunks = (n_cols + 63) / 64;
+  hipLaunchKernelGGL(k_tsdf_reset_cols, dim3((unsigned)(lt_deal_count(n_chunks, LT_RESET_CHUNKS_PER_WAVE, t->dim[1], 4) / 4)),
+                     dim3(256), 0, (hipStream_t)stream,
                      t->tsdf, t->weight, t->color, t->rem, n_cols, t->dim[2], t->col_epoch, t->epoch, t->bits, t->col_zw,
                      t->chunk_epoch);
   LT_HIP(hipGetLastError());
@@ -1328,7 +1353,8 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
     if (!t->zw_snap) LT_HIP(hipMalloc((void**)&t->zw_snap, 2 * n_cols * sizeof(unsigned)));
     LT_HIP(hipMemcpyAsync(t->zw_snap, t->col_zw, 2 * n_cols * sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     zw_snap = t->zw_snap;
-    hipLaunchKernelGGL(k_tsdf_integrate_written<true>, dim3((unsigned)min((int)((n_cols + 63) / 64), 1 << 20)), dim3(256), 0,
+    hipLaunchKernelGGL(k_tsdf_integrate_written<true>,
+                       dim3((unsigned)lt_deal_count((int)((n_cols + 63) / 64), LT_WRITTEN_CHUNKS_PER_WG, t->dim[1], 1)), dim3(256), 0,
                        stream, t->tsdf, t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1],
                        t->origin[2], t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, color_im, depth_im,
                        rem_im, t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, zw_snap, t->dct, t->chunk_epoch);
