@@ -48,6 +48,18 @@ if os.environ.get("LIDARHIP_DEBUG_TSDF"):
         nwg = max(1, (H * W + 63) // 64)
         print("  per workgroup (100 MHz wall clock, mean us): phase A %.2f, A + first chunk's pairs + scan %.2f, voxel rounds %.2f (%d chunks)"
               % (c3[4] / nwg / 100.0, c3[5] / nwg / 100.0, c3[6] / max(1, c3[7]) / 100.0, c3[7]))
+if "--ranges" in sys.argv:
+    # how tight the per-column written ranges (min .. max z, what k_tsdf_integrate_written / reset walk) are around what was written
+    tv, wv, _, _ = vol.get_volume_tensors()
+    n_written = n_cols = n_range = 0
+    zs = torch.arange(tv.shape[2], device=dev)
+    for x0 in range(0, tv.shape[0], 100):
+        m = (tv[x0:x0 + 100] != 1) | (wv[x0:x0 + 100] != 0)
+        anyc = m.any(dim=2)
+        lo = torch.where(m, zs, tv.shape[2]).amin(dim=2)
+        hi = torch.where(m, zs, -1).amax(dim=2)
+        n_written += int(m.sum()); n_cols += int(anyc.sum()); n_range += int((hi - lo + 1)[anyc].sum())
+    print("written voxels %d in %d columns; sum of the columns' min..max ranges %d (x %.2f)" % (n_written, n_cols, n_range, n_range / max(1, n_written)))
 if "--count" in sys.argv:
     sc.set_device_mesh(mesh)
     st = sc.render(rs, (0, 0, 0), count=True)["stats"]
