@@ -213,3 +213,16 @@ def test_mesh_after_reset_and_reintegration_equals_oracle(oracle):
     got = [a.cpu().numpy() for a in vol.extract_mesh().tensors()]
     _assert_same_mesh(got, want)
     vol.close()
+
+
+def test_fusion_chains_in_flight_equal_the_single_chain():
+    """Output scans are independent (lidar_deform.py:393-462): three chains -- volume, mesh, scene, HIP stream and host thread
+    each -- run reset -> integrate (two observations) -> marching cubes -> render concurrently (tools/chain_pipeline.py, what
+    bench.py reports as fusion_chain.pipelined); every chain's final range / label image equals the single chain's."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import chain_pipeline
+    rec = chain_pipeline.run(chains=3, n=4, n_obs=2, device=0, workload="C1", warm=1, voxel=0.2)
+    assert rec["verified"] is True
+    assert rec["mesh_faces"] > 10000

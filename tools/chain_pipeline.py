@@ -15,7 +15,7 @@ from lidar_transfer_amd.raytracer import RaySet, Scene
 from lidar_transfer_amd.synth import WORKLOADS, synth_scene
 
 
-def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=2):
+def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=2, voxel=0.05):
     wl = WORKLOADS[workload]; H, W = wl["H"], wl["W"]; dev = torch.device("cuda", device)
     lib = _lib.load()
     mesh0 = [torch.from_numpy(x).to(dev) for x in synth_scene(0, wl["tris"])]
@@ -39,7 +39,7 @@ def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=2):
 
     class Chain:
         def __init__(self):
-            self.vol = TSDFVolume(bnds, 0.05, wl["fov_up"], wl["fov_down"])
+            self.vol = TSDFVolume(bnds, voxel, wl["fov_up"], wl["fov_down"])
             self.mesh = DeviceMesh(device)
             self.sc = Scene(device)
             self.out = self.sc.alloc_outputs(H * W)
@@ -72,17 +72,22 @@ def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=2):
                 for _ in range(warm):
                     c.scan()
                 c.stream.synchronize()
-                bar.wait()
+                bar.wait()  # (BrokenBarrierError if another chain failed: ends this one too)
                 for _ in range(n_each):
                     c.scan()
                 c.stream.synchronize()
+            except threading.BrokenBarrierError:
+                pass
             except BaseException as e:  # noqa: BLE001
                 errs.append(repr(e))
                 bar.abort()
         th = [threading.Thread(target=work, args=(c,)) for c in cs]
         for t in th:
             t.start()
-        bar.wait()
+        try:
+            bar.wait()
+        except threading.BrokenBarrierError:
+            pass  # (a chain failed in its warm-up: reported below)
         t0 = time.perf_counter()
         for t in th:
             t.join()
