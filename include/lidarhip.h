@@ -322,6 +322,20 @@ int lt_mesh_get(lt_mesh* mesh, int* n_verts, int* n_faces, float** verts, int** 
  * mesh where marching cubes wrote it -- no PCIe traffic between fusion and range image. */
 int lt_scene_set_mesh(lt_scene* scene, lt_mesh* mesh);
 
+/* One OUTPUT SCAN of the reference's `mesh` adaption in one call, nothing leaving HBM: a fresh volume (lt_tsdf_reset) <-
+ * n_obs observations (lt_tsdf_integrate_dev each; color_ims / depth_ims / rem_ims are HOST arrays of n_obs DEVICE
+ * pointers, images [im_h * im_w] f32) -> marching cubes into `mesh` -> lt_scene_set_mesh -> lt_scene_render_dev of
+ * `rayset` from `origin` (HOST, 3 floats) into the DEVICE output images (any may be NULL), and -- with sync != 0 -- a wait
+ * for `stream`.  Replaces the body of MultiSemLaserScan.deform's mesh branch per output scan (auxiliary/laserscan.py:
+ * 874-914: TSDFVolume(...) :886, integrate per scan :896-899, throw_rays_at_mesh :907 = get_mesh + C_Trace).  One call
+ * per scan is what lets several scans be in flight from several host threads of a Python caller (the interpreter lock is
+ * released for the whole chain): lidar_transfer_amd.pipeline.FusionScanPipeline.  Returns the first error of the chain. */
+int lt_fusion_scan_dev(lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* rayset, int n_obs,
+                       const float* const* color_ims, const float* const* depth_ims, const float* const* rem_ims,
+                       int im_h, int im_w, float obs_weight, unsigned tsdf_flags, const float* origin,
+                       float* endpoints, int* endcolors, float* range, float* endrem, int* tri, unsigned trace_flags,
+                       void* stream, int sync);
+
 /* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
 
 /* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new

@@ -1148,3 +1148,23 @@ extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {
   }
   return lt_scene_set_mesh_dev(s, m->verts, m->faces, m->colors, m->rem, m->n_verts, m->n_faces);
 }
+
+// One output scan of the `mesh` adaption (laserscan.py:874-914) in one call: see include/lidarhip.h.
+extern "C" int lt_fusion_scan_dev(lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* rayset, int n_obs,
+                                  const float* const* color_ims, const float* const* depth_ims,
+                                  const float* const* rem_ims, int im_h, int im_w, float obs_weight, unsigned tsdf_flags,
+                                  const float* origin, float* endpoints, int* endcolors, float* range, float* endrem,
+                                  int* tri, unsigned trace_flags, void* stream, int sync) {
+  if (!vol || !mesh || !scene || !rayset || !origin || n_obs < 0 || (n_obs > 0 && (!color_ims || !depth_ims || !rem_ims))) {
+    lt_set_error("lt_fusion_scan_dev: invalid argument");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_CHECK(lt_tsdf_reset(vol, stream));
+  for (int k = 0; k < n_obs; ++k)
+    LT_CHECK(lt_tsdf_integrate_dev(vol, color_ims[k], depth_ims[k], rem_ims[k], im_h, im_w, obs_weight, tsdf_flags, stream));
+  LT_CHECK(lt_tsdf_extract_mesh_dev(vol, mesh, stream, nullptr));
+  LT_CHECK(lt_scene_set_mesh(scene, mesh));
+  LT_CHECK(lt_scene_render_dev(scene, rayset, origin, endpoints, endcolors, range, endrem, tri, trace_flags, stream, nullptr));
+  if (sync) LT_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return LT_OK;
+}

@@ -260,3 +260,185 @@ class HostScanPipeline:
             self.close()
         except Exception:
             pass
+
+
+class FusionScanPipeline:
+    """The reference's ``mesh`` adaption per output scan -- fuse ``number_of_scans`` range images into a fresh TSDF volume
+    (laserscan.py:874-903), ``get_mesh`` (fusion_lidar.py:403-424), ``throw_rays_at_mesh`` (:426-455) -- entirely in HBM
+    and with ``chains`` output scans IN FLIGHT: output scans are independent (own volume, mesh and image,
+    lidar_deform.py:393-462), the chain's kernels are mostly sparse sweeps that leave the chip half empty (DESIGN.md
+    section 7c), and 4 x 3.2 GB per default volume is nothing in 288 GB.  Every chain owns a :class:`TSDFVolume`, a
+    :class:`DeviceMesh`, a :class:`Scene`, a HIP stream and a host thread; scans are dealt to the chains in turn.
+
+        pipe = FusionScanPipeline(vol_bnds, voxel_size, fov_up, fov_down, rays, H)   # source fov; target rays [H*W,3] CUDA
+        t = pipe.submit([(color_im, depth_im, rem_im), ...], origin)   # CUDA tensors; color_im [h,w,3] or folded [h,w]
+        ...
+        out = pipe.wait(t)     # dict of CUDA tensors: endpoints, endcolors, range, endrem, tri; 'n_verts', 'n_faces'
+        pipe.close()
+
+    The observation tensors must be COMPLETE when a chain reads them: by default ``submit`` waits (on the host) for the
+    caller's current stream; a caller whose images are finished anyway passes ``inputs_ready=True``.  The tensors are kept
+    referenced until the scan is done; the images are complete when ``wait`` returns.  A scan is ONE native call
+    (``lt_fusion_scan_dev``) on its chain's thread, so the interpreter lock is free while the GPU works."""
+
+    def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, rays, H, chains=3, device=None, merge=True,
+                 label_image=False):
+        import queue
+        import threading
+
+        import torch
+
+        from .fusion import DeviceMesh, TSDFVolume
+        if chains < 1:
+            raise ValueError("chains: at least one")
+        self._torch = torch
+        self._lib = _lib.load()
+        self.device = rays.device if device is None else torch.device("cuda", device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.rayset = RaySet(rays, H)  # one read-only ray set for all chains
+        self.n_rays = self.rayset.n_rays
+        self.label_image = bool(label_image)
+        self._flags = _lib.LT_TRACE_WRITE_MISSES | (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0)
+        self._merge = _lib.LT_TSDF_MERGE if merge else 0
+        self._chains = []
+        for _ in range(int(chains)):
+            ch = dict(vol=TSDFVolume(vol_bnds, voxel_size, fov_up, fov_down, device=idx, merge=merge),
+                      mesh=DeviceMesh(idx), scene=Scene(idx), stream=torch.cuda.Stream(self.device), q=queue.Queue())
+            ch["thread"] = threading.Thread(target=self._work, args=(ch,), daemon=True)
+            self._chains.append(ch)
+        self._lock = threading.Lock()
+        self._done = {}    # ticket -> threading.Event
+        self._result = {}  # ticket -> outputs dict | exception
+        self._next = 0
+        for ch in self._chains:
+            ch["thread"].start()
+
+    # ---- a chain's thread ---------------------------------------------------------------------------------------------
+    def _scan(self, ch, obs, origin, out):
+        torch, lib = self._torch, self._lib
+        st = ch["stream"]
+        keep = []
+        n = len(obs)
+        vp = C.c_void_p
+        cp, dp, rp = (vp * max(n, 1))(), (vp * max(n, 1))(), (vp * max(n, 1))()
+        with torch.cuda.stream(st):
+            if out is None:
+                out = ch["scene"].alloc_outputs(self.n_rays, label_image=self.label_image)
+            h = w = 0
+            for k, (color_im, depth_im, rem_im) in enumerate(obs):
+                c = color_im
+                if c.dim() == 3:  # fold RGB into one channel (fusion_lidar.py:261-264), float32 like the reference
+                    c = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2])
+                c = c.to(torch.float32).contiguous()
+                d = depth_im.to(torch.float32).contiguous()
+                r = rem_im.to(torch.float32).contiguous()
+                if k and (d.shape[0], d.shape[1]) != (h, w):
+                    raise ValueError("observations of one output scan must have one image shape")
+                h, w = d.shape[0], d.shape[1]
+                keep += [c, d, r]
+                cp[k], dp[k], rp[k] = c.data_ptr(), d.data_ptr(), r.data_ptr()
+        org = (C.c_float * 3)(*[float(x) for x in origin])
+
+        def p(key):
+            a = out.get(key)
+            return a.data_ptr() if a is not None else None
+        # the whole chain of the scan in ONE native call: the interpreter lock is released for all of it.  The call
+        # returns with the render QUEUED (it waits for the stream once, inside marching cubes: the mesh sizes); an event
+        # behind the render is what wait() waits for, so the chain's next scan is queued while this one still renders.
+        _lib.check(lib.lt_fusion_scan_dev(ch["vol"]._h, ch["mesh"]._h, ch["scene"]._h, self.rayset._h, n, cp, dp, rp, h, w,
+                                          1.0, self._merge, org, p("endpoints"), p("endcolors"), p("range"), p("endrem"),
+                                          p("tri"), self._flags, vp(st.cuda_stream), 0), "lt_fusion_scan_dev")
+        done = torch.cuda.Event()
+        done.record(st)
+        res = dict(out)
+        res["n_verts"], res["n_faces"] = ch["mesh"].n_verts, ch["mesh"].n_faces
+        res["_done"] = (done, keep, obs)  # (temporaries and observations stay referenced until the event has passed)
+        return res
+
+    def _work(self, ch):
+        self._torch.cuda.set_device(self.device)
+        while True:
+            job = ch["q"].get()
+            if job is None:
+                return
+            ticket, obs, origin, out = job
+            try:
+                res = self._scan(ch, obs, origin, out)
+            except BaseException as e:  # noqa: BLE001  (handed to the waiter)
+                res = e
+            with self._lock:
+                self._result[ticket] = res
+                ev = self._done[ticket]
+            ev.set()
+
+    # ---- caller's side --------------------------------------------------------------------------------------------------
+    def submit(self, observations, origin=(0.0, 0.0, 0.0), out=None, inputs_ready=False):
+        """Queue one output scan: ``observations`` = the (color_im, depth_im, rem_im) CUDA tensors fused into its volume,
+        in order.  Returns the ticket.  ``out``: a dict like ``Scene.alloc_outputs`` returns (missing keys are not written).
+        ``inputs_ready``: the caller guarantees that the observation tensors are complete (no wait for its stream)."""
+        import threading
+        torch = self._torch
+        if not self._chains:
+            raise RuntimeError("FusionScanPipeline.submit: the pipeline is closed")
+        obs = [tuple(o) for o in observations]
+        for o in obs:
+            if len(o) != 3 or not all(isinstance(a, torch.Tensor) and a.is_cuda for a in o):
+                raise ValueError("observations: (color_im, depth_im, rem_im) CUDA tensors")
+        if not inputs_ready:
+            torch.cuda.current_stream(self.device).synchronize()  # (see the class docstring)
+        with self._lock:
+            t = self._next
+            self._next += 1
+            self._done[t] = threading.Event()
+        self._chains[t % len(self._chains)]["q"].put((t, obs, tuple(origin), out))
+        return t
+
+    def wait(self, ticket):
+        """Images of the scan with this ticket (complete when the call returns).  A ticket is handed out once."""
+        ticket = int(ticket)
+        with self._lock:
+            ev = self._done.get(ticket)
+        if ev is None:
+            raise KeyError(f"FusionScanPipeline.wait: ticket {ticket} is unknown or was already collected")
+        ev.wait()
+        with self._lock:
+            res = self._result.pop(ticket)
+            del self._done[ticket]
+        if isinstance(res, BaseException):
+            raise res
+        res.pop("_done")[0].synchronize()
+        return res
+
+    def flush(self):
+        """Complete every submitted scan; their images stay collectable with :meth:`wait`."""
+        with self._lock:
+            evs = list(self._done.values())
+        for ev in evs:
+            ev.wait()
+        for ch in self._chains:
+            ch["stream"].synchronize()
+
+    def close(self):
+        chains, self._chains = getattr(self, "_chains", []), []
+        for ch in chains:
+            ch["q"].put(None)
+        for ch in chains:
+            ch["thread"].join()
+            ch["mesh"].close()
+            ch["scene"].close()
+            ch["vol"].close()
+        if getattr(self, "rayset", None) is not None and chains:
+            self.rayset.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

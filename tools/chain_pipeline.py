@@ -1,118 +1,80 @@
 #!/usr/bin/env python3
 """The fusion chain (reset -> integrate -> marching cubes -> render, mesh never leaves HBM) with SEVERAL output scans in
-flight: every output scan of the reference's loop has its own volume, mesh and image (lidar_deform.py:393-462), so `chains`
-host threads each run the chain for their own scans on their own HIP stream, volume, mesh and scene.  The kernels of the chain
-are mostly sparse sweeps that leave the chip half empty; chains in flight fill each other's gaps.
+flight: lidar_transfer_amd.pipeline.FusionScanPipeline -- every output scan of the reference's loop has its own volume,
+mesh and image (lidar_deform.py:393-462), so `chains` host threads each run the chain for their own scans on their own HIP
+stream, volume, mesh and scene.  The kernels of the chain are mostly sparse sweeps that leave the chip half empty
+(DESIGN.md section 7c); chains in flight fill each other's gaps.
     python tools/chain_pipeline.py [chains [scans per chain [observations]]]     -> one JSON line
-Every chain's last range / label image is compared bit for bit with the single chain's."""
-import ctypes as C, json, os, sys, threading, time
+Every scan's range / label image is compared bit for bit with the single chain's."""
+import gc, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from lidar_transfer_amd import _lib
-from lidar_transfer_amd.fusion import DeviceMesh, TSDFVolume
 from lidar_transfer_amd.laserscan import create_rays
+from lidar_transfer_amd.pipeline import FusionScanPipeline
 from lidar_transfer_amd.raytracer import RaySet, Scene
 from lidar_transfer_amd.synth import WORKLOADS, synth_scene
 
 
-def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=2, voxel=0.05):
+def run(chains=3, n=12, n_obs=1, device=0, workload="C2", warm=8, voxel=0.05):
     wl = WORKLOADS[workload]; H, W = wl["H"], wl["W"]; dev = torch.device("cuda", device)
-    lib = _lib.load()
+    torch.cuda.set_device(dev)
     mesh0 = [torch.from_numpy(x).to(dev) for x in synth_scene(0, wl["tris"])]
     rays = torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev)
     rs = RaySet(rays, H)
     sc0 = Scene(device); sc0.set_mesh(*mesh0)
     o = sc0.render(rs, (0, 0, 0)); torch.cuda.synchronize()
+    # the observation: this very sensor looking at scene 0; label in channel 0 (laserscan.py:893-895), folded
     folded = (o["endcolors"][:, 2].reshape(H, W).float() * 65536.0).contiguous()
     depth = o["range"].reshape(H, W).clone(); remi = o["endrem"].reshape(H, W).clone()
     gen = torch.Generator(device=dev); gen.manual_seed(1234)
-    obs = [(folded, depth)]
-    for k in range(1, n_obs):
+    obs = [(folded, depth, remi)]
+    for k in range(1, n_obs):  # the neighbouring scans re-projected into the primary pose: noise, holes, a few other labels
         noise = (torch.rand((H, W), device=dev, generator=gen) - 0.5) * 0.04
         hole = torch.rand((H, W), device=dev, generator=gen) < 0.05
         flip = torch.rand((H, W), device=dev, generator=gen) < 0.02
         obs.append((torch.where(flip, torch.full_like(folded, 50.0 * 65536.0), folded).contiguous(),
-                    torch.where(hole | (depth == 0), torch.zeros_like(depth), depth + noise).contiguous()))
+                    torch.where(hole | (depth == 0), torch.zeros_like(depth), depth + noise).contiguous(), remi))
     torch.cuda.synchronize()
-    org = (C.c_float * 3)(0, 0, 0)
+    sc0.close(); rs.close()
     bnds = np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]])
 
-    class Chain:
-        def __init__(self):
-            self.vol = TSDFVolume(bnds, voxel, wl["fov_up"], wl["fov_down"])
-            self.mesh = DeviceMesh(device)
-            self.sc = Scene(device)
-            self.out = self.sc.alloc_outputs(H * W)
-            self.stream = torch.cuda.Stream(dev)
-            self.sp = C.c_void_p(self.stream.cuda_stream)
-
-        def scan(self):
-            _lib.check(lib.lt_tsdf_reset(self.vol._h, self.sp), "reset")
-            for f_k, d_k in obs:
-                _lib.check(lib.lt_tsdf_integrate_dev(self.vol._h, f_k.data_ptr(), d_k.data_ptr(), remi.data_ptr(), H, W, 1.0,
-                                                     _lib.LT_TSDF_MERGE, self.sp), "integrate")
-            _lib.check(lib.lt_tsdf_extract_mesh_dev(self.vol._h, self.mesh._h, self.sp, None), "marching cubes")
-            _lib.check(lib.lt_scene_set_mesh(self.sc._h, self.mesh._h), "set mesh")
-            o = self.out
-            _lib.check(lib.lt_scene_render_dev(self.sc._h, rs._h, org, o["endpoints"].data_ptr(), o["endcolors"].data_ptr(),
-                                               o["range"].data_ptr(), o["endrem"].data_ptr(), o["tri"].data_ptr(),
-                                               _lib.LT_TRACE_WRITE_MISSES, self.sp, None), "render")
-
-        def close(self):
-            self.mesh.close(); self.vol.close()
-
-    def timed(cs, n_each):
-        """wall time of n_each scans on every chain of cs, all in flight together"""
-        bar = threading.Barrier(len(cs) + 1)
-        errs = []
-
-        def work(c):
+    def timed(n_chains):
+        """wall time of n scans per chain, all submitted at once; the images of every scan"""
+        with FusionScanPipeline(bnds, voxel, wl["fov_up"], wl["fov_down"], rays, H, chains=n_chains, device=device) as pipe:
+            for t in [pipe.submit(obs, inputs_ready=True) for _ in range(warm * n_chains)]:
+                pipe.wait(t)
+            # (the images of every timed scan are kept for the comparison below: allocated BEFORE the clock -- fresh device
+            # memory inside the timed region would be hipMalloc calls, not the caching allocator's recycling)
+            bufs = [pipe._chains[0]["scene"].alloc_outputs(pipe.n_rays) for _ in range(n * n_chains)]
+            torch.cuda.synchronize()
+            # (no collector pass inside the clock: with torch's object graph a full collection is a 30-60 ms pause that
+            # holds the interpreter lock -- it landed in the first scans of a burst and looked like a GPU stall)
+            gc.collect()
+            gc.disable()
             try:
-                torch.cuda.set_device(dev)
-                for _ in range(warm):
-                    c.scan()
-                c.stream.synchronize()
-                bar.wait()  # (BrokenBarrierError if another chain failed: ends this one too)
-                for _ in range(n_each):
-                    c.scan()
-                c.stream.synchronize()
-            except threading.BrokenBarrierError:
-                pass
-            except BaseException as e:  # noqa: BLE001
-                errs.append(repr(e))
-                bar.abort()
-        th = [threading.Thread(target=work, args=(c,)) for c in cs]
-        for t in th:
-            t.start()
-        try:
-            bar.wait()
-        except threading.BrokenBarrierError:
-            pass  # (a chain failed in its warm-up: reported below)
-        t0 = time.perf_counter()
-        for t in th:
-            t.join()
-        dt = time.perf_counter() - t0
-        if errs:
-            raise RuntimeError(errs[0])
-        return dt
+                t0 = time.perf_counter()
+                tickets = [pipe.submit(obs, out=b, inputs_ready=True) for b in bufs]  # (synchronised above)
+                outs = [pipe.wait(t) for t in tickets]
+                dt = time.perf_counter() - t0
+            finally:
+                gc.enable()
+            nvol = int(np.prod(pipe._chains[0]["vol"]._vol_dim))
+        return dt, outs, nvol
 
-    cs = [Chain() for _ in range(chains)]
-    t1 = timed(cs[:1], n)
-    ref_range = cs[0].out["range"].clone(); ref_label = cs[0].out["endcolors"].clone()
-    tn = timed(cs, n)
-    torch.cuda.synchronize()
-    same = all(torch.equal(c.out["range"], ref_range) and torch.equal(c.out["endcolors"], ref_label) for c in cs)
+    tn, outs, nvol = timed(chains)
+    t1, outs1, _ = timed(1)
+    ref_range, ref_label, faces = outs1[-1]["range"], outs1[-1]["endcolors"], outs1[-1]["n_faces"]
+    same = all(torch.equal(q["range"], ref_range) and torch.equal(q["endcolors"], ref_label) and q["n_faces"] == faces
+               for q in outs)
     R = H * W
-    rec = {"chains_in_flight": chains, "scans_per_chain": n, "observations": n_obs,
-           "one_chain_ms_per_scan": round(t1 / n * 1e3, 4),
-           "ms_per_scan": round(tn / (n * chains) * 1e3, 4), "scans_per_s": round(n * chains / tn, 1),
-           "value": round(R * n * chains / tn / 1e6, 2), "unit": "Mrays/s",
-           "gain_over_one_chain": round((t1 / n) / (tn / (n * chains)), 3),
-           "verified": bool(same), "mesh_faces": cs[0].mesh.n_faces,
-           "hbm_resident_GB": round(chains * 4 * np.prod(cs[0].vol._vol_dim) * 4 / 2**30, 1)}
-    for c in cs:
-        c.close()
-    return rec
+    return {"chains_in_flight": chains, "scans_per_chain": n, "observations": n_obs,
+            "one_chain_ms_per_scan": round(t1 / n * 1e3, 4),
+            "ms_per_scan": round(tn / (n * chains) * 1e3, 4), "scans_per_s": round(n * chains / tn, 1),
+            "value": round(R * n * chains / tn / 1e6, 2), "unit": "Mrays/s",
+            "gain_over_one_chain": round((t1 / n) / (tn / (n * chains)), 3),
+            "verified": bool(same), "scans_verified": len(outs), "mesh_faces": int(faces),
+            "hbm_resident_GB": round(chains * 4 * nvol * 4 / 2**30, 1),
+            "api": "lidar_transfer_amd.pipeline.FusionScanPipeline"}
 
 
 if __name__ == "__main__":
