@@ -1043,24 +1043,27 @@ def main():
     e2e = guarded("e2e_single_call", e2e_host_call) if (rank == 0 and world == 1 and not args.no_e2e) else None
     if e2e:
         e2e = {"single_call": e2e, "pipelined": guarded("e2e_pipelined", e2e_pipelined)}
-    chain = guarded("fusion_chain", fusion_chain) if (rank == 0 and not args.no_chain and world == 1) else None
-    chain5 = guarded("fusion_chain_nscans5", fusion_chain, 4, 5) if (chain and rank == 0 and world == 1) else None
-
-    def fusion_chain_pipelined(chains=3, n=12, nscans=1):
-        """The same chain with `chains` output scans in flight (own volume, mesh, scene, HIP stream and host thread each --
-        output scans are independent, lidar_deform.py:393-462): the chain's sparse sweeps leave the chip half empty, scans
-        in flight fill each other's gaps.  tools/chain_pipeline.py; every chain's last images are compared bit for bit
-        with the single chain's (`verified`)."""
+    def fusion_chain_pipelined(chains=3):
+        """The same chain with `chains` output scans in flight (lidar_transfer_amd.pipeline.FusionScanPipeline: own volume,
+        mesh, scene, HIP stream and host thread each -- output scans are independent, lidar_deform.py:393-462): the chain's
+        sparse sweeps leave the chip half empty, scans in flight fill each other's gaps.  tools/chain_pipeline.py; one and
+        five observations per scan on the same pipeline; every timed scan's images are compared bit for bit with the
+        single chain's (`verified`).  Runs BEFORE the single-chain legs: its 38 GB of volumes should be the process's
+        first big allocation."""
         if torch.cuda.get_device_properties(dev).total_memory < 100 * 2**30:
             return None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import chain_pipeline
-        return chain_pipeline.run(chains, n, nscans, local_rank, args.workload)
+        return chain_pipeline.run_cases(chains, ((12, 1), (6, 5)), local_rank, args.workload)
+
+    pipelined = guarded("fusion_chain_pipelined", fusion_chain_pipelined) if (rank == 0 and not args.no_chain and world == 1) else None
+    chain = guarded("fusion_chain", fusion_chain) if (rank == 0 and not args.no_chain and world == 1) else None
+    chain5 = guarded("fusion_chain_nscans5", fusion_chain, 4, 5) if (chain and rank == 0 and world == 1) else None
 
     if chain:
-        chain["pipelined"] = guarded("fusion_chain_pipelined", fusion_chain_pipelined)
+        chain["pipelined"] = (pipelined or [None, None])[0]
     if chain5:
-        chain5["pipelined"] = guarded("fusion_chain_nscans5_pipelined", fusion_chain_pipelined, 3, 6, 5)
+        chain5["pipelined"] = (pipelined or [None, None])[1]
     if rank == 0:
         value = world * K * R / dt / 1e6
         rl = roofline(args.strategy, ser_ms, kern_ms)
