@@ -282,3 +282,48 @@ def test_fusion_scan_pipeline_equals_the_step_by_step_api():
         with pytest.raises(ValueError):
             pipe.submit([(np.zeros((H, W)), scans[0][0][1], scans[0][0][2])])
     rs.close(); sc.close()
+
+
+def test_bare_lt_fusion_scan_dev_symbol_edge_cases():
+    """The native per-scan entry point through ctypes: no observation at all (a fresh volume: no surface, every ray a miss,
+    outputs written as misses), NULL handles / NULL image arrays (error code + message, nothing launched), and a scan
+    whose only observation is empty (all depths 0: the reference leaves at depth_value == 0)."""
+    import ctypes as C
+    import torch
+    from lidar_transfer_amd import _lib
+    from lidar_transfer_amd.fusion import DeviceMesh, TSDFVolume
+    from lidar_transfer_amd.laserscan import create_rays
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    H, W = 16, 128
+    rays = torch.from_numpy(create_rays(10.0, -20.0, H, W)).to(dev)
+    rs = RaySet(rays, H)
+    vol = TSDFVolume(np.array([[-6.4, 6.4], [-6.4, 6.4], [-1.6, 1.6]]), 0.1, 10.0, -20.0)
+    mesh, sc = DeviceMesh(0), Scene(0)
+    out = sc.alloc_outputs(H * W)
+    for v in out.values():
+        v.fill_(7)
+    st = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(st.cuda_stream)
+    org = (C.c_float * 3)(0, 0, 0)
+    vp = C.c_void_p
+    none = (vp * 1)()
+
+    def call(vol_h, n_obs, cp, dp, rp):
+        return lib.lt_fusion_scan_dev(vol_h, mesh._h, sc._h, rs._h, n_obs, cp, dp, rp, H, W, 1.0, _lib.LT_TSDF_MERGE, org,
+                                      out["endpoints"].data_ptr(), out["endcolors"].data_ptr(), out["range"].data_ptr(),
+                                      out["endrem"].data_ptr(), out["tri"].data_ptr(), _lib.LT_TRACE_WRITE_MISSES, sp, 1)
+    assert call(vol._h, 0, None, None, None) == 0
+    assert mesh.n_faces == 0 and mesh.n_verts == 0
+    assert int((out["range"] != 0).sum()) == 0 and int((out["tri"] != -1).sum()) == 0
+    assert call(None, 0, None, None, None) != 0 and b"lt_fusion_scan_dev" in lib.lt_last_error()
+    assert call(vol._h, 1, None, None, None) != 0
+    z = torch.zeros((H, W), device=dev)
+    cp, dp, rp = (vp * 1)(z.data_ptr()), (vp * 1)(z.data_ptr()), (vp * 1)(z.data_ptr())
+    for v in out.values():
+        v.fill_(7)
+    assert call(vol._h, 1, cp, dp, rp) == 0
+    assert mesh.n_faces == 0 and int((out["range"] != 0).sum()) == 0
+    del none
+    mesh.close(); sc.close(); vol.close(); rs.close()
