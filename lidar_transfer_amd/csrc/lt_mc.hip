@@ -225,7 +225,9 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
 // blocks on average, 4 at most).  What the kernel's time is made of (per-wave wall-clock stamps, tools/mc_wave_times.py):
 // a live block is a chain of four dependent round trips to cold memory -- case table, chunk flags, the rows' stamps, the
 // sign words: ~1.7 us each -- plus the cell loops: 7.6 us for a wave with one block, 11 us with two; the slots are 0.2 busy.
+#ifndef LT_MC_BLOCKS_PER_WAVE
 #define LT_MC_BLOCKS_PER_WAVE 8
+#endif
 __device__ __forceinline__ bool mc_block_live(const unsigned* __restrict__ chunk_epoch, unsigned epoch, const mc_dims& D,
                                               int b, int n_chunks) {
   if (!chunk_epoch) return true;

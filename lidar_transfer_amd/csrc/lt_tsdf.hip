@@ -529,7 +529,9 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
 // chunks come in clusters, lt_deal_count) -- its first lanes read one stamp each, a ballot finds the written ones.  (Not
 // faster than a wave per chunk, 23 against 25 us: a written chunk is a chain of three dependent round trips -- chunk stamp,
 // column stamps, column ranges -- of ~1.7 us each, and the kernel is as long as its slowest waves; but an eighth of the waves.)
+#ifndef LT_RESET_CHUNKS_PER_WAVE
 #define LT_RESET_CHUNKS_PER_WAVE 8
+#endif
 __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsdf, float* __restrict__ weight,
                                                          float* __restrict__ color, float* __restrict__ rem,
                                                          int n_cols, int dim_z, const unsigned* __restrict__ col_epoch,
@@ -968,7 +970,17 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
 // (prefix sum of the range lengths in LDS), the signs of what was written go to the columns' sign words as one OR and
 // one AND-NOT per run of lanes holding one column's word.  (First version: a wave per chunk, four columns per iteration
 // with 16 lanes each -- a wall's chunk kept its wave for 16 rounds, 138 us; a wave per 16 columns: 86 us.)
-#define LT_WRITTEN_CHUNKS_PER_WG 32
+// debug (-DLT_TSDF_STAMP; tools/tsdf_written_times.py): per workgroup of k_tsdf_integrate_written -- wall clock (100 MHz) at its
+// start and end, time spent in the chunks' prologues (ranges -> LDS) and in their voxel rounds, written chunks walked
+#ifdef LT_TSDF_STAMP
+__device__ unsigned long long g_tsdf_stamp[5 << 12];
+extern "C" int lt_debug_tsdf_stamps(unsigned long long* out, int n_wgs) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tsdf_stamp), (size_t)min(n_wgs, 1 << 12) * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifndef LT_WRITTEN_CHUNKS_PER_WG
+#define LT_WRITTEN_CHUNKS_PER_WG 8  // (swept 4 .. 32 on the default volume: 62 / 58 / 70 / 71 us)
+#endif
 template <bool MERGE>
 __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
@@ -984,7 +996,13 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
   const int tid = threadIdx.x, lane = tid & 63;
   const int n_cols = vol_dim_x * vol_dim_y, n_chunks = (n_cols + 63) / 64;
   // a workgroup takes LT_WRITTEN_CHUNKS_PER_WG chunks, a stride apart (lt_deal_count); its first lanes read one stamp each
-  // (a workgroup per chunk was 250 000 waves on the default volume, most of which read a stamp and left: 72 -> 64 us)
+  // (a workgroup per chunk was 250 000 waves on the default volume, most of which read a stamp and left: 72 -> 58-64 us.
+  // Per-workgroup stamps, tools/tsdf_written_times.py: a written chunk holds ~114 voxels in its columns' ranges and costs
+  // 1.4 us of prologue + 3.3 us of voxel rounds; the launch is its slowest workgroups, not its work)
+#ifdef LT_TSDF_STAMP
+  const unsigned long long st_t0 = wall_clock64();
+  unsigned long long st_pro = 0, st_ev = 0, st_n = 0;
+#endif
   if (tid < 64) {
     const int ch = lane * (int)gridDim.x + (int)blockIdx.x;
     const unsigned long long m =
@@ -994,6 +1012,9 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
   __syncthreads();
   for (unsigned long long live = w_live; live; live &= live - 1) {  // (workgroup-uniform)
     const int chunk = (__ffsll((long long)live) - 1) * (int)gridDim.x + (int)blockIdx.x;
+#ifdef LT_TSDF_STAMP
+    const unsigned long long st_a = wall_clock64();
+#endif
     if (tid < 64) {
       const int c = chunk * 64 + lane;
       int lo = 0, len = 0, px = 0;
@@ -1022,6 +1043,10 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
       if (lane == 63) w_pre[64] = inc;
     }
     __syncthreads();
+#ifdef LT_TSDF_STAMP
+    const unsigned long long st_b = wall_clock64();
+    st_pro += st_b - st_a; st_n += 1;
+#endif
     const int V = w_pre[64];
     for (int jb = 0; jb < V; jb += 256) {  // (workgroup-uniform trips: the run aggregation below shuffles)
       const int j = jb + tid;
@@ -1056,7 +1081,17 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
       }
     }
     __syncthreads();  // the chunk's arrays are reused
+#ifdef LT_TSDF_STAMP
+    st_ev += wall_clock64() - st_b;
+    st_n += (unsigned long long)V << 16;
+#endif
   }
+#ifdef LT_TSDF_STAMP
+  if (tid == 0 && blockIdx.x < (1 << 12)) {
+    unsigned long long* o = g_tsdf_stamp + 5 * blockIdx.x;
+    o[0] = st_t0; o[1] = wall_clock64(); o[2] = st_pro; o[3] = st_ev; o[4] = st_n;
+  }
+#endif
 }
 
 // the columns that are not in the wedge table (k_wd_keys: quirk), one thread per voxel, by the reference's own
