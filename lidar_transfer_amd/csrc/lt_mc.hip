@@ -224,7 +224,8 @@ __device__ __forceinline__ bool mc_rows_dirty(const unsigned* __restrict__ col_e
 // waves + wave, lt_deal_count): written chunks come in clusters, dealt this way every wave gets its share (1.4 live
 // blocks on average, 4 at most).  What the kernel's time is made of (per-wave wall-clock stamps, tools/mc_wave_times.py):
 // a live block is a chain of four dependent round trips to cold memory -- case table, chunk flags, the rows' stamps, the
-// sign words: ~1.7 us each -- plus the cell loops: 7.6 us for a wave with one block, 11 us with two; the slots are 0.2 busy.
+// sign words: 0.9 us each in this kernel, 0.35 us on an idle chip -- plus 3-4 us of cell loops for the slowest lane: 7.6 us
+// for a wave with one block, 11 us with two; the slots are 0.2 busy.
 #ifndef LT_MC_BLOCKS_PER_WAVE
 #define LT_MC_BLOCKS_PER_WAVE 8
 #endif

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
 // Three chunks in four of a street scene are clean: a wave takes LT_RESET_CHUNKS_PER_WAVE chunks, a stride apart (written
 // chunks come in clusters, lt_deal_count) -- its first lanes read one stamp each, a ballot finds the written ones.  (Not
 // faster than a wave per chunk, 23 against 25 us: a written chunk is a chain of three dependent round trips -- chunk stamp,
-// column stamps, column ranges -- of ~1.7 us each, and the kernel is as long as its slowest waves; but an eighth of the waves.)
+// column stamps, column ranges -- and the kernel is as long as its slowest waves; but an eighth of the waves.)
 #ifndef LT_RESET_CHUNKS_PER_WAVE
 #define LT_RESET_CHUNKS_PER_WAVE 8
 #endif
