@@ -278,13 +278,34 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
   // ~60 instructions and an LDS look-up per cell, and a row through a wall along z has 60 active cells a word: its wave
   // waits for that one lane, and the launch for its slowest waves.  Words with more than LT_MC_HEAVY cells are therefore
   // counted by the WAVE, a lane per cell: the owner's eight corner masks are broadcast (v_readlane), every lane looks up
-  // its cell, three ballots add the counts up (42 -> 38 us on the default volume).
-#define LT_MC_HEAVY 6
+  // its cell, three ballots add the counts up (42 -> 32 us on the default volume, with the threshold swept and the lanes'
+  // own loops on 32-bit half words).
+#ifndef LT_MC_HEAVY
+#define LT_MC_HEAVY 16  // (swept on the default volume: 2: 50 us, 4: 39, 6: 38, 10 .. 24: 32-33, 40: 35, never: 39)
+#endif
   auto count_tris = [&](const mc_masks& M) -> unsigned {  // (called by all 64 lanes)
     unsigned t = 0;
     const bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
-    if (!heavy)
-      for (u64 a = M.ac; a; a &= a - 1) t += s_nt[mc_case(M, __ffsll((long long)a) - 1)];
+    if (!heavy) {
+      // the word's halves one after the other: with 32-bit masks a cell is 8 x (v_bfe_u32, v_lshl_or_b32) + a 32-bit
+      // find-first / clear-lowest, a third of the instructions of the 64-bit shifts of mc_case
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned a = (unsigned)(M.ac >> (32 * h));
+        if (a == 0u) continue;
+        unsigned m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          m[i] = (unsigned)(((i & 4) ? M.s[i & 1][(i >> 1) & 1] : M.m[i & 1][(i >> 1) & 1]) >> (32 * h));
+        for (; a; a &= a - 1) {
+          const int b = __ffs((int)a) - 1;
+          unsigned cs = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cs |= ((m[i] >> b) & 1u) << i;
+          t += s_nt[cs];
+        }
+      }
+    }
     for (u64 hm = __ballot(heavy); hm; hm &= hm - 1) {
       const int r = __ffsll((long long)hm) - 1;  // (wave-uniform)
       int cs = 0;
