@@ -722,7 +722,6 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     (void)mine;
   }
   __syncthreads();
-  const u64 lm = (1ull << lane) - 1ull;
   const mc_rec first = s_rec[0], last = s_rec[nw - 1];
   const int vbase0 = first.vbase, tbase0 = first.tbase;
   const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) - vbase0;
@@ -731,45 +730,35 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   continue;
 #endif
   // ---- vertices
-  // Two ways to list them.  SPARSE batch (the usual one: a street scene's word owns 3.6 vertices): lane j finds vertex j --
-  // its word by the words' vertex bases, its voxel by a binary search over the popcounts of the three edge masks below a
-  // bit -- one pass of ~150 vector instructions for up to 64 vertices.  DENSE batch (walls along z, noise): a pass per
-  // word with a lane per voxel, ~35 instructions a word, whatever it holds.
-  const bool sparse_v = nvt <= 128;
+  // Listing: a lane takes one (word, SEGMENT of 8 voxels) pair -- 8 K pairs, one per lane for K = 8 --, finds where its
+  // segment's vertices start in the batch's output range (the word's base + three popcounts below the segment: no search,
+  // no scan) and walks its own voxels.  A street scene's segment holds 0.45 vertices on average and 24 at most: the walk
+  // is short where the batch is sparse and costs what a lane-per-voxel pass costs where it is dense (walls along z), so one
+  // path serves both -- the lane-per-ITEM search it replaces (word by the bases, voxel by a 6-step binary search over
+  // three 64-bit popcounts) was 277 vector instructions per batch.
+  constexpr int NPV = (8 * K + 63) / 64;
   for (int vb = 0; vb < nvt; vb += LT_MC_VCAP) {
-    if (sparse_v) {
-      for (int j = lane; j < min(LT_MC_VCAP, nvt - vb); j += 64) {
-        const int g = vb + j;  // vertex g of the batch
-        int k = 0;
-        for (int q = 1; q < nw; ++q) k += (s_rec[q].vbase - vbase0 <= g) ? 1 : 0;
-        const mc_rec R = s_rec[k];
-        const int r = g - (R.vbase - vbase0);  // rank inside the word, in (voxel, axis) order
-        int b = 0;  // largest b with (vertices of voxels below b) <= r: the owner voxel
 #pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) {
-          const u64 below = (1ull << (b + sh)) - 1ull;  // (b + sh <= 63)
-          const int c = __popcll(R.ex & below) + __popcll(R.ey & below) + __popcll(R.ez & below);
-          if (c <= r) b += sh;
+    for (int i = 0; i < NPV; ++i) {
+      const int p = lane + 64 * i, k = p >> 3, seg = p & 7;
+      if (k < nw) {
+        const mc_rec R = s_rec[k];
+        const unsigned ex8 = (unsigned)(R.ex >> (8 * seg)) & 255u, ey8 = (unsigned)(R.ey >> (8 * seg)) & 255u,
+                       ez8 = (unsigned)(R.ez >> (8 * seg)) & 255u;
+        unsigned any = ex8 | ey8 | ez8;
+        if (any) {
+          const u64 below = (1ull << (8 * seg)) - 1ull;
+          int j = R.vbase - vbase0 - vb + __popcll(R.ex & below) + __popcll(R.ey & below) + __popcll(R.ez & below);
+          const unsigned e0 = (unsigned)k | ((unsigned)(8 * seg) << 4);
+          for (; any; any &= any - 1u) {
+            const int bb = __ffs((int)any) - 1;
+            const unsigned e = e0 + ((unsigned)bb << 4);
+            if ((ex8 >> bb) & 1u) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)e; ++j; }
+            if ((ey8 >> bb) & 1u) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (1u << 10)); ++j; }
+            if ((ez8 >> bb) & 1u) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (2u << 10)); ++j; }
+          }
         }
-        const u64 below = (1ull << b) - 1ull;
-        int a_r = r - (__popcll(R.ex & below) + __popcll(R.ey & below) + __popcll(R.ez & below));  // 0 .. 2 among the voxel's
-        const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull);
-        int axis = 0;
-        if (!(fx && a_r == 0)) {
-          a_r -= fx;
-          axis = (fy && a_r == 0) ? 1 : 2;
-        }
-        s_vl[j] = (unsigned short)((unsigned)k | ((unsigned)b << 4) | ((unsigned)axis << 10));
       }
-    } else
-    for (int k = 0; k < nw; ++k) {  // lane = voxel of word k: its (up to three) vertices into the list
-      const mc_rec R = s_rec[k];
-      const int fx = (int)((R.ex >> lane) & 1ull), fy = (int)((R.ey >> lane) & 1ull), fz = (int)((R.ez >> lane) & 1ull);
-      int j = R.vbase - vbase0 - vb + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
-      const unsigned e = (unsigned)k | ((unsigned)lane << 4);
-      if (fx) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)e; ++j; }
-      if (fy) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (1u << 10)); ++j; }
-      if (fz) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (2u << 10)); }
     }
     __syncthreads();
 #if defined(LT_MC_STOP) && LT_MC_STOP == 2  // ... + vertex list
@@ -814,53 +803,52 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   continue;
 #endif
   // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
-  // the batch's active cells in order (word, z), with their case; then one scan per 64 cells gives every cell the index
-  // of its first triangle (a scan per word cost more vector instructions than everything else in this kernel)
-  int ncell = s_cpre[nw];  // (wave-uniform)
-  if (ncell <= 128) {  // SPARSE batch: lane c finds cell c -- its word by the prefix, its voxel as the r-th set bit of the mask
-    for (int c = lane; c < ncell; c += 64) {
-      int k = 0;
-      for (int q = 1; q < nw; ++q) k += (s_cpre[q] <= c) ? 1 : 0;
-      int r = c - s_cpre[k];
-      const u64 ac = s_cm[k][8];
-      int b = 0;  // the r-th (0-based) set bit of ac
-#pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) {
-        const int cnt = __popc((unsigned)(ac >> b) & (sh == 32 ? 0xFFFFFFFFu : ((1u << sh) - 1u)));
-        if (cnt <= r) { r -= cnt; b += sh; }
-      }
-      int cs = 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) cs |= (int)((s_cm[k][q] >> b) & 1ull) << q;
-      s_cl[c] = (unsigned)k | ((unsigned)b << 4) | ((unsigned)cs << 13);
-    }
-  } else {
-  ncell = 0;
-  for (int k = 0; k < nw; ++k) {
-    const u64 ac = s_cm[k][8];
-    if (ac == 0ull) continue;
-    if ((ac >> lane) & 1ull) {
-      int cs = 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) cs |= (int)((s_cm[k][q] >> lane) & 1ull) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
-      s_cl[ncell + __popcll(ac & lm)] = (unsigned)k | ((unsigned)lane << 4) | ((unsigned)cs << 13);
-    }
-    ncell += __popcll(ac);
-  }
-  }
-  __syncthreads();
+  // the batch's active cells in order (word, z) with their case, and the (batch-relative) index of every cell's first
+  // triangle: the same (word, segment) dealing -- a lane lists the cells of its 8 voxels (the word's cell base + a popcount
+  // below the segment) and adds up their triangle counts, ONE wave scan over the lanes turns the sums into offsets, and
+  // the lane hands them to its cells.  (Before: a lane per cell with two searches, then a scan per 64 cells -- 386 vector
+  // instructions per batch, more than any other section of the kernel.)
+  const int ncell = s_cpre[nw];  // (wave-uniform)
   {
-    int run = 0;  // triangles before this chunk of cells (relative to the batch's first)
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-      const int c = c0 + lane;
-      const int nt = c < ncell ? LT_MC_NTRIS[(s_cl[c] >> 13) & 255] : 0;
-      int inc = nt;
+    int run = 0;  // triangles of the pairs before this round of 64
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int p = lane + 64 * i, k = p >> 3, seg = p & 7;
+      unsigned ac8 = 0, ntp = 0;  // ntp: the triangle counts of the segment's cells, 3 bits each, in cell order
+      int c0 = 0, tsum = 0;
+      if (k < nw) {
+        const u64 ac = s_cm[k][8];
+        ac8 = (unsigned)(ac >> (8 * seg)) & 255u;
+        if (ac8) {
+          c0 = s_cpre[k] + __popcll(ac & ((1ull << (8 * seg)) - 1ull));
+          unsigned m8[8];  // the corner masks' bits of this segment
+#pragma unroll
+          for (int q = 0; q < 8; ++q) m8[q] = (unsigned)(s_cm[k][q] >> (8 * seg)) & 255u;
+          int c = c0, sh = 0;
+          for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, sh += 3) {
+            const int bb = __ffs((int)a8) - 1;
+            unsigned cs = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
+            s_cl[c] = (unsigned)k | ((unsigned)(8 * seg + bb) << 4) | (cs << 13);
+            const unsigned nt = LT_MC_NTRIS[cs];
+            ntp |= nt << sh;
+            tsum += (int)nt;
+          }
+        }
+      }
+      int inc = tsum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const int q = __shfl_up(inc, o, 64);
         if (lane >= o) inc += q;
       }
-      if (c < ncell) s_ct[c] = (unsigned short)(run + inc - nt);
+      int t0 = run + inc - tsum;
+      int c = c0;
+      for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, ntp >>= 3) {
+        s_ct[c] = (unsigned short)t0;
+        t0 += (int)(ntp & 7u);
+      }
       run += __shfl(inc, 63, 64);
     }
   }
