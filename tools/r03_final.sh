@@ -11,6 +11,7 @@ bash tools/r03_profile.sh > gpurun_out/r03/profile.log 2>&1
 cp $(ls gpurun_out/r03/chain5/*/s_kernel_stats.csv gpurun_out/r03/chain5/s_kernel_stats.csv 2>/dev/null | head -1) gpurun_out/r03/chain5_kernel_stats.csv
 find gpurun_out/r03 -name "*kernel_trace.csv" -size +2M -delete
 bash tools/tlb_probe.sh > /dev/null 2>&1
+bash tools/atomic_probe.sh > /dev/null 2>&1
 for c in 2 3 4; do python tools/chain_pipeline.py $c 16 1 2>&1 | tail -1; done > gpurun_out/r03/chain_pipeline.txt
 python tools/chain_pipeline.py 3 8 5 2>&1 | tail -1 >> gpurun_out/r03/chain_pipeline.txt
 for st in 1 2; do

@@ -30,6 +30,44 @@ __global__ void k_chase_many(const uint64_t* __restrict__ buf, size_t stride_q, 
   if (idx == 0xdeadbeefull) out[0] = idx;
 }
 
+// ... with M independent chains per lane (memory-level parallelism per wave), and optionally BOTH 64-byte halves of a node's
+// 128-byte line per hop: what the memory side delivers in random REQUESTS per second
+template <int M, bool PAIR>
+__global__ void k_chase_mlp(const uint64_t* __restrict__ buf, size_t stride_q, size_t n, int hops, uint64_t* out) {
+  uint64_t idx[M];
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int m = 0; m < M; ++m) idx[m] = ((t * M + m) * 2654435761ull + 12345u) & (n - 1);
+  uint64_t acc = 0;
+  for (int h = 0; h < hops; ++h) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const uint64_t* p = buf + idx[m] * stride_q;
+      if (PAIR) acc += p[8];  // the other 64-byte half of the 128-byte line (stride >= 128 B)
+      idx[m] = p[0];
+    }
+  }
+  if (acc == 0x1234567ull) out[0] = acc;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    if (idx[m] == 0xdeadbeefull) out[0] = idx[m];
+}
+
+template <int M, bool PAIR>
+static double rate_mlp(const uint64_t* buf, size_t st, size_t n, uint64_t* out) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int hops = 64 / M;
+  hipLaunchKernelGGL((k_chase_mlp<M, PAIR>), dim3(8192), dim3(64), 0, 0, buf, st / 8, n, 4, out);
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL((k_chase_mlp<M, PAIR>), dim3(8192), dim3(64), 0, 0, buf, st / 8, n, hops, out);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return 8192.0 * 64 * M * hops / (ms * 1e-3) / 1e9;  // G hops / s
+}
+
 int main() {
   const size_t n = (size_t)1 << 24;  // 16 M nodes: 1 GB of distinct cache lines, far beyond L2 (32 MB) + Infinity Cache (256 MB)
   const size_t strides[] = {64, 256, 1024, 2048, 3072};
@@ -61,6 +99,12 @@ int main() {
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%10zu %10.2f %12zu %14.0f %16.2f\n", st, bytes / 1e9, bytes >> 21, best, 8192.0 * 64 * 64 / (ms * 1e-3) / 1e9);
+    if (st == 256 || st == 2048) {
+      printf("    chains per lane 1 / 2 / 4 / 8, 64 B per hop:  %.1f / %.1f / %.1f / %.1f G hops/s\n", rate_mlp<1, false>(buf, st, n, out),
+             rate_mlp<2, false>(buf, st, n, out), rate_mlp<4, false>(buf, st, n, out), rate_mlp<8, false>(buf, st, n, out));
+      printf("    ... both halves of the 128-byte line per hop:  %.1f / %.1f / %.1f / %.1f G hops/s (x 128 B)\n", rate_mlp<1, true>(buf, st, n, out),
+             rate_mlp<2, true>(buf, st, n, out), rate_mlp<4, true>(buf, st, n, out), rate_mlp<8, true>(buf, st, n, out));
+    }
     CK(hipFree(buf));
   }
   return 0;
