@@ -41,6 +41,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROARCH.md, L2 section)
+RANDOM_REQ_CEILING_G = 52.0   # G random 64-byte read requests per second the memory side delivers (tools/tlb_probe.hip, profiles/r03)
+ATOMIC_CEILING_G = 27.0       # G memory-side atomics per second (tools/atomic_probe.hip, profiles/r03)
 N_SIMD, SHADER_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 # Calibrated with tools/valu_calib.hip (profiles/r03/valu_calib.txt, 4096 straight-line v_fma_f32 per lane):
 #   * SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in every regime (1.000 per instruction): it counts issued instructions, it is NOT
@@ -637,6 +639,22 @@ def main():
                     return float(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), e
         return None, None, None
 
+    def measured_ea(kernel, spl):
+        """TCC_EA0 request counts per launch (tools/ea_to_json.py), valid for this workload, launch shape and kernel sources"""
+        import glob
+        want = kernel_source_hash("scatter")
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ea_requests.json")), reverse=True):
+            try:
+                doc = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            for e in doc.get("entries", []):
+                if (e.get("workload") == args.workload and not args.target and e.get("scans_per_launch") == spl
+                        and e.get("kernel_source_hash") == want and e.get("kernel") == kernel
+                        and "tcc_ea0_rdreq_per_launch" in e and "tcc_ea0_atomic_per_launch" in e):
+                    return dict(e, _path=os.path.relpath(path, ROOT))
+        return None
+
     def roofline(strategy, serial_ms, insitu_ms):
         spl = args.batch if strategy == "scatter" else 1  # scans per launch of the dominant kernel
         c = np.mean(np.array(cnt[strategy], dtype=np.float64), axis=0)
@@ -681,6 +699,24 @@ def main():
                             f"SIMDs at {SHADER_GHZ} GHz (the chip sustains 2.0-2.2 under load): the share of the kernel's "
                             "time a SIMD needs to ISSUE its vector work at the peak rate"}
             d["valu_issue"] = valu
+        if strategy == "scatter":
+            # the REQUEST view of the memory side (last block): TCC_EA0 counters of the same launches
+            # (profiles/rNN/ea_requests.json, keyed like pmc.json) against the two ceilings the probes measured
+            ea = measured_ea("k_sc_tris", spl)
+            if ea:
+                rd, at = ea["tcc_ea0_rdreq_per_launch"], ea["tcc_ea0_atomic_per_launch"]
+                sec = serial_ms * 1e-3
+                d["memory_side"] = {
+                    "ea_read_requests_per_launch": rd, "ea_atomics_per_launch": at,
+                    "read_requests_G_per_s": round(rd / sec / 1e9, 2), "atomics_G_per_s": round(at / sec / 1e9, 2),
+                    "random_read_ceiling_G_per_s": RANDOM_REQ_CEILING_G, "atomic_ceiling_G_per_s": ATOMIC_CEILING_G,
+                    "frac_of_random_read_ceiling": round(rd / sec / 1e9 / RANDOM_REQ_CEILING_G, 4),
+                    "frac_of_atomic_ceiling": round(at / sec / 1e9 / ATOMIC_CEILING_G, 4),
+                    "note": "every device-scope atomic is executed at the memory side (private L2s per XCD): one per accepted "
+                            "hit; ceilings: tools/tlb_probe.hip (52 G random 64-byte requests/s with the chip full of "
+                            "chains, any parallelism per lane), tools/atomic_probe.hip (27 G non-returning atomicMin/s on "
+                            "an image-sized region) -> profiles/r03/tlb_probe.txt, atomic_probe.txt",
+                    "source": ea["_path"]}
         if strategy == "lbvh":
             # The contract figure above prices the algorithmic bytes against HBM, but the tree is L2-resident (counter
             # traffic ~ 1/40 of the algorithmic bytes): the HBM view is kept as a sub-record and the block's bound / frac
