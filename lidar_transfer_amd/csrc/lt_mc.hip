@@ -1099,11 +1099,19 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   else if (n_active > 0)
   {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
-    // (A/B: LIDARHIP_MC_EMIT_WAVES=n caps the grid, the waves then take batches in turn.  Default: a wave per batch --
-    // 31 500 waves on the default volume's street scene: 101 us; 12 288 persistent waves: 97, 6144: 117, 3072: 130.  The
-    // kernel is neither launch-rate nor residency bound (LDS 10.8 -> 8.2 KB per wave: 105 -> 101 us): a batch is a chain of
-    // ~6 dependent memory round trips, ~15 us under load, and 31 500 of them over ~4 900 resident waves is the 100 us.)
-    static const int max_waves = []() { const char* e = getenv("LIDARHIP_MC_EMIT_WAVES"); return e && atoi(e) > 0 ? atoi(e) : (1 << 24); }();
+    // The grid: persistent waves taking batches in turn (bi += gridDim), twice the resident capacity (18 waves of 8.2 KB
+    // LDS per CU, tools/occ_probe.hip).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on
+    // average and up to 42, tools/mc_wave_times.py): a wave per batch 96 us -- a wave's start and drain 31 500 times --,
+    // 4 608 / 9 216 / 18 432 persistent waves 107 / 87 / 86 us (static dealing is at the mercy of the heavy batches: with
+    // one round of waves the slowest wave is the kernel), and persistent waves DRAWING their batches from eight counters
+    // (returning atomics, the draw for the next batch issued under the current one) 117-128 us: a returning atomic is a
+    // memory-side round trip that the batch's first barrier waits for.  LIDARHIP_MC_EMIT_WAVES=n: n waves; =0: a wave per batch.
+    static const int env_waves = []() { const char* e = getenv("LIDARHIP_MC_EMIT_WAVES"); return e ? atoi(e) : -1; }();
+    static const int dflt_waves = [&]() {
+      hipDeviceProp_t prop;
+      return hipGetDeviceProperties(&prop, m->device) == hipSuccess ? prop.multiProcessorCount * 36 : 9216;
+    }();
+    const int max_waves = env_waves > 0 ? env_waves : (env_waves == 0 ? (1 << 24) : dflt_waves);
     auto grid = [&](int k) { return dim3((unsigned)min((n_active + k - 1) / k, max_waves)); };
     if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
     else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);

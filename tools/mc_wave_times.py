@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Debug: per-wave wall-clock stamps of k_mc_words / k_mc_compact on the fusion chain's default volume.
-Needs a library built with the stamps:  LIDARHIP_EXTRA_FLAGS=-DLT_MC_STAMP=1 (k_mc_words) or =2 (k_mc_compact)."""
+Needs a library built with the stamps:  LIDARHIP_EXTRA_FLAGS=-DLT_MC_STAMP=1 (k_mc_words), =2 (k_mc_compact) or =3
+(k_mc_emit_batch: a batch's life by section) -- exported for this process too."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,6 +30,22 @@ nw = 1 << 16
 buf = np.zeros(4 * nw, np.uint64)
 lib.lt_debug_mc_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.lt_debug_mc_stamps(buf.ctypes.data_as(C.c_void_p), nw) == 0
+if "-DLT_MC_STAMP=3" in os.environ.get("LIDARHIP_EXTRA_FLAGS", ""):
+    # k_mc_emit_batch by section: wall clock (100 MHz) accumulated over all batches of all launches
+    t = buf[:8 * (1 << 15)].reshape(-1, 8).astype(np.float64) / 100.0
+    t = t[t[:, 0] > 0]
+    names = ["records -> LDS", "sign words, compact indices, neighbour records", "-", "vertex list",
+             "vertex pass (field samples, attributes, stores drained)", "cell masks, cell list, triangle offsets",
+             "triangle list + pass (stores drained)"]
+    print("k_mc_emit_batch: %d batches of the last launch; a batch's life by section (us): mean / p90" % len(t))
+    for i, nm in enumerate(names):
+        if nm != "-":
+            print("  %-58s %6.2f %6.2f" % (nm, t[:, i].mean(), np.percentile(t[:, i], 90)))
+    life = t[:, [0, 1, 3, 4, 5, 6]].sum(axis=1)
+    print("  %-58s %6.2f %6.2f" % ("a batch, start to end", life.mean(), np.percentile(life, 90)))
+    print("  a batch's life: p99 %.1f, p99.9 %.1f, max %.1f us; the %d batches above 30 us hold %.1f %% of the wave time" % (
+        np.percentile(life, 99), np.percentile(life, 99.9), life.max(), int((life > 30).sum()), 100.0 * life[life > 30].sum() / life.sum()))
+    sys.exit(0)
 t = buf.reshape(nw, 4).astype(np.int64)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()

@@ -12,12 +12,13 @@ cp $(ls gpurun_out/r03/chain5/*/s_kernel_stats.csv gpurun_out/r03/chain5/s_kerne
 find gpurun_out/r03 -name "*kernel_trace.csv" -size +2M -delete
 bash tools/tlb_probe.sh > /dev/null 2>&1
 bash tools/atomic_probe.sh > /dev/null 2>&1
+bash tools/occ_probe.sh > /dev/null 2>&1
 for c in 2 3 4; do python tools/chain_pipeline.py $c 16 1 2>&1 | tail -1; done > gpurun_out/r03/chain_pipeline.txt
 python tools/chain_pipeline.py 3 8 5 2>&1 | tail -1 >> gpurun_out/r03/chain_pipeline.txt
-for st in 1 2; do
+for st in 1 2 3; do
   export LIDARHIP_EXTRA_FLAGS="-DLT_MC_STAMP=$st"   # (exported: the library rebuilds itself when its flags differ from the caller's)
   python -c "from lidar_transfer_amd import build; build.build_lib(force=True)" > /dev/null 2>&1
-  echo "== LT_MC_STAMP=$st ($( [ $st = 1 ] && echo k_mc_words || echo k_mc_compact ))"; python tools/mc_wave_times.py 2>&1 | grep -v amdgpu.ids | tail -12
+  echo "== LT_MC_STAMP=$st ($( [ $st = 1 ] && echo k_mc_words || ( [ $st = 2 ] && echo k_mc_compact || echo k_mc_emit_batch ) ))"; python tools/mc_wave_times.py 2>&1 | grep -v amdgpu.ids | tail -12
 done > gpurun_out/r03/mc_wave_times.txt
 unset LIDARHIP_EXTRA_FLAGS
 python -c "from lidar_transfer_amd import build; build.build_lib(force=True)" > /dev/null 2>&1
