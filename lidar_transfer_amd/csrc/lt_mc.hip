@@ -43,8 +43,12 @@ extern "C" int lt_debug_mc_stamps(unsigned long long* out, int n_waves) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mc_stamp), (size_t)min(n_waves, 1 << 16) * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #define LT_MC_STAMP_AT(which, w, i, v) do { if (LT_MC_STAMP == (which) && (threadIdx.x & 63) == 0 && (w) < (1 << 16)) g_mc_stamp[(w) * 4 + (i)] = (v); } while (0)
+// =3: k_mc_emit_batch by section -- g_mc_stamp[8 b + i]: the wall clock between marks i - 1 and i of batch b (plain stores:
+// atomics on eight shared words serialise the waves behind them and measure themselves)
+#define LT_MC_SECTION(i) do { if (LT_MC_STAMP == 3) { const unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0 && bi < (1 << 15)) g_mc_stamp[bi * 8 + (i)] = t_ - st_last; st_last = t_; } } while (0)
 #else
 #define LT_MC_STAMP_AT(which, w, i, v) do { } while (0)
+#define LT_MC_SECTION(i) do { } while (0)
 #endif
 
 typedef unsigned long long u64;
@@ -663,6 +667,9 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   // (a wave takes batches until none is left; by default the grid has a wave per batch -- see the launch)
   const int n_batches = (n_active + K - 1) / K;
   for (int bi = blockIdx.x; bi < n_batches; bi += gridDim.x) {
+#ifdef LT_MC_STAMP
+  unsigned long long st_last = wall_clock64();
+#endif
   const int ci0 = bi * K;
   const int nw = min(K, n_active - ci0);
   const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
@@ -675,6 +682,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     s_xyz[lane][1] = row - (row / D.ny) * D.ny;
   }
   __syncthreads();
+  LT_MC_SECTION(0);  // records
   for (int p = lane; p < 8 * nw; p += 64) {  // (k, slot): sign word and record of the word (x + dx, y + dy, wz + dw)
     const int k = p >> 3, slot = p & 7;
     const int x = s_xyz[k][0], y = s_xyz[k][1], wz = s_xyz[k][2];
@@ -697,6 +705,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     s_nb[k][slot] = e;
   }
   __syncthreads();
+  LT_MC_SECTION(1);  // sign words, compact indices, neighbour records
   if (lane < nw) {  // the cell masks of word `lane`, once
     u64 w8[8];
 #pragma unroll
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       }
     }
     __syncthreads();
+    LT_MC_SECTION(3);  // vertex list
 #if defined(LT_MC_STOP) && LT_MC_STOP == 2  // ... + vertex list
     continue;
 #endif
@@ -799,6 +809,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     __syncthreads();
   }
+  LT_MC_SECTION(4);  // vertex pass (field samples, attributes, stores drained)
 #if defined(LT_MC_STOP) && LT_MC_STOP == 3  // ... + vertex pass
   continue;
 #endif
@@ -853,6 +864,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
   }
   __syncthreads();
+  LT_MC_SECTION(5);  // cell masks, cell list, triangle offsets
 #if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
   continue;
 #endif
@@ -895,6 +907,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     __syncthreads();
   }
+    LT_MC_SECTION(6);  // triangle list + pass (stores drained)
     __syncthreads();  // the batch's arrays are reused
   }
 }
