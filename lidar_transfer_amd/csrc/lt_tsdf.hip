@@ -599,6 +599,16 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
 // the whole wave, columns across the lanes.  Columns whose voxels the reference's float index arithmetic can misplace
 // (y = dim_y - 1 beyond 2^24 voxels, col_plain) are not in the table: k_tsdf_integrate_quirk evaluates them voxel by voxel.
 // Bit-identical to the column walk and to the one-thread-per-voxel restatement (tests/test_tsdf_gpu.py).
+#ifdef LT_PIX_STAMP  // (-DLT_PIX_STAMP; tools/tsdf_written_times.py --pix): per workgroup of k_tsdf_integrate_pix -- start, end of phase A,
+// end of the first chunk's pairs + scan, end of the voxel rounds, end (plain stores: shared counters measure themselves)
+__device__ unsigned long long g_pix_stamp[5 << 12];
+extern "C" int lt_debug_pix_stamps(unsigned long long* out, int n_wgs) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pix_stamp), (size_t)min(n_wgs, 1 << 12) * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define LT_PIX_MARK(i) do { if (tid == 0 && blockIdx.x < (1 << 12)) g_pix_stamp[5 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define LT_PIX_MARK(i) do { } while (0)
+#endif
 struct wd_geom {
   int dim_x, dim_y, dim_z;
   float ox, oy, oz, vs;
@@ -737,6 +747,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
   };
   for (int p0 = blockIdx.x * 64; p0 < n_pix; p0 += gridDim.x * 64) {  // (workgroup-uniform)
     const unsigned long long tm0 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;  // (100 MHz; debug)
+    LT_PIX_MARK(0);
     // ---- A: the pixels' runs of table entries ------------------------------------------------------------------------
     {  // stage the quanta of the wedges these 64 pixels search (one image column when im_h is a multiple of 64)
       const int px_a = p0 / im_h, px_b = min(p0 + 63, n_pix - 1) / im_h;
@@ -807,6 +818,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     const int agg_k0 = a_k0, agg_span = a_span;
     const bool agg = agg_span <= LT_PIX_AGG;  // (workgroup-uniform)
     if (VCOUNT && tid == 0) atomicAdd(&dbg[4], (unsigned long long)wall_clock64() - tm0);  // phase A
+    LT_PIX_MARK(1);
     // ---- B: chunks of pairs ---------------------------------------------------------------------------------------------
     for (int base = 0; base < T; base += LT_PIX_CHUNK) {
       constexpr int PPT = LT_PIX_CHUNK / 256;  // pairs per thread
@@ -893,6 +905,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       const int V = run, n_slots = min(T - base, LT_PIX_CHUNK);
       const unsigned long long tm1 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;
       if (VCOUNT && tid == 0 && base == 0) atomicAdd(&dbg[5], tm1 - tm0);  // ... + first chunk's pairs and scan
+      if (base == 0) LT_PIX_MARK(2);
       // the chunk's voxels, one per thread and round
       for (int jb = 0; jb < V; jb += 256) {  // (workgroup-uniform trips: the run aggregation below shuffles)
         const int j = jb + tid;
@@ -945,6 +958,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       }
       __syncthreads();  // the chunk's arrays are reused
     }
+    LT_PIX_MARK(3);
     // the merged ranges -> col_zw, stamps: once per column (all pairs of all chunks have merged: the barrier above)
     if (agg)
       for (int i = tid; i < agg_span; i += 256) {
@@ -958,6 +972,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
           chunk_epoch[c >> 6] = epoch;
         }
       }
+    LT_PIX_MARK(4);
     __syncthreads();  // ... and the pixels'
   }
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Debug: per-workgroup wall-clock stamps of k_tsdf_integrate_written (the further observations of a fused scan) on the fusion
-chain's default volume.  Needs a library built with LIDARHIP_EXTRA_FLAGS=-DLT_TSDF_STAMP (exported for this process too)."""
+chain's default volume.  Needs a library built with LIDARHIP_EXTRA_FLAGS=-DLT_TSDF_STAMP (exported for this process too).
+    --pix: the phases of k_tsdf_integrate_pix per workgroup instead (library built with -DLT_PIX_STAMP)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,6 +28,22 @@ for i in range(3):
     for d in (depth, depth2):
         assert lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), d.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
 torch.cuda.synchronize()
+if "--pix" in sys.argv:  # k_tsdf_integrate_pix of the FIRST observation (library built with -DLT_PIX_STAMP)
+    assert lib.lt_tsdf_reset(vol._h, sp) == 0
+    assert lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), depth.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
+    torch.cuda.synchronize()
+    n = 1 << 12
+    buf = np.zeros(5 * n, np.uint64)
+    lib.lt_debug_pix_stamps.argtypes = [C.c_void_p, C.c_int]
+    assert lib.lt_debug_pix_stamps(buf.ctypes.data_as(C.c_void_p), n) == 0
+    t = buf.reshape(n, 5).astype(np.int64); t = t[(t > 0).all(axis=1)]  # (a workgroup without pairs sets no mark 2)
+    t0 = t[:, 0].min()
+    u = (t - t0) / 100.0
+    print("k_tsdf_integrate_pix: %d workgroups, span %.1f us" % (len(t), u[:, 4].max()))
+    for name, a in (("start", u[:, 0]), ("phase A", u[:, 1] - u[:, 0]), ("first chunk's pairs + scan", u[:, 2] - u[:, 1]),
+                    ("voxel rounds (+ further chunks)", u[:, 3] - u[:, 2]), ("flush", u[:, 4] - u[:, 3]), ("life", u[:, 4] - u[:, 0]), ("end", u[:, 4])):
+        print("  %-32s mean %7.2f p50 %7.2f p90 %7.2f max %7.2f us" % (name, a.mean(), np.percentile(a, 50), np.percentile(a, 90), a.max()))
+    sys.exit(0)
 n = 1 << 12
 buf = np.zeros(5 * n, np.uint64)
 lib.lt_debug_tsdf_stamps.argtypes = [C.c_void_p, C.c_int]
