@@ -1394,7 +1394,16 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
   const int words_z = (t->dim[2] + 63) / 64;
   const int n_pix = im_h * im_w;
-  const unsigned nb = (unsigned)min((n_pix + 63) / 64, 1 << 20);  // a workgroup per 64 pixels
+  // a workgroup per 64 pixels -- unless that is more than the chip holds at once (5 per CU: 97 VGPRs, 27.5 KB of LDS): the
+  // workgroups then walk the groups of 64 in turn, so that the launch is ONE round of resident workgroups
+  // (LIDARHIP_PIX_WGS=n: n workgroups; =0: one per 64 pixels)
+  static const int env_wgs = []() { const char* e = getenv("LIDARHIP_PIX_WGS"); return e ? atoi(e) : -1; }();
+  static const int res_wgs = [&]() {
+    hipDeviceProp_t prop;
+    return hipGetDeviceProperties(&prop, t->device) == hipSuccess ? prop.multiProcessorCount * 5 : 1280;
+  }();
+  const int groups = (n_pix + 63) / 64;
+  const unsigned nb = (unsigned)min(groups, env_wgs > 0 ? env_wgs : (env_wgs == 0 ? (1 << 20) : res_wgs));
   const unsigned* zw_snap = nullptr;
   if (!fresh_volume) {
     // the written ranges as they stand before this observation (32 MB on the default volume: a device copy), then every
