@@ -83,9 +83,14 @@ def parse():
     ap.add_argument("--target", default="", help="target sensor YAML (lidar_deform.py --target: name, fov_up, fov_down, "
                                                   "beams, angle_res_hor, fov_hor); overrides the workload's sensor model")
     ap.add_argument("--strategy", default=os.environ.get("LT_BENCH_STRATEGY", "scatter"), choices=["scatter", "lbvh"])
-    ap.add_argument("--scenes", type=int, default=12,
-                    help="distinct scenes cycled through per rank (12 x 26 MB exceeds the 256 MB Infinity Cache, so a "
-                         "scan does not find its mesh cached from the last time round)")
+    # what k_sc_tris streams per scene is faces + vertices = 18.3 MB on C2 (colours / remissions are only gathered for hit
+    # triangles), so 12 scenes = 220 MB FIT the 256 MiB Infinity Cache: round 3's default was MALL-assisted by ~6 %
+    # (profiles/r04/scenes_sweep.jsonl: 4 / 12 / 24 / 48 / 64 scenes -> 11.75 / 10.54 / 10.01 / 9.85 / 9.93 Grays/s; FETCH_SIZE
+    # does not move, it counts Infinity-Cache hits).  48 x 18.3 MB = 878 MB > 2 x 256 MiB: the value no longer changes.
+    ap.add_argument("--scenes", type=int, default=int(os.environ.get("LT_BENCH_SCENES", "48")),
+                    help="distinct scenes cycled through per rank; faces + vertices of all of them (18.3 MB each on C2) must "
+                         "exceed twice the 256 MiB Infinity Cache so that no scan finds its mesh cached from the last time "
+                         "round (profiles/r04/scenes_sweep.jsonl)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "16")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("LT_BENCH_BATCH", "8")),
@@ -328,8 +333,11 @@ def main():
 
     gather_info = {}
 
-    def run(strategy, K, Wm, keep):
-        """Timed region for one strategy; returns (seconds, mean dominant-kernel ms, hits of the last scan)."""
+    def run(strategy, K, Wm, keep, groups=None, probe_every=PROBE_EVERY):
+        """Timed region for one strategy; returns (seconds, mean dominant-kernel ms, hits of the last scan).
+        `groups`: batches in flight (default: all --streams / --batch of them); `probe_every`: HIP-event pair around
+        every n-th launch of the dominant kernel."""
+        PROBE_EVERY = max(1, probe_every)  # noqa: N806  (shadows the module default inside this timed region)
         dist_on = dist.is_initialized()
         range_all = torch.zeros((K, R), dtype=torch.float32, device=dev) if keep else None
         # the kept colour output is the semantic-label image itself (LT_TRACE_LABEL_IMAGE = deform's unpack
@@ -412,7 +420,7 @@ def main():
         BATCH = args.batch if strategy == "scatter" else 1
         if BATCH > 1:
             assert S % BATCH == 0, "--streams must be a multiple of --batch"
-            n_groups = S // BATCH
+            n_groups = min(groups, S // BATCH) if groups else S // BATCH
             arr = lambda vals: (vp * BATCH)(*vals)  # noqa: E731
             grp_scenes = [arr([wh[g * BATCH + j] for j in range(BATCH)]) for g in range(n_groups)]
             grp_rays = [arr([rh[g * BATCH + j] for j in range(BATCH)]) for g in range(n_groups)]
@@ -599,11 +607,13 @@ def main():
 
     # ---- counting passes (outside the clock): work per scan for the roofline ------------------------------
     cnt = {"scatter": [], "lbvh": []}
+    hit_ray_counts = []
     for i in range(len(scenes)):
         workers[0].set_mesh(*scenes[i])
         o = workers[0].render(raysets[0], origin, out=scratch[0], count=True)
         cnt["scatter"].append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
-        if args.strategy == "lbvh" or not args.no_other:
+        hit_ray_counts.append(int((o["range"] > 0).sum().item()))
+        if (args.strategy == "lbvh" or not args.no_other) and (args.strategy == "lbvh" or i < 12):  # (the side leg: 12 scenes say enough)
             workers[0].build()
             o = workers[0].trace(rays, origin, H, out=scratch[0], count=True)
             cnt["lbvh"].append((o["stats"]["nodes_visited"], o["stats"]["tris_tested"], o["stats"]["n_hits"]))
@@ -1075,6 +1085,24 @@ def main():
         other = guarded("other_strategy", other_leg)
 
     iso_ms = guarded("isolated_kernel", isolated_kernel_ms, args.strategy)
+
+    def one_batch_in_flight():
+        """The timed region once more with ONE batch in flight (one stream, launches strictly one after the other), every
+        k_sc_tris launch bracketed by HIP events: here the kernel durations are exclusive AND inside a wall-clocked region,
+        so launches x kernel time must FIT in the region's time -- the check the default region (two overlapped batches,
+        which fill each other's tails) cannot offer."""
+        Ko = max(args.batch * 8, min(K, 1024))
+        odt, okern, _, _ = run("scatter", Ko, max(args.batch * 2, min(Wm, 64)), keep=False, groups=1, probe_every=1)
+        n_launch = (Ko + args.batch - 1) // args.batch
+        return {"batches_in_flight": 1, "scans": Ko, "value": round(world * Ko * R / odt / 1e6, 3), "unit": "Mrays/s",
+                "region_ms": round(odt * 1e3, 4), "k_sc_tris_launches": n_launch,
+                "k_sc_tris_avg_ms": round(okern, 5), "launches_x_kernel_ms": round(n_launch * okern, 4),
+                "kernel_share_of_region": round(n_launch * okern / (odt * 1e3), 4),
+                "fits_in_region": bool(n_launch * okern <= odt * 1e3),
+                "note": "one stream, one batch of scans in flight: k_sc_tris -> k_sc_rest -> k_sc_resolve strictly in turn; "
+                        "HIP events around EVERY k_sc_tris launch of the region"}
+
+    one_batch = guarded("one_batch_in_flight", one_batch_in_flight) if (args.strategy == "scatter" and args.batch > 1) else None
     # the PCIe-inclusive clocks and the fusion chain are single-GPU records (like cpu_baseline): rank 0 at N = 1 only
     e2e = guarded("e2e_single_call", e2e_host_call) if (rank == 0 and world == 1 and not args.no_e2e) else None
     if e2e:
@@ -1110,6 +1138,25 @@ def main():
                               "note": "same kernel, launches of ONE scan each, back to back on one stream (nothing beside "
                                       "them), after the timed region"}
         if args.strategy == "scatter":
+            # path_frac: the figure that is bounded by the DRIVER's clock -- algorithmic bytes of all three kernels per step
+            # over ms_per_step against the HBM peak.  k_sc_tris: as above; k_sc_resolve: per ray the 8-B z-min cell read and
+            # re-armed (16 B) + the five images written (range 4, label 4, remission 4, end point 12, triangle 4 = 28 B), per
+            # hit ray the winner's face (12 B), three remissions (12 B) and one label (4 B); k_sc_rest redoes deferred work
+            # of k_sc_tris: no algorithmic bytes of its own.
+            cs = np.mean(np.array(cnt["scatter"], dtype=np.float64), axis=0)
+            hit_rays = float(np.mean(hit_ray_counts)) if hit_ray_counts else float(cs[2])
+            b_tris = rl["algorithmic_bytes_per_scan"]
+            b_res = R * (16 + 28) + hit_rays * 28
+            step_s = dt / args.steps
+            rl["path_frac"] = round((b_tris + b_res) * SPS / step_s / 1e9 / HBM_PEAK_GBS, 4)
+            rl["path"] = {"algorithmic_bytes_per_scan": {"k_sc_tris": int(b_tris), "k_sc_resolve": int(b_res), "k_sc_rest": 0},
+                          "achieved": round((b_tris + b_res) * SPS / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": rl["path_frac"],
+                          "frac_k_sc_tris_bytes_only": round(b_tris * SPS / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "algorithmic bytes of the whole three-kernel path per step / ms_per_step (the driver-timed "
+                                  "number) / 8 TB/s; needs no kernel-exclusivity argument"}
+            if one_batch:
+                rl["one_batch_in_flight"] = one_batch
             # all three kernels of a scan together at the measured scan rate: the HBM bandwidth the whole path
             # sustains over the timed region (PMC traffic per launch from profiles/rNN/pmc.json, null when stale)
             parts = [measured_traffic("scatter", args.batch, k)[0] for k in ("k_sc_tris", "k_sc_rest", "k_sc_resolve")]

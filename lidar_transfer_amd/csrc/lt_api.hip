@@ -14,6 +14,17 @@ void lt_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int lt_cu_count(int device) {
+  static int cache[64];  // 0 = not asked yet (benign race: every writer stores the same value)
+  const int slot = (device >= 0 && device < 64) ? device : 0;
+  int v = __atomic_load_n(&cache[slot], __ATOMIC_RELAXED);
+  if (v > 0) return v;
+  hipDeviceProp_t prop;
+  v = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  __atomic_store_n(&cache[slot], v, __ATOMIC_RELAXED);
+  return v;
+}
+
 extern "C" const char* lt_last_error(void) { return g_err; }
 extern "C" const char* lt_version(void) { return "lidarhip 0.1 (gfx950)"; }
 

@@ -7,6 +7,8 @@
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void lt_set_error(const char* fmt, ...);
+// compute units of a device, cached per device index (a process may hold volumes / meshes on several GPUs)
+int lt_cu_count(int device);
 
 #define LT_HIP(call)                                                                          \
   do {                                                                                        \

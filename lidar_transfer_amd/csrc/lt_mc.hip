@@ -1120,10 +1120,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     // (returning atomics, the draw for the next batch issued under the current one) 117-128 us: a returning atomic is a
     // memory-side round trip that the batch's first barrier waits for.  LIDARHIP_MC_EMIT_WAVES=n: n waves; =0: a wave per batch.
     static const int env_waves = []() { const char* e = getenv("LIDARHIP_MC_EMIT_WAVES"); return e ? atoi(e) : -1; }();
-    static const int dflt_waves = [&]() {
-      hipDeviceProp_t prop;
-      return hipGetDeviceProperties(&prop, m->device) == hipSuccess ? prop.multiProcessorCount * 36 : 9216;
-    }();
+    const int dflt_waves = lt_cu_count(m->device) * 36;
     const int max_waves = env_waves > 0 ? env_waves : (env_waves == 0 ? (1 << 24) : dflt_waves);
     auto grid = [&](int k) { return dim3((unsigned)min((n_active + k - 1) / k, max_waves)); };
     if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);

@@ -25,7 +25,7 @@
 //     field of view before asinf; the band around the limits takes the exact path;
 //   * columns written since the last reset are stamped with the volume's epoch: reset re-initialises those only, and
 //     marching cubes (lt_mc.hip) does not read the clean ones.
-// The one-thread-per-voxel restatement of the reference kernel is test infrastructure (tests/csrc/lt_tsdf_dense.hip,
+// The one-thread-per-voxel restatement of the reference kernel is test infrastructure (oracle/lt_tsdf_dense.hip,
 // not in this library): the A/B partner of the kernels below -- bit-identical volumes, tests/test_tsdf_gpu.py.
 #include "lt_internal.h"
 #include <math.h>
@@ -1279,10 +1279,27 @@ void lt_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, int n, 
 // sort buffers); rebuilt when an integrate comes with another image width
 static int tsdf_wedge_build(lt_tsdf* t, int im_w, int rho_bits, hipStream_t stream) {
   const int n = t->dim[0] * t->dim[1];
-  if (!t->wd_px) {
-    LT_HIP(hipMalloc((void**)&t->wd_px, (size_t)n * sizeof(int)));
-    LT_HIP(hipMalloc((void**)&t->wd_ent, (size_t)n * sizeof(int2)));
-    LT_HIP(hipMalloc((void**)&t->wd_key, (size_t)n * sizeof(unsigned)));
+  if (!t->wd_px || !t->wd_ent || !t->wd_key) {
+    // all three or none: an allocation that fails half way must not leave a non-NULL wd_px behind (the next integrate
+    // would skip this block and launch the table kernels on NULL tables)
+    if (t->wd_px || t->wd_ent || t->wd_key) LT_HIP(hipStreamSynchronize(stream));
+    if (t->wd_px) (void)hipFree(t->wd_px);
+    if (t->wd_ent) (void)hipFree(t->wd_ent);
+    if (t->wd_key) (void)hipFree(t->wd_key);
+    t->wd_px = nullptr; t->wd_ent = nullptr; t->wd_key = nullptr;
+    t->wd_w = 0;
+    bool ok = hipMalloc((void**)&t->wd_px, (size_t)n * sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&t->wd_ent, (size_t)n * sizeof(int2)) == hipSuccess &&
+              hipMalloc((void**)&t->wd_key, (size_t)n * sizeof(unsigned)) == hipSuccess;
+    if (!ok) {
+      if (t->wd_px) (void)hipFree(t->wd_px);
+      if (t->wd_ent) (void)hipFree(t->wd_ent);
+      if (t->wd_key) (void)hipFree(t->wd_key);
+      t->wd_px = nullptr; t->wd_ent = nullptr; t->wd_key = nullptr;
+      (void)hipGetLastError();
+      lt_set_error("lt_tsdf: out of device memory for the wedge table (%d columns)", n);
+      return LT_ERR_NO_MEMORY;
+    }
   }
   if (t->wd_start) { LT_HIP(hipStreamSynchronize(stream)); (void)hipFree(t->wd_start); t->wd_start = nullptr; }
   if (t->wd_qcols) { (void)hipFree(t->wd_qcols); t->wd_qcols = nullptr; }
@@ -1398,10 +1415,7 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   // workgroups then walk the groups of 64 in turn, so that the launch is ONE round of resident workgroups
   // (LIDARHIP_PIX_WGS=n: n workgroups; =0: one per 64 pixels)
   static const int env_wgs = []() { const char* e = getenv("LIDARHIP_PIX_WGS"); return e ? atoi(e) : -1; }();
-  static const int res_wgs = [&]() {
-    hipDeviceProp_t prop;
-    return hipGetDeviceProperties(&prop, t->device) == hipSuccess ? prop.multiProcessorCount * 5 : 1280;
-  }();
+  const int res_wgs = lt_cu_count(t->device) * 5;
   const int groups = (n_pix + 63) / 64;
   const unsigned nb = (unsigned)min(groups, env_wgs > 0 ? env_wgs : (env_wgs == 0 ? (1 << 20) : res_wgs));
   const unsigned* zw_snap = nullptr;

@@ -185,7 +185,7 @@ class HostScanPipeline:
                    "lt_hostpipe_create")
         self._h = h
         self.depth = int(depth)
-        self._live = {}  # ticket -> [inputs kept alive (dropped when the slot is reused), outputs (kept until wait())]
+        self._live = {}  # ticket -> [inputs kept alive (dropped when the slot is reused), outputs (kept until wait()), own]
 
     def alloc_outputs(self):
         np = self._np
@@ -204,7 +204,8 @@ class HostScanPipeline:
         u8 = colors.dtype == np.uint8
         colors = np.ascontiguousarray(colors, np.uint8 if u8 else np.int32)
         org = np.ascontiguousarray(np.asarray(origin, np.float32).reshape(-1)[:3])
-        if out is None:
+        own = out is None  # outputs allocated here must stay collectable; the caller's own arrays need no keeping
+        if own:
             out = self.alloc_outputs()
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
 
@@ -218,10 +219,12 @@ class HostScanPipeline:
                                           rem.ctypes.data_as(fp), verts.size // 3, faces.size // 3, p("endpoints", fp),
                                           p("endcolors", ip), p("range", fp), p("endrem", fp), p("tri", ip), C.byref(t))
         if t.value >= 0:
-            self._live[t.value] = [(verts, faces, colors, rem, org), out]
+            self._live[t.value] = [(verts, faces, colors, rem, org), out, own]
             # the scan whose slot this submit reused was completed by it (its images are already in ITS output
             # arrays): the library no longer reads its inputs -- drop those, but keep the outputs until the caller
-            # collects them with wait() (a caller may submit more than `depth` scans before waiting)
+            # collects them with wait() (a caller may submit more than `depth` scans before waiting).  Entries whose
+            # outputs are the CALLER's own arrays are dropped by flush(): a caller who passes `out` and never calls
+            # wait() does not grow this table beyond the scans between two flushes
             old = self._live.get(t.value - self.depth)
             if old is not None:
                 old[0] = None
@@ -230,7 +233,8 @@ class HostScanPipeline:
 
     def wait(self, ticket):
         """Images of the scan with this ticket (complete when the call returns).  A ticket is handed out once: a second
-        wait() for it -- or a ticket this pipe never issued -- raises ``KeyError``."""
+        wait() for it, a ticket this pipe never issued, or a ticket submitted with the caller's own ``out`` arrays and
+        completed by a flush() since (those are forgotten there) raises ``KeyError``."""
         ticket = int(ticket)
         if ticket not in self._live:
             raise KeyError(f"HostScanPipeline.wait: ticket {ticket} is unknown or was already collected")
@@ -238,8 +242,11 @@ class HostScanPipeline:
         return self._live.pop(ticket)[1]
 
     def flush(self):
-        """Complete every submitted scan; their images stay collectable with :meth:`wait`."""
+        """Complete every submitted scan.  Images the pipe allocated stay collectable with :meth:`wait`; scans submitted
+        with the caller's own ``out`` arrays are complete in those arrays and forgotten here."""
         _lib.check(self._lib.lt_hostpipe_flush(self._h), "lt_hostpipe_flush")
+        for t in [t for t, item in self._live.items() if not item[2]]:
+            del self._live[t]
         for item in self._live.values():
             item[0] = None
 
@@ -260,6 +267,25 @@ class HostScanPipeline:
             self.close()
         except Exception:
             pass
+
+
+def _fusion_chain_worker(pipe_ref, q):
+    """Thread body of one chain of :class:`FusionScanPipeline`: takes jobs from the chain's queue until it receives
+    ``None``.  Holds the pipeline only while a job runs (weak reference otherwise)."""
+    first = True
+    while True:
+        job = q.get()
+        if job is None:
+            return
+        pipe = pipe_ref()
+        if pipe is None:
+            return
+        if first:
+            pipe._torch.cuda.set_device(pipe.device)
+            first = False
+        ch = next(c for c in pipe._chains_all if c["q"] is q)
+        pipe._run_job(ch, job)
+        del pipe, ch
 
 
 class FusionScanPipeline:
@@ -285,6 +311,7 @@ class FusionScanPipeline:
                  label_image=False):
         import queue
         import threading
+        import weakref
 
         import torch
 
@@ -305,8 +332,11 @@ class FusionScanPipeline:
         for _ in range(int(chains)):
             ch = dict(vol=TSDFVolume(vol_bnds, voxel_size, fov_up, fov_down, device=idx, merge=merge),
                       mesh=DeviceMesh(idx), scene=Scene(idx), stream=torch.cuda.Stream(self.device), q=queue.Queue())
-            ch["thread"] = threading.Thread(target=self._work, args=(ch,), daemon=True)
+            # the worker holds a WEAK reference to the pipeline: a bound method as thread target would keep an un-closed
+            # pipeline (and its chains' volumes: GBs of HBM each) alive for ever -- __del__ could never run
+            ch["thread"] = threading.Thread(target=_fusion_chain_worker, args=(weakref.ref(self), ch["q"]), daemon=True)
             self._chains.append(ch)
+        self._chains_all = list(self._chains)  # (close() empties _chains first; a worker finishing its job still finds its chain)
         self._lock = threading.Lock()
         self._done = {}    # ticket -> threading.Event
         self._result = {}  # ticket -> outputs dict | exception
@@ -327,10 +357,13 @@ class FusionScanPipeline:
                 out = ch["scene"].alloc_outputs(self.n_rays, label_image=self.label_image)
             h = w = 0
             for k, (color_im, depth_im, rem_im) in enumerate(obs):
-                c = color_im
-                if c.dim() == 3:  # fold RGB into one channel (fusion_lidar.py:261-264), float32 like the reference
+                # float32 FIRST, then fold RGB into one channel -- the reference's order (fusion_lidar.py:260-264:
+                # color_im.astype(np.float32), then floor(b*256*256 + g*256 + r)); folding in the caller's dtype wraps a
+                # uint8 image to 0 and overflows float16
+                c = color_im.to(torch.float32)
+                if c.dim() == 3:
                     c = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2])
-                c = c.to(torch.float32).contiguous()
+                c = c.contiguous()
                 d = depth_im.to(torch.float32).contiguous()
                 r = rem_im.to(torch.float32).contiguous()
                 if k and (d.shape[0], d.shape[1]) != (h, w):
@@ -356,21 +389,16 @@ class FusionScanPipeline:
         res["_done"] = (done, keep, obs)  # (temporaries and observations stay referenced until the event has passed)
         return res
 
-    def _work(self, ch):
-        self._torch.cuda.set_device(self.device)
-        while True:
-            job = ch["q"].get()
-            if job is None:
-                return
-            ticket, obs, origin, out = job
-            try:
-                res = self._scan(ch, obs, origin, out)
-            except BaseException as e:  # noqa: BLE001  (handed to the waiter)
-                res = e
-            with self._lock:
-                self._result[ticket] = res
-                ev = self._done[ticket]
-            ev.set()
+    def _run_job(self, ch, job):
+        ticket, obs, origin, out = job
+        try:
+            res = self._scan(ch, obs, origin, out)
+        except BaseException as e:  # noqa: BLE001  (handed to the waiter)
+            res = e
+        with self._lock:
+            self._result[ticket] = res
+            ev = self._done[ticket]
+        ev.set()
 
     # ---- caller's side --------------------------------------------------------------------------------------------------
     def submit(self, observations, origin=(0.0, 0.0, 0.0), out=None, inputs_ready=False):
@@ -408,6 +436,12 @@ class FusionScanPipeline:
         if isinstance(res, BaseException):
             raise res
         res.pop("_done")[0].synchronize()
+        # the images were allocated on the chain's stream: tell the caching allocator that the caller's stream uses them,
+        # so that freeing them early cannot hand their memory back to the chain while the caller still reads it
+        cur = self._torch.cuda.current_stream(self.device)
+        for v in res.values():
+            if isinstance(v, self._torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
         return res
 
     def flush(self):
@@ -423,8 +457,10 @@ class FusionScanPipeline:
         chains, self._chains = getattr(self, "_chains", []), []
         for ch in chains:
             ch["q"].put(None)
+        import threading
         for ch in chains:
-            ch["thread"].join()
+            if ch["thread"] is not threading.current_thread():  # (__del__ may run on a worker that dropped the last reference)
+                ch["thread"].join()
             ch["mesh"].close()
             ch["scene"].close()
             ch["vol"].close()

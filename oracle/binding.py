@@ -38,6 +38,19 @@ def build(quiet: bool = True) -> None:
 
 _oracle = None
 _refs = {}
+_dense = None
+
+
+def dense_lib():
+    """oracle/liblt_tsdf_dense.so: the one-thread-per-voxel HIP restatement of the reference's pycuda ``integrate`` kernel
+    (fusion_lidar.py:66-229; oracle/lt_tsdf_dense.hip) -- the A/B partner of the product's TSDF kernels on the GPU."""
+    global _dense
+    if _dense is None:
+        path = os.path.join(HERE, "liblt_tsdf_dense.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", HERE, "dense"], check=True, stdout=subprocess.DEVNULL)
+        _dense = C.CDLL(path)
+    return _dense
 
 
 def _lib():

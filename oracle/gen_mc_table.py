@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gen_mc_table.py -- build the 256-case marching-cubes triangle table used by BOTH the HIP kernels
-(lidar_transfer_amd/csrc/lt_mc_table.h) and the CPU oracle (oracle/lt_mc_table.h).  BUILD / TEST INFRASTRUCTURE.
+(lidar_transfer_amd/csrc/lt_mc_table.h), which the CPU oracle includes too (oracle/Makefile: -I../lidar_transfer_amd/csrc).  BUILD / TEST INFRASTRUCTURE.
 
 Why generated and not copied: the reference calls scikit-image's ``marching_cubes_lewiner``
 (/root/reference auxiliary/fusion_lidar.py:407); scikit-image is not part of the reference, is not importable in this
@@ -32,7 +32,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = [os.path.join(HERE, "lt_mc_table.h"), os.path.join(ROOT, "lidar_transfer_amd", "csrc", "lt_mc_table.h")]
+OUT = [os.path.join(ROOT, "lidar_transfer_amd", "csrc", "lt_mc_table.h")]  # ONE copy: the CPU oracle includes it from there
 
 
 def corner_offset(i):

@@ -60,11 +60,12 @@
 
 #define LTO_NORM_SSE 0
 #define LTO_NORM_EXACT 1
-#define LTO_NORM_SSE_TABLE 2 /* RSQRTSS emulated from oracle/rsqrt_sse_table.h (measured on an Intel CPU) */
+#define LTO_NORM_SSE_TABLE 2 /* RSQRTSS emulated from lidar_transfer_amd/csrc/lt_rsqrt_sse_table.h (measured on an Intel CPU) */
 
-#define LTO_NORM_AMD_TABLE 3 /* ... from oracle/rsqrt_amd_table.h (measured on the GPU box's AMD EPYC host) */
-#include "rsqrt_sse_table.h"
-#include "rsqrt_amd_table.h"
+#define LTO_NORM_AMD_TABLE 3 /* ... from lidar_transfer_amd/csrc/lt_rsqrt_amd_table.h (measured on the GPU box's AMD EPYC host) */
+/* ONE copy of each generated table: the product's (the Makefile adds -I../lidar_transfer_amd/csrc) */
+#include "lt_rsqrt_sse_table.h"
+#include "lt_rsqrt_amd_table.h"
 
 typedef struct {
   double t_setup_ms, t_build_ms, t_trace_ms;

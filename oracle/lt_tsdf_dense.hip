@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- not part of liblidarhip.so.
+// ORACLE / TEST INFRASTRUCTURE ONLY -- not part of liblidarhip.so; nothing in lidar_transfer_amd/ links or loads it.
 //
 // One thread per voxel: the reference's pycuda kernel `integrate` (/root/reference auxiliary/fusion_lidar.py:66-229,
 // CUDA source inside a Python string) restated statement by statement for the GPU, as the A/B baseline of the shipped
@@ -8,7 +8,8 @@
 // assumption the product makes and is NOT pinned against a CUDA run (parity unpinned for the
 // class-aware branch; tests/golden/make_golden_tsdf_cuda.py is the generator that would pin it).
 //
-// Built by tests/build_helpers.py into tests/lib/liblt_tsdf_dense.so; operates on raw device pointers.
+// Built by oracle/Makefile (target `dense`) into oracle/liblt_tsdf_dense.so; loaded by oracle.binding.dense_lib();
+// operates on raw device pointers.
 #include <hip/hip_runtime.h>
 #include <math.h>
 

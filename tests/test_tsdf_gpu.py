@@ -151,11 +151,10 @@ yaw = np.linspace(-np.pi, np.pi, W)
 half = 15.0 if voxel < 0.1 else 20.0
 vol = TSDFVolume(np.array([[-half, half], [-half, half], [-5.0, 5.0]]), voxel, fu, fd, merge=merge)   # 0.05: 600 x 600 x 200 = 72 M voxels
 if os.environ.get("LT_TEST_TSDF") == "dense":
-    # the A/B partner: the one-thread-per-voxel restatement of the reference kernel (tests/csrc/lt_tsdf_dense.hip, a
-    # TEST library) writes the volume's fields through their raw pointers; the product only allocates and resets them
-    sys.path.insert(0, os.path.join(sys.path[0], "tests"))
-    import build_helpers
-    dense = C.CDLL(build_helpers.build("liblt_tsdf_dense.so"))
+    # the A/B partner: the one-thread-per-voxel restatement of the reference kernel (oracle/lt_tsdf_dense.hip, an
+    # ORACLE library) writes the volume's fields through their raw pointers; the product only allocates and resets them
+    from oracle import binding as ob
+    dense = ob.dense_lib()
     def integrate_dense(color_im, depth_im, rem_im, cam_pose=None, obs_weight=1.):
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
         c = dev(color_im)
@@ -213,7 +212,7 @@ np.savez(sys.argv[1], **{f"{k}{i}": a for k, v in out.items() for i, a in enumer
                                                    (True, 15.0, -20.0, 0.25, (25, 301)), (True, 5.0, -30.0, 0.25, (70, 97))])
 def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge, fu, fd, voxel, hw):
     """The work-saving integrate (per-column image column and dead-column test, conservative sine test, dirty-column
-    reset) against the plain one-thread-per-voxel restatement of the reference kernel (tests/csrc/lt_tsdf_dense.hip: a TEST
+    reset) against the plain one-thread-per-voxel restatement of the reference kernel (oracle/lt_tsdf_dense.hip: an ORACLE
     library, not in liblidarhip.so) on a 72 M-voxel volume -- beyond 2^24
     voxels, where the reference's float voxel index misplaces voxels next to x boundaries -- two observations, a
     reset, the same two observations again: all four fields bit-identical, and the volume after the reset round equals
