@@ -997,6 +997,165 @@ def main():
                                                     "in per vertex")}}
         return rec
 
+    def deform_from_points(nscans=5, n=8):
+        """The reference's REAL loop body from point clouds, composed and timed (laserscan.py:863-918 + :1121-1178): per output
+        scan `nscans` source clouds (~120 k points each, float64 as after apply_pose) -> do_range_projection_new +
+        do_label_projection_new per cloud (ONE lt_range_projection_batch_dev call) -> fresh 2000x2000x200 volume, integrate
+        x nscans -> marching cubes -> ray cast of the target sensor -> write(): filter + pack the .bin / .label bytes
+        (lt_pack_scan_dev).  Nothing leaves HBM but the mesh sizes and the number of packed points.  `verified`: the source
+        images equal the single-cloud call's (lt_range_projection_dev, pinned to the reference's goldens), and the target
+        images + packed bytes equal the step-by-step API run from those images."""
+        import ctypes as C
+        from lidar_transfer_amd import _lib
+        from lidar_transfer_amd.deform import DeviceDeform
+        if torch.cuda.get_device_properties(dev).total_memory < 60 * 2**30 or args.target:
+            return None
+        lib = _lib.load()
+        vp = C.c_void_p
+        w = workers[0]
+        w.set_mesh(*scenes[0])
+        o = w.render(raysets[0], origin)
+        torch.cuda.synchronize()
+        hit = o["tri"] >= 0
+        p0 = o["endpoints"][hit].double()
+        l0 = o["endcolors"][hit][:, 2].contiguous().to(torch.int32)
+        r0 = o["endrem"][hit].contiguous()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4321)
+        clouds = []
+        for k in range(nscans):   # the neighbouring scans, re-projected into the primary pose: the same surfaces, centimetre noise, holes
+            if k == 0:
+                clouds.append((p0.contiguous(), r0, l0))
+                continue
+            keep = torch.rand(p0.shape[0], device=dev, generator=gen) > 0.05
+            scale = 1.0 + (torch.rand((int(keep.sum().item()), 1), device=dev, generator=gen, dtype=torch.float64) - 0.5) * 0.001
+            lk = l0[keep].clone()
+            flip = torch.rand(lk.shape[0], device=dev, generator=gen) < 0.02
+            lk[flip] = 50
+            clouds.append(((p0[keep] * scale).contiguous(), r0[keep].contiguous(), lk.contiguous()))
+        n_pts = [int(c[0].shape[0]) for c in clouds]
+        bnds = np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]])
+        dd = DeviceDeform((H, W, wl["fov_up"], wl["fov_down"]), (H, W, wl["fov_up"], wl["fov_down"]), bnds, 0.05,
+                          device=local_rank)
+        st = torch.cuda.current_stream(dev)
+        sp = vp(st.cuda_stream)
+        org = (C.c_float * 3)(*origin)
+        FLG = _lib.LT_TRACE_WRITE_MISSES | _lib.LT_TRACE_LABEL_IMAGE
+        out = dd.scene.alloc_outputs(R, label_image=True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        ms = np.zeros((n, 6))
+        t_wall = []
+        packed = None
+        for i in range(n + 2):
+            t0 = time.perf_counter()
+            ev[0].record()
+            src = dd.projector.project(clouds, dd.fov_up, dd.fov_down, H, W, new=True, remove=True,
+                                       outputs=("range", "rem", "label_folded"), stream=st)
+            ev[1].record()
+            _lib.check(lib.lt_tsdf_reset(dd.vol._h, sp), "reset")
+            ev[2].record()
+            for s_ in src:
+                _lib.check(lib.lt_tsdf_integrate_dev(dd.vol._h, s_["label_folded"].data_ptr(), s_["range"].data_ptr(),
+                                                     s_["rem"].data_ptr(), H, W, 1.0, _lib.LT_TSDF_MERGE, sp), "integrate")
+            ev[3].record()
+            _lib.check(lib.lt_tsdf_extract_mesh_dev(dd.vol._h, dd.mesh_obj._h, sp, None), "marching cubes")
+            ev[4].record()
+            _lib.check(lib.lt_scene_set_mesh(dd.scene._h, dd.mesh_obj._h), "set mesh")
+            _lib.check(lib.lt_scene_render_dev(dd.scene._h, dd.rayset._h, org, out["endpoints"].data_ptr(),
+                                               out["endcolors"].data_ptr(), out["range"].data_ptr(),
+                                               out["endrem"].data_ptr(), out["tri"].data_ptr(), FLG, sp, None), "render")
+            ev[5].record()
+            packed = dd._pack(out["endpoints"], False, out["endrem"], out["endcolors"], None, R, st)
+            ev[6].record()
+            torch.cuda.synchronize()
+            if i > 1:
+                t_wall.append(time.perf_counter() - t0)
+                ms[i - 2] = [ev[k].elapsed_time(ev[k + 1]) for k in range(6)]
+        # the same chain as ONE DeviceDeform.mesh() call (lt_range_projection_batch_dev -> lt_fusion_scan_dev -> lt_pack_scan_dev)
+        t_one = []
+        for i in range(n + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = dd.mesh(clouds, origin)
+            torch.cuda.synchronize()
+            if i:
+                t_one.append(time.perf_counter() - t0)
+        # ---- verification against the step-by-step API -----------------------------------------------------------------
+        ok = True
+        from lidar_transfer_amd.laserscan import SemLaserScan
+        for k, (pk, rk, lk) in enumerate(clouds):
+            s = SemLaserScan(H, W, 300, {})
+            s.points, s.remissions, s.label = pk.cpu().numpy(), rk.cpu().numpy(), lk.cpu().numpy().astype(np.uint32)
+            s.do_range_projection_new(dd.fov_up, dd.fov_down, remove=True)   # the single-cloud call (host arrays in and out)
+            ok = ok and np.array_equal(src[k]["range"].cpu().numpy().view(np.int32), s.range_image.view(np.int32))
+            ok = ok and np.array_equal(src[k]["rem"].cpu().numpy().view(np.int32), s.proj_remissions.view(np.int32))
+            ok = ok and np.array_equal(src[k]["label_folded"].cpu().numpy(),
+                                       np.floor(s.label_image[:, :, 0].astype(np.float32) * 256 * 256))
+        same_call = bool(torch.equal(got["range"].reshape(-1).view(torch.int32), out["range"].view(torch.int32))) and \
+            bool(torch.equal(got["label"].reshape(-1), out["endcolors"])) and bool(torch.equal(got["bin"], packed[0])) and \
+            bool(torch.equal(got["label_file"], packed[1]))
+        ok = ok and same_call
+        hits_c = int((out["range"] > 0).sum().item())
+        nv, nf = dd.mesh_obj.n_verts, dd.mesh_obj.n_faces
+        n_packed = int(packed[0].shape[0])
+        # ---- projection alone: `reps` batch calls back to back (events on the launch stream) ------------------------------
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outs_keep = [dict(s_) for s_ in src]
+        for _ in range(3):
+            dd.projector.project(clouds, dd.fov_up, dd.fov_down, H, W, new=True, remove=True, out=outs_keep,
+                                 outputs=("range", "rem", "label_folded"), stream=st)
+        e0.record()
+        for _ in range(reps):
+            dd.projector.project(clouds, dd.fov_up, dd.fov_down, H, W, new=True, remove=True, out=outs_keep,
+                                 outputs=("range", "rem", "label_folded"), stream=st)
+        e1.record()
+        torch.cuda.synchronize()
+        proj_ms = e0.elapsed_time(e1) / reps
+        # the single-cloud device call for comparison (four kernels + a host synchronisation per cloud)
+        kept = C.c_int(0)
+        t_single = []
+        for rep_ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for (pk, rk, lk), s_ in zip(clouds, outs_keep):
+                _lib.check(lib.lt_range_projection_dev(pk.data_ptr(), 1, rk.data_ptr(), lk.data_ptr(), int(pk.shape[0]),
+                                                       float(dd.fov_up), float(dd.fov_down), H, W, None, 0,
+                                                       _lib.LT_PROJ_NEW | _lib.LT_PROJ_REMOVE, None, 0, None, None, None,
+                                                       None, None, None, None, None, None, s_["range"].data_ptr(), None,
+                                                       s_["rem"].data_ptr(), None, None, None, 0.0, -1.0, 0.0,
+                                                       C.byref(kept), sp), "lt_range_projection_dev")
+            torch.cuda.synchronize()
+            if rep_ > 1:
+                t_single.append(time.perf_counter() - t0)
+        filled = sum(int((s_["range"] > 0).sum().item()) for s_ in outs_keep)
+        tot_pts = sum(n_pts)
+        alg = tot_pts * (24 + 8) + nscans * R * (16 + 12) + filled * (24 + 8)
+        dd.close()
+        m = np.median(ms, axis=0)
+        t = float(np.median(t_wall))
+        return {"what": f"deform('mesh') + write() per output scan from {nscans} float64 point clouds of {n_pts[0]}..{min(n_pts)} points "
+                        f"(laserscan.py:863-918, :1121-1178): batched z-min projection -> reset 2000x2000x200 volume -> integrate "
+                        f"x{nscans} -> marching cubes -> render {H}x{W} -> pack .bin/.label bytes; all in HBM",
+                "observations": nscans, "points_per_scan": n_pts, "ms_per_output_scan": round(t * 1e3, 3),
+                "ms_per_output_scan_one_call": round(float(np.median(t_one)) * 1e3, 3),
+                "output_scans_per_s": round(1.0 / t, 1),
+                "phase_ms": {"projection": round(float(m[0]), 4), "reset": round(float(m[1]), 4),
+                             "integrate": round(float(m[2]), 4), "marching_cubes": round(float(m[3]), 4),
+                             "render": round(float(m[4]), 4), "pack": round(float(m[5]), 4)},
+                "mesh_verts": nv, "mesh_faces": nf, "hit_fraction": round(hits_c / R, 4), "points_written": n_packed,
+                "verified": bool(ok),
+                "projection": {"ms": round(proj_ms, 4), "clouds_per_call": nscans, "us_per_cloud": round(proj_ms * 1e3 / nscans, 2),
+                               "Mpoints_per_s": round(tot_pts / proj_ms / 1e3, 1), "dtype": "f64",
+                               "algorithmic_bytes_per_call": int(alg),
+                               "achieved": round(alg / (proj_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(alg / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "atomics_G_per_s": round(tot_pts / (proj_ms * 1e-3) / 1e9, 2), "atomic_ceiling_G_per_s": ATOMIC_CEILING_G,
+                               "single_cloud_call_ms_per_cloud": round(float(np.median(t_single)) * 1e3 / nscans, 4),
+                               "bytes": "per point 24 B in + one 8-B memory-side atomicMin; per cell 16 B key read + re-arm, 12 B "
+                                        "of images out (range, remission, folded label); per filled cell 24 + 8 B gathered",
+                               "kernels": ["k_pb_project", "k_pb_resolve"]}}
+
     def e2e_pipelined(n_scans=200, depth=4):
         """The same host-buffer work for a SEQUENCE of scans (the reference's loop over output scans): lt_hostpipe keeps
         `depth` scans in flight -- uploads of scans i+1, i+2 (two uploader threads) | render of scan i | download of scan
@@ -1124,6 +1283,7 @@ def main():
     chain = guarded("fusion_chain", fusion_chain) if (rank == 0 and not args.no_chain and world == 1) else None
     chain5 = guarded("fusion_chain_nscans5", fusion_chain, 4, 5) if (chain and rank == 0 and world == 1) else None
 
+    from_points = guarded("deform_from_points", deform_from_points) if (chain and rank == 0 and world == 1) else None
     if chain:
         chain["pipelined"] = (pipelined or [None, None])[0]
     if chain5:
@@ -1209,6 +1369,9 @@ def main():
             out["fusion_chain"] = chain
         if chain5:
             out["fusion_chain_nscans5"] = chain5
+        if from_points:
+            out["deform_from_points"] = from_points
+            out["projection"] = from_points["projection"]
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             cb = guarded("cpu_baseline", cpu_baseline, wl, 0, args.cpu_reps or 12)
             out["cpu_baseline"] = cb

@@ -263,6 +263,58 @@ int lt_range_projection(const void* points, int is_f64, const float* rem, const 
                         float* range_img, float* xyz_img, float* rem_img, int* label_img, float* color_img,
                         float* mask_img, float range_init, float rem_init, float xyz_init, int* n_kept);
 
+/*
+ * lt_range_projection_batch_dev -- the same projection for SEVERAL clouds in one launch sequence, nothing read back by the
+ * host, no memsets between calls: the `number_of_scans` observations of one output scan (MultiSemLaserScan.deform,
+ * auxiliary/laserscan.py:874-881: do_range_projection_new + do_label_projection_new per source scan; :841-843 for the merged
+ * cloud of the `cp` adaption).  Same per-point arithmetic and the same winner per cell as lt_range_projection_dev; the
+ * per-point COMPACTED outputs of that call are not produced -- what the callers downstream consume are images:
+ *
+ *   lt_projector   owns the z-min workspace (one per caller thread / HIP stream; calls on one projector are serialised)
+ *   clouds[k]      DEVICE pointers of cloud k: points [n,3] f32 / f64 (is_f64, one dtype per call), rem [n] f32 or NULL,
+ *                  label [n] u32 or NULL
+ *   out[k]         [H*W] DEVICE images of cloud k, every member may be NULL:
+ *                    idx            index of the winning point among the KEPT points (remove_points numbering), -1 empty
+ *                    range, xyz [H*W,3], rem, label, color [H*W,3], mask    as lt_range_projection_dev
+ *                    label_folded   float32 floor(label * 256 * 256): the colour image TSDFVolume.integrate folds from
+ *                                   proj_label3 (laserscan.py:893-895, fusion_lidar.py:260-264) -- feed it to
+ *                                   lt_tsdf_integrate_dev / lt_fusion_scan_dev as color_im
+ *                    proj_x, proj_y int32 pixel of the winner; proj_xf, proj_yf its unclamped coordinates in the points'
+ *                                   dtype (do_range_projection_new's proj_x / proj_y / proj_x_float / proj_y_float,
+ *                                   laserscan.py:384-388; an EMPTY cell holds the values of the last kept point, numpy's
+ *                                   index -1)
+ *                    n_kept         DEVICE int: number of points that survived the removals
+ * Asynchronous on `stream`; more than 8 clouds are processed in groups of 8.
+ */
+typedef struct lt_projector lt_projector;
+typedef struct lt_cloud {
+  const void* points;
+  const float* rem;
+  const unsigned* label;
+  int n;
+} lt_cloud;
+typedef struct lt_proj_images {
+  int* idx;
+  float* range;
+  float* xyz;
+  float* rem;
+  int* label;
+  float* color;
+  float* mask;
+  float* label_folded;
+  int* proj_x;
+  int* proj_y;
+  void* proj_xf;
+  void* proj_yf;
+  int* n_kept;
+} lt_proj_images;
+int lt_projector_create(lt_projector** projector, int device);
+int lt_projector_destroy(lt_projector* projector);
+int lt_range_projection_batch_dev(lt_projector* projector, int n_clouds, const lt_cloud* clouds, int is_f64,
+                                  double fov_up, double fov_down, int H, int W, const double* beam_angles, int n_beams,
+                                  unsigned flags, const float* color_lut, int lut_len, const lt_proj_images* out,
+                                  float range_init, float rem_init, float xyz_init, void* stream);
+
 /* ---- before the render: class-aware TSDF fusion of range images (device-resident volumes) -------- */
 
 typedef struct lt_tsdf lt_tsdf; /* opaque: four float32 volumes [dim_x][dim_y][dim_z] (tsdf, weight, colour, rem) */

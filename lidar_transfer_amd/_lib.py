@@ -29,7 +29,8 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
            "lt_tsdf_volumes", "lt_tsdf_touch", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_fusion_scan_dev", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
-           "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free"]
+           "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free", "lt_projector_create",
+           "lt_projector_destroy", "lt_range_projection_batch_dev"]
 
 
 class Stats(C.Structure):
@@ -42,6 +43,17 @@ class Stats(C.Structure):
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Cloud(C.Structure):
+    """Mirror of ``lt_cloud`` (include/lidarhip.h): DEVICE pointers of one point cloud of a batch."""
+    _fields_ = [("points", C.c_void_p), ("rem", C.c_void_p), ("label", C.c_void_p), ("n", C.c_int)]
+
+
+class ProjImages(C.Structure):
+    """Mirror of ``lt_proj_images``: the [H*W] DEVICE images of one cloud; NULL = not wanted."""
+    _fields_ = [(k, C.c_void_p) for k in ("idx", "range", "xyz", "rem", "label", "color", "mask", "label_folded", "proj_x",
+                                           "proj_y", "proj_xf", "proj_yf", "n_kept")]
 
 
 _lib = None
@@ -151,6 +163,13 @@ def load():
     lib.lt_range_projection.restype = C.c_int
     lib.lt_range_projection_dev.argtypes = proj + [vp]
     lib.lt_range_projection_dev.restype = C.c_int
+    lib.lt_projector_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.lt_projector_destroy.argtypes = [vp]
+    lib.lt_range_projection_batch_dev.argtypes = [vp, C.c_int, C.POINTER(Cloud), C.c_int, C.c_double, C.c_double, C.c_int,
+                                                  C.c_int, vp, C.c_int, C.c_uint, vp, C.c_int, C.POINTER(ProjImages),
+                                                  C.c_float, C.c_float, C.c_float, vp]
+    for name in ("lt_projector_create", "lt_projector_destroy", "lt_range_projection_batch_dev"):
+        getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
 

@@ -17,7 +17,10 @@
 // float32 transcendental results are the correctly rounded value (computed in double, rounded once).
 #include "lt_internal.h"
 #include <math.h>
+#include <string.h>
+#include <algorithm>
 #include <mutex>
+#include <new>
 
 #define LT_EMPTY_IDX 0x7F7F7F7F  // hipMemset(0x7F) pattern: larger than any point index
 
@@ -365,6 +368,374 @@ extern "C" int lt_range_projection_dev(const void* points, int is_f64, const flo
                                proj_x_kept, proj_y_kept, (float*)proj_xf_kept, (float*)proj_yf_kept, idx_img,
                                range_img, xyz_img, rem_img, label_img, color_img, mask_img, range_init, rem_init,
                                xyz_init, n_kept, st);
+}
+
+// ---- batched, synchronisation-free projection (lt_range_projection_batch_dev) ------------------------------------------
+// The `number_of_scans` clouds of one output scan (laserscan.py:874-881: do_range_projection_new + do_label_projection_new
+// per scan) in ONE launch sequence on the caller's stream, nothing read back by the host:
+//   k_pb_project   a thread per point of every cloud: the reference's per-point expressions (project_point, above) and ONE
+//                  64-bit atomicMin per kept point -- no per-point temporaries are written (the single-cloud call stores
+//                  cell / depth / xf / yf per point: 28 B written and read again per point);
+//   [k_pb_assign]  only for the OLD variant on float64 clouds, whose order key (a float64 depth) leaves no room for the index
+//   [k_pb_prefix]  only when an output needs the numbering of the KEPT points (idx / mask images, proj_x .. images, n_kept)
+//   k_pb_resolve   a thread per cell of every image: decodes the winner, RE-COMPUTES its projection from the point itself
+//                  (the same deterministic function), gathers remission / label / colour, writes the images and re-arms the
+//                  cell's key for the next call (no memsets between calls).
+// The key.  `_new` keeps its running minimum in a float32 image and replaces when `depth[i] < image` (laserscan.py:366, :376):
+// the winner is the first point of the minimum's float32 bucket unless points of that bucket lie BELOW the float32 value
+// (rounded up) -- then the last of those.  hi word = float32 bits of the depth (positive floats order like unsigned
+// integers); lo word = 0x7fffffff - index for a rounded-up point (they beat the others, the highest index first),
+// 0x80000000 | index otherwise (lowest index first): one atomicMin yields exactly that point.  float32 clouds never round.
+// The OLD variant on float32 clouds: closest point, lowest index among equal depths (k_project's rule) -- the same key.
+#define LT_PB_MAX 8
+#define LT_PB_EMPTY (~0ull)
+
+struct pb_cloud {
+  const void* pts; const float* rem; const unsigned* label;
+  int n, block0;                 // points; first workgroup of this cloud in the per-point grids
+  unsigned long long* key;       // [cells] z-min key, LT_PB_EMPTY when no point fell into the cell
+  unsigned long long* dmin;      // [cells] float64 depth bits (OLD variant on float64 clouds), else unused
+  unsigned long long* keep;      // [ceil(n / 64)] kept-point mask per wave of k_pb_project
+  int* wprefix;                  // [ceil(n / 64)] kept points before the wave (k_pb_prefix)
+  int* meta;                     // [2] number of kept points, original index of the last kept point (-1: none)
+  int* idx_img; float* range_img; float* xyz_img; float* rem_img; int* label_img; float* color_img; float* mask_img;
+  float* fold_img; int* px_img; int* py_img; void* xf_img; void* yf_img; int* n_kept;
+};
+struct pb_args { pb_cloud c[LT_PB_MAX]; int n_clouds; };
+
+__device__ __forceinline__ int pb_find_cloud(const pb_args& A, int block) {
+  int c = 0;
+#pragma unroll
+  for (int k = 1; k < LT_PB_MAX; ++k)
+    if (k < A.n_clouds && block >= A.c[k].block0) c = k;
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned long long pb_key(T depth, int i) {
+  const float df = (float)depth;
+  const bool up = (double)depth < (double)df;  // lies below its float32 value: replaces an incumbent of the same bucket
+  const unsigned lo = up ? (0x7fffffffu - (unsigned)i) : (0x80000000u | (unsigned)i);
+  return ((unsigned long long)__float_as_uint(df) << 32) | lo;
+}
+__device__ __forceinline__ int pb_key_index(unsigned long long k) {
+  const unsigned lo = (unsigned)k;
+  return (lo & 0x80000000u) ? (int)(lo & 0x7fffffffu) : (int)(0x7fffffffu - lo);
+}
+
+// MODE 0: the single-key variants (NEW on any dtype, OLD on float32).  MODE 1: OLD on float64 -- depth minimum only.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_pb_project(pb_args A, T pi_t, T abs_fov_down, T fov, int H, int W,
+                                                    const double* __restrict__ beams, int n_beams, int drop_zero,
+                                                    int drop_outside) {
+  const int ci = pb_find_cloud(A, blockIdx.x);
+  const pb_cloud& c = A.c[ci];
+  const int i = (blockIdx.x - c.block0) * 256 + threadIdx.x;
+  bool keep = false;
+  if (i < c.n) {
+    const T* pts = (const T*)c.pts;
+    const proj_out<T> o = project_point<T>(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], pi_t,
+                                           abs_fov_down, fov, H, W, beams, n_beams, drop_zero, drop_outside);
+    keep = o.cell >= 0;
+    if (keep) {
+      if (MODE == 0) atomicMin(&c.key[o.cell], pb_key<T>(o.depth, i));
+      else atomicMin(&c.dmin[o.cell], (unsigned long long)__double_as_longlong((double)o.depth));
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && i < c.n) c.keep[i >> 6] = m;
+}
+
+// OLD variant, float64: among the points that equal the cell's depth minimum the lowest index wins
+__global__ __launch_bounds__(256) void k_pb_assign(pb_args A, double pi_t, double abs_fov_down, double fov, int H, int W,
+                                                   const double* __restrict__ beams, int n_beams, int drop_zero,
+                                                   int drop_outside) {
+  const int ci = pb_find_cloud(A, blockIdx.x);
+  const pb_cloud& c = A.c[ci];
+  const int i = (blockIdx.x - c.block0) * 256 + threadIdx.x;
+  if (i >= c.n) return;
+  if (!((c.keep[i >> 6] >> (i & 63)) & 1ull)) return;
+  const double* pts = (const double*)c.pts;
+  const proj_out<double> o = project_point<double>(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], pi_t,
+                                                   abs_fov_down, fov, H, W, beams, n_beams, drop_zero, drop_outside);
+  if ((unsigned long long)__double_as_longlong(o.depth) == c.dmin[o.cell])
+    atomicMin(&c.key[o.cell], (unsigned long long)(0x80000000u | (unsigned)i));
+}
+
+// one workgroup per cloud: exclusive prefix of the waves' kept counts, the total, the last kept point
+__global__ __launch_bounds__(256) void k_pb_prefix(pb_args A) {
+  __shared__ int part[256];
+  __shared__ int last_s;
+  const pb_cloud& c = A.c[blockIdx.x];
+  const int nw = (c.n + 63) >> 6;
+  const int per = (nw + 255) / 256;
+  const int w0 = threadIdx.x * per, w1 = min(nw, w0 + per);
+  if (threadIdx.x == 0) last_s = -1;
+  int sum = 0, last = -1;
+  for (int w = w0; w < w1; ++w) {
+    const unsigned long long m = c.keep[w];
+    sum += __popcll(m);
+    if (m) last = w * 64 + 63 - __clzll((long long)m);
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (last >= 0) atomicMax(&last_s, last);
+  // Hillis-Steele over 256 partials
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+  for (int w = w0; w < w1; ++w) {
+    c.wprefix[w] = run;
+    run += __popcll(c.keep[w]);
+  }
+  if (threadIdx.x == 255) {
+    c.meta[0] = part[255];
+    c.meta[1] = last_s;
+    if (c.n_kept) *c.n_kept = part[255];
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_pb_resolve(pb_args A, int blocks_per_cloud, T pi_t, T abs_fov_down, T fov, int H,
+                                                    int W, const double* __restrict__ beams, int n_beams, int drop_zero,
+                                                    int drop_outside, const float* __restrict__ lut, int lut_len,
+                                                    float range_init, float rem_init, float xyz_init, int have_prefix) {
+  const int ci = blockIdx.x / blocks_per_cloud;
+  const pb_cloud& c = A.c[ci];
+  const int cell = (blockIdx.x - ci * blocks_per_cloud) * 256 + threadIdx.x;
+  if (cell >= H * W) return;
+  const unsigned long long key = c.key[cell];
+  c.key[cell] = LT_PB_EMPTY;
+  if (MODE == 1) c.dmin[cell] = LT_PB_EMPTY;
+  const bool has = key != LT_PB_EMPTY;
+  const T* pts = (const T*)c.pts;
+  const bool want_xy = c.px_img || c.py_img || c.xf_img || c.yf_img;
+  // an empty cell's pixel coordinates are those of the LAST kept point: numpy's index -1 (laserscan.py:384-388)
+  int i = has ? pb_key_index(key) : ((want_xy && have_prefix) ? c.meta[1] : -1);
+  T x = (T)0, y = (T)0, z = (T)0;
+  proj_out<T> o;
+  o.depth = (T)0; o.xf = (T)0; o.yf = (T)0; o.px = 0; o.py = 0; o.cell = -1;
+  if (i >= 0) {
+    x = pts[3 * (size_t)i]; y = pts[3 * (size_t)i + 1]; z = pts[3 * (size_t)i + 2];
+    if (has ? (want_xy || c.range_img) : true)
+      o = project_point<T>(x, y, z, pi_t, abs_fov_down, fov, H, W, beams, n_beams, drop_zero, drop_outside);
+  }
+  int k = -1;
+  if (has && have_prefix) k = c.wprefix[i >> 6] + __popcll(c.keep[i >> 6] & ((1ull << (i & 63)) - 1ull));
+  if (c.idx_img) c.idx_img[cell] = has ? k : -1;
+  if (c.range_img) c.range_img[cell] = has ? (float)o.depth : range_init;
+  if (c.xyz_img) {
+    c.xyz_img[3 * (size_t)cell] = has ? (float)x : xyz_init;
+    c.xyz_img[3 * (size_t)cell + 1] = has ? (float)y : xyz_init;
+    c.xyz_img[3 * (size_t)cell + 2] = has ? (float)z : xyz_init;
+  }
+  if (c.rem_img) c.rem_img[cell] = (has && c.rem) ? c.rem[i] : rem_init;
+  const unsigned lab = (has && c.label) ? c.label[i] : 0u;
+  if (c.label_img) c.label_img[cell] = (int)lab;
+  // the colour image `integrate` is handed, already folded (laserscan.py:893-895: the label in channel 0;
+  // fusion_lidar.py:260-264: float32, floor(c0 * 256 * 256 + c1 * 256 + c2))
+  if (c.fold_img) c.fold_img[cell] = floorf((float)lab * 256.0f * 256.0f);
+  if (c.color_img) {
+    const bool ok = has && lut && (int)lab < lut_len;
+    c.color_img[3 * (size_t)cell] = ok ? lut[3 * (size_t)lab] : 0.f;
+    c.color_img[3 * (size_t)cell + 1] = ok ? lut[3 * (size_t)lab + 1] : 0.f;
+    c.color_img[3 * (size_t)cell + 2] = ok ? lut[3 * (size_t)lab + 2] : 0.f;
+  }
+  if (c.mask_img) c.mask_img[cell] = (has && k > 0) ? 1.f : 0.f;  // proj_idx > 0 (sic, laserscan.py:292)
+  if (c.px_img) c.px_img[cell] = o.px;
+  if (c.py_img) c.py_img[cell] = o.py;
+  if (c.xf_img) ((T*)c.xf_img)[cell] = o.xf;
+  if (c.yf_img) ((T*)c.yf_img)[cell] = o.yf;
+}
+
+struct lt_projector {
+  int device = 0;
+  size_t cap_n = 0, cap_cells = 0;          // per cloud slot
+  bool armed = false, dmin_armed = false;
+  unsigned long long* key[LT_PB_MAX] = {};
+  unsigned long long* dmin[LT_PB_MAX] = {};
+  unsigned long long* keep[LT_PB_MAX] = {};
+  int* wprefix[LT_PB_MAX] = {};
+  int* meta = nullptr;                      // [LT_PB_MAX][2]
+  double* beams = nullptr;                  // [1024]
+  double beams_host[1024];
+  int n_beams_cached = -1;
+  std::mutex mu;
+};
+
+namespace {
+void pj_free(lt_projector* p) {
+  for (int k = 0; k < LT_PB_MAX; ++k) {
+    void* ps[] = {p->key[k], p->dmin[k], p->keep[k], p->wprefix[k]};
+    for (void* q : ps)
+      if (q) (void)hipFree(q);
+    p->key[k] = p->dmin[k] = p->keep[k] = nullptr;
+    p->wprefix[k] = nullptr;
+  }
+  p->cap_n = p->cap_cells = 0;
+  p->armed = p->dmin_armed = false;
+}
+
+int pj_reserve(lt_projector* p, size_t n_max, size_t cells, bool need_dmin, hipStream_t st) {
+  if (n_max > p->cap_n || cells > p->cap_cells) {
+    if (p->cap_n || p->cap_cells) LT_HIP(hipStreamSynchronize(st));
+    const size_t cn = std::max(p->cap_n, n_max + n_max / 4 + 1024), cc = std::max(p->cap_cells, cells + 1024);
+    pj_free(p);
+    for (int k = 0; k < LT_PB_MAX; ++k) {
+      LT_HIP(hipMalloc((void**)&p->key[k], cc * sizeof(unsigned long long)));
+      LT_HIP(hipMalloc((void**)&p->keep[k], (cn / 64 + 2) * sizeof(unsigned long long)));
+      LT_HIP(hipMalloc((void**)&p->wprefix[k], (cn / 64 + 2) * sizeof(int)));
+    }
+    p->cap_n = cn;
+    p->cap_cells = cc;
+  }
+  if (need_dmin && !p->dmin[0]) {
+    for (int k = 0; k < LT_PB_MAX; ++k) LT_HIP(hipMalloc((void**)&p->dmin[k], p->cap_cells * sizeof(unsigned long long)));
+    p->dmin_armed = false;
+  }
+  if (!p->armed)
+    for (int k = 0; k < LT_PB_MAX; ++k)
+      LT_HIP(hipMemsetAsync(p->key[k], 0xFF, p->cap_cells * sizeof(unsigned long long), st));
+  if (need_dmin && !p->dmin_armed)
+    for (int k = 0; k < LT_PB_MAX; ++k)
+      LT_HIP(hipMemsetAsync(p->dmin[k], 0xFF, p->cap_cells * sizeof(unsigned long long), st));
+  return LT_OK;
+}
+
+template <typename T>
+int pj_run(lt_projector* p, pb_args& A, int total_blocks, bool old_f64, bool need_prefix, double fov_up_deg,
+           double fov_down_deg, int H, int W, int n_beams, unsigned flags, const float* lut, int lut_len, float range_init,
+           float rem_init, float xyz_init, hipStream_t st) {
+  const double fu = fov_up_deg / 180.0 * M_PI, fd = fov_down_deg / 180.0 * M_PI;
+  const double fov = fabs(fd) + fabs(fu);
+  const int drop_zero = (flags & (LT_PROJ_REMOVE | LT_PROJ_NEW)) ? 1 : 0, drop_outside = (flags & LT_PROJ_REMOVE) ? 1 : 0;
+  const int cells = H * W, bpc = (cells + 255) / 256;
+  if (total_blocks > 0) {
+    if (old_f64) {
+      hipLaunchKernelGGL((k_pb_project<T, 1>), dim3(total_blocks), dim3(256), 0, st, A, (T)M_PI, (T)fabs(fd), (T)fov, H, W,
+                         (const double*)p->beams, n_beams, drop_zero, drop_outside);
+      hipLaunchKernelGGL(k_pb_assign, dim3(total_blocks), dim3(256), 0, st, A, M_PI, fabs(fd), fov, H, W,
+                         (const double*)p->beams, n_beams, drop_zero, drop_outside);
+    } else {
+      hipLaunchKernelGGL((k_pb_project<T, 0>), dim3(total_blocks), dim3(256), 0, st, A, (T)M_PI, (T)fabs(fd), (T)fov, H, W,
+                         (const double*)p->beams, n_beams, drop_zero, drop_outside);
+    }
+  }
+  if (need_prefix) hipLaunchKernelGGL(k_pb_prefix, dim3(A.n_clouds), dim3(256), 0, st, A);
+  if (old_f64)
+    hipLaunchKernelGGL((k_pb_resolve<T, 1>), dim3(bpc * A.n_clouds), dim3(256), 0, st, A, bpc, (T)M_PI, (T)fabs(fd), (T)fov,
+                       H, W, (const double*)p->beams, n_beams, drop_zero, drop_outside, lut, lut_len, range_init, rem_init,
+                       xyz_init, need_prefix ? 1 : 0);
+  else
+    hipLaunchKernelGGL((k_pb_resolve<T, 0>), dim3(bpc * A.n_clouds), dim3(256), 0, st, A, bpc, (T)M_PI, (T)fabs(fd), (T)fov,
+                       H, W, (const double*)p->beams, n_beams, drop_zero, drop_outside, lut, lut_len, range_init, rem_init,
+                       xyz_init, need_prefix ? 1 : 0);
+  LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+}  // namespace
+
+extern "C" int lt_projector_create(lt_projector** pj, int device) {
+  if (!pj) {
+    lt_set_error("lt_projector_create: NULL handle pointer");
+    return LT_ERR_INVALID_ARG;
+  }
+  *pj = nullptr;
+  int dev = device;
+  if (dev < 0) LT_HIP(hipGetDevice(&dev));
+  LT_HIP(hipSetDevice(dev));
+  lt_projector* p = new (std::nothrow) lt_projector();
+  if (!p) {
+    lt_set_error("lt_projector_create: out of host memory");
+    return LT_ERR_NO_MEMORY;
+  }
+  p->device = dev;
+  if (hipMalloc((void**)&p->meta, LT_PB_MAX * 2 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&p->beams, 1024 * sizeof(double)) != hipSuccess) {
+    if (p->meta) (void)hipFree(p->meta);
+    delete p;
+    (void)hipGetLastError();
+    lt_set_error("lt_projector_create: out of device memory");
+    return LT_ERR_NO_MEMORY;
+  }
+  *pj = p;
+  return LT_OK;
+}
+
+extern "C" int lt_projector_destroy(lt_projector* p) {
+  if (!p) return LT_OK;
+  (void)hipSetDevice(p->device);
+  (void)hipDeviceSynchronize();
+  pj_free(p);
+  if (p->meta) (void)hipFree(p->meta);
+  if (p->beams) (void)hipFree(p->beams);
+  delete p;
+  return LT_OK;
+}
+
+extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, const lt_cloud* clouds, int is_f64,
+                                             double fov_up, double fov_down, int H, int W, const double* beam_angles,
+                                             int n_beams, unsigned flags, const float* color_lut, int lut_len,
+                                             const lt_proj_images* out, float range_init, float rem_init, float xyz_init,
+                                             void* stream) {
+  if (!p || n_clouds < 0 || (n_clouds > 0 && (!clouds || !out)) || H <= 0 || W <= 0 || n_beams < 0 || n_beams > 1024 ||
+      (n_beams > 0 && !beam_angles)) {
+    lt_set_error("lt_range_projection_batch_dev: invalid argument (n_clouds=%d H=%d W=%d n_beams=%d)", n_clouds, H, W, n_beams);
+    return LT_ERR_INVALID_ARG;
+  }
+  size_t n_max = 0;
+  for (int k = 0; k < n_clouds; ++k) {
+    if (clouds[k].n < 0 || (clouds[k].n > 0 && !clouds[k].points)) {
+      lt_set_error("lt_range_projection_batch_dev: cloud %d: n=%d points=%p", k, clouds[k].n, clouds[k].points);
+      return LT_ERR_INVALID_ARG;
+    }
+    n_max = std::max(n_max, (size_t)clouds[k].n);
+  }
+  std::lock_guard<std::mutex> lock(p->mu);
+  LT_HIP(hipSetDevice(p->device));
+  hipStream_t st = (hipStream_t)stream;
+  const bool old_f64 = is_f64 && !(flags & LT_PROJ_NEW);
+  LT_CHECK(pj_reserve(p, n_max, (size_t)H * W, old_f64, st));
+  p->armed = false;  // (until the resolve pass of this call has been queued)
+  if (old_f64) p->dmin_armed = false;
+  if (n_beams > 0 && (n_beams != p->n_beams_cached || memcmp(p->beams_host, beam_angles, n_beams * sizeof(double)) != 0)) {
+    // the table is read by kernels of EARLIER calls on this stream: the copy is stream-ordered behind them; a pageable
+    // source is staged by the runtime before the call returns, so beams_host may be overwritten by the next call
+    memcpy(p->beams_host, beam_angles, n_beams * sizeof(double));
+    LT_HIP(hipMemcpyAsync(p->beams, p->beams_host, n_beams * sizeof(double), hipMemcpyHostToDevice, st));
+    p->n_beams_cached = n_beams;
+  }
+  for (int g0 = 0; g0 < n_clouds; g0 += LT_PB_MAX) {
+    pb_args A;
+    A.n_clouds = std::min(LT_PB_MAX, n_clouds - g0);
+    int blocks = 0;
+    bool need_prefix = false;
+    for (int k = 0; k < A.n_clouds; ++k) {
+      const lt_cloud& ci = clouds[g0 + k];
+      const lt_proj_images& o = out[g0 + k];
+      pb_cloud& c = A.c[k];
+      c.pts = ci.points; c.rem = ci.rem; c.label = ci.label; c.n = ci.n; c.block0 = blocks;
+      blocks += (ci.n + 255) / 256;
+      c.key = p->key[k]; c.dmin = p->dmin[k]; c.keep = p->keep[k]; c.wprefix = p->wprefix[k]; c.meta = p->meta + 2 * k;
+      c.idx_img = o.idx; c.range_img = o.range; c.xyz_img = o.xyz; c.rem_img = o.rem; c.label_img = o.label;
+      c.color_img = o.color; c.mask_img = o.mask; c.fold_img = o.label_folded; c.px_img = o.proj_x; c.py_img = o.proj_y;
+      c.xf_img = o.proj_xf; c.yf_img = o.proj_yf; c.n_kept = o.n_kept;
+      need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept;
+    }
+    for (int k = A.n_clouds; k < LT_PB_MAX; ++k) { A.c[k] = A.c[0]; A.c[k].n = 0; A.c[k].block0 = 0x7fffffff; }
+    const int rc = is_f64 ? pj_run<double>(p, A, blocks, old_f64, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
+                                           color_lut, lut_len, range_init, rem_init, xyz_init, st)
+                          : pj_run<float>(p, A, blocks, false, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
+                                          color_lut, lut_len, range_init, rem_init, xyz_init, st);
+    if (rc != LT_OK) return rc;
+  }
+  p->armed = true;  // k_pb_resolve re-armed every cell it looked at
+  if (old_f64) p->dmin_armed = true;
+  return LT_OK;
 }
 
 // Host-pointer convenience: stages everything through device buffers, same semantics.

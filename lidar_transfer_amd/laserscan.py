@@ -41,6 +41,107 @@ def create_rays_device(fov_up, fov_down, H, W, device=None, stream=None):
     return out
 
 
+class Projector:
+    """Batched, synchronisation-free spherical projection on the GPU (``lt_range_projection_batch_dev``): the
+    ``number_of_scans`` clouds of one output scan -- ``do_range_projection_new`` + ``do_label_projection_new`` per source scan
+    in ``MultiSemLaserScan.deform`` (auxiliary/laserscan.py:874-881) -- in one launch sequence on the caller's stream, images
+    out as CUDA tensors, nothing read back.  One projector per caller thread / stream (it owns the z-min workspace).
+
+        pj = Projector()
+        imgs = pj.project([(points, rem, label), ...], fov_up, fov_down, H, W, new=True, remove=True,
+                          outputs=("range", "rem", "label_folded"))      # list of dicts of [H, W] CUDA tensors
+
+    ``points`` [n,3] float32 or float64 (one dtype per call: the arithmetic follows it, as numpy's does), ``rem`` [n]
+    float32 or None, ``label`` [n] int32 / uint32 or None.  Outputs: ``idx`` (numbering of the KEPT points, -1 empty),
+    ``range``, ``xyz``, ``rem``, ``label``, ``color`` (needs ``color_lut``), ``mask``, ``label_folded`` (what
+    ``TSDFVolume.integrate`` folds from ``proj_label3``), ``proj_x`` / ``proj_y`` / ``proj_xf`` / ``proj_yf``, ``n_kept``
+    (a 1-element int32 tensor).  Empty cells: 0 / -1 / 0 for range / rem / xyz with ``new`` (laserscan.py:362-368), -1
+    everywhere for the old variant (:37-53)."""
+
+    _IMG = {"idx": ("int32", 1), "range": ("float32", 1), "xyz": ("float32", 3), "rem": ("float32", 1), "label": ("int32", 1),
+            "color": ("float32", 3), "mask": ("float32", 1), "label_folded": ("float32", 1), "proj_x": ("int32", 1),
+            "proj_y": ("int32", 1), "proj_xf": (None, 1), "proj_yf": (None, 1)}
+
+    def __init__(self, device=None):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        self._lib = _lib.load()
+        self._torch = torch
+        idx = torch.cuda.current_device() if device is None else (device.index if hasattr(device, "index") else int(device))
+        self.device = torch.device("cuda", idx)
+        h = C.c_void_p()
+        _lib.check(self._lib.lt_projector_create(C.byref(h), idx), "lt_projector_create")
+        self._h = h
+
+    def project(self, clouds, fov_up, fov_down, H, W, new=True, remove=False, beam_angles=None, color_lut=None,
+                outputs=("range", "rem", "label"), out=None, stream=None):
+        import ctypes as C
+
+        from . import _lib
+        torch = self._torch
+        n = len(clouds)
+        if n == 0:
+            return []
+        dt = clouds[0][0].dtype
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("points: float32 or float64")
+        keep, cl, im, res = [], (_lib.Cloud * n)(), (_lib.ProjImages * n)(), []
+        for k, (pts, rem, lab) in enumerate(clouds):
+            if pts.dtype != dt:
+                raise TypeError("all clouds of one call share one dtype")
+            pts = pts.contiguous()
+            rem = rem.to(torch.float32).contiguous() if rem is not None else None
+            lab = lab.to(torch.int32).contiguous() if (lab is not None and lab.dtype not in (torch.int32,)) else lab
+            keep += [pts, rem, lab]
+            cl[k].points = pts.data_ptr()
+            cl[k].rem = rem.data_ptr() if rem is not None else None
+            cl[k].label = lab.data_ptr() if lab is not None else None
+            cl[k].n = int(pts.shape[0])
+            o = dict(out[k]) if out is not None else {}
+            for name in outputs:
+                if name in o:
+                    continue
+                if name == "n_kept":
+                    o[name] = torch.empty(1, dtype=torch.int32, device=self.device)
+                    continue
+                tdt, ch = self._IMG[name]
+                tdt = dt if tdt is None else getattr(torch, tdt)
+                o[name] = torch.empty((H, W, ch) if ch > 1 else (H, W), dtype=tdt, device=self.device)
+            for name, t in o.items():
+                setattr(im[k], name, t.data_ptr())
+            res.append(o)
+        lut = color_lut.to(torch.float32).contiguous() if color_lut is not None else None
+        beams = None
+        if beam_angles is not None and len(beam_angles):
+            import numpy as np
+            beams = np.ascontiguousarray(beam_angles, dtype=np.float64)
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        flags = (_lib.LT_PROJ_NEW if new else 0) | (_lib.LT_PROJ_REMOVE if remove else 0)
+        init = (0.0, -1.0, 0.0) if new else (-1.0, -1.0, -1.0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.lt_range_projection_batch_dev(
+                self._h, n, cl, int(dt == torch.float64), float(fov_up), float(fov_down), int(H), int(W),
+                beams.ctypes.data_as(C.c_void_p) if beams is not None else None, 0 if beams is None else len(beams), flags,
+                lut.data_ptr() if lut is not None else None, 0 if lut is None else int(lut.shape[0]), im, *init,
+                C.c_void_p(st.cuda_stream)), "lt_range_projection_batch_dev")
+        self._keep = (keep, lut)  # inputs stay referenced until the next call (the kernels are queued, not finished)
+        return res
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_projector_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LaserScan:
     """Spherical projection part of the reference's ``LaserScan`` (auxiliary/laserscan.py:14-292),
     computed by ``liblidarhip.so`` (``lt_range_projection``, HIP atomic z-min).

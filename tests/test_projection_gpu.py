@@ -223,3 +223,107 @@ def test_label_beyond_the_colour_table_raises_like_the_reference():
     bad.do_range_projection(3.0, -25.0, remove=True)
     with pytest.raises(IndexError):
         bad.do_label_projection()
+
+
+# ---- the batched, synchronisation-free entry (lt_range_projection_batch_dev) ---------------------------------------------
+def _fuzz_cloud(rng, n, dtype, fd, fu):
+    r = rng.uniform(0.5, 80.0, n); yaw = rng.uniform(-np.pi, np.pi, n)
+    pitch = np.deg2rad(rng.uniform(fd - 3, fu + 3, n))
+    pts = np.stack([r * np.cos(pitch) * np.cos(yaw), r * np.cos(pitch) * np.sin(yaw), r * np.sin(pitch)], 1).astype(dtype)
+    if n >= 500:
+        pts[10:60] = pts[100:150]
+        pts[200:230] *= dtype(2.0)
+        pts[5] = 0
+    rem = rng.uniform(0, 1, n).astype(np.float32)
+    lab = rng.choice(list(COLOR_DICT.keys()), n).astype(np.uint32)
+    return pts, rem, lab
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("new", [True, False])
+@pytest.mark.parametrize("remove", [True, False])
+def test_batch_projection_equals_the_single_cloud_call(dtype, new, remove):
+    """Twelve clouds of different sizes (0, 1, 7 ... 130 000 points: more than one group of 8) through ONE
+    lt_range_projection_batch_dev call, twice in a row on one projector (the resolve pass re-arms the workspace), against
+    the single-cloud call per cloud -- which the golden vectors of the reference's own Python pin (tests above): every
+    image bit for bit, incl. the numbering of the kept points, the pixel coordinates of empty cells (numpy's index -1)
+    and the folded label image `integrate` consumes."""
+    import torch
+    from lidar_transfer_amd.laserscan import Projector, SemLaserScan
+    rng = np.random.default_rng(7 + 2 * int(new) + int(remove))
+    H, W, fu, fd = 32, 512, 4.0, -24.0
+    sizes = [0, 1, 7, 500, 20000, 60000, 130000, 3000, 64, 65, 4097, 25000]
+    beams = list(np.deg2rad(np.linspace(fu, fd, H))) if (new and remove and dtype == np.float64) else None
+    pj = Projector()
+    outs = ("idx", "range", "xyz", "rem", "label", "color", "mask", "label_folded", "proj_x", "proj_y", "proj_xf",
+            "proj_yf", "n_kept")
+    for rep in range(2):
+        clouds = [_fuzz_cloud(rng, n, dtype, fd, fu) for n in sizes]
+        if not (new or remove):
+            for pts, _, _ in clouds:       # the old variant without `remove` divides by depth 0: not a valid input
+                if len(pts) > 5:
+                    pts[5] = pts[6]
+        ref = []
+        for pts, rem, lab in clouds:
+            s = SemLaserScan(H, W, 300, COLOR_DICT, None, beams)
+            s.points, s.remissions, s.label = pts.copy(), rem.copy(), lab.copy()
+            s.colorize()
+            if new:
+                s.do_range_projection_new(fu, fd, remove=remove)
+                s.do_label_projection_new()
+            else:
+                s.do_range_projection(fu, fd, remove=remove)
+                s.do_label_projection()
+            ref.append(s)
+        lut = torch.from_numpy(ref[0].color_lut).cuda()
+        dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(r).cuda(), torch.from_numpy(l.astype(np.int32)).cuda())
+               for p, r, l in clouds]
+        got = pj.project(dev, fu, fd, H, W, new=new, remove=remove, beam_angles=beams, color_lut=lut if new else None,
+                         outputs=outs)   # (the old variant's mirror passes no colour table: its colour image is 0)
+        torch.cuda.synchronize()
+        for k, (s, g) in enumerate(zip(ref, got)):
+            g = {n: t.cpu().numpy() for n, t in g.items()}
+            o = s._last
+            tag = f"rep {rep} cloud {k} (n={sizes[k]})"
+            assert int(g["n_kept"][0]) == s.points.shape[0], tag
+            assert np.array_equal(g["idx"], o["idx"]), tag
+            assert np.array_equal(g["range"].view(np.int32), o["range"].view(np.int32)), tag
+            assert np.array_equal(g["rem"].view(np.int32), o["remi"].view(np.int32)), tag
+            assert np.array_equal(g["label"], o["labi"]), tag
+            assert np.array_equal(g["xyz"].view(np.int32), o["xyz"].view(np.int32)), tag
+            assert np.array_equal(g["color"], o["col"]), tag
+            assert np.array_equal(g["mask"], o["mask"]), tag
+            assert np.array_equal(g["label_folded"], np.floor(o["labi"].astype(np.float32) * 256 * 256)), tag
+            if new and s.points.shape[0]:
+                assert np.array_equal(g["proj_x"], s.proj_x) and np.array_equal(g["proj_y"], s.proj_y), tag
+                assert np.array_equal(g["proj_xf"], s.proj_x_float) and np.array_equal(g["proj_yf"], s.proj_y_float), tag
+    pj.close()
+
+
+def test_batch_projection_on_the_reference_golden_at_baseline_scale():
+    """120 000 float64 points -> 64 x 2048 (golden F9, made by the reference's own do_range_projection_new +
+    do_label_projection_new): the images of the batched entry by SHA-256, five copies of the cloud in one call."""
+    import hashlib
+    import torch
+    from lidar_transfer_amd.laserscan import Projector
+    from lidar_transfer_amd.synth import synth_cloud
+    g = np.load(os.path.join(GOLD, "f9_range_projection_full.npz"))
+    H, W, fu, fd = int(g["H"]), int(g["W"]), float(g["fov_up"]), float(g["fov_down"])
+    pts, rem_p, lab = synth_cloud(int(g["seed"]), int(g["n_points"]), dtype=np.float64, fov_up=fu, fov_down=fd)
+    pts[1000:1100] = pts[5000:5100]
+    pts[7] = 0
+    assert hashlib.sha256(pts.tobytes()).digest() == bytes(g["f64_new_points_sha256"]), "synthetic cloud drifted"
+    cl = (torch.from_numpy(pts).cuda(), torch.from_numpy(rem_p).cuda(), torch.from_numpy(lab.astype(np.int32)).cuda())
+    pj = Projector()
+    got = pj.project([cl] * 5, fu, fd, H, W, new=True, remove=True,
+                     outputs=("idx", "range", "rem", "label", "proj_x", "proj_y"))
+    torch.cuda.synchronize()
+    for o in got:
+        arrs = dict(index=o["idx"].cpu().numpy(), proj_range=o["range"].cpu().numpy(),
+                    proj_remissions=o["rem"].cpu().numpy(), proj_label=o["label"].cpu().numpy(),
+                    proj_x=o["proj_x"].cpu().numpy(), proj_y=o["proj_y"].cpu().numpy())
+        for name, a in arrs.items():
+            a = np.ascontiguousarray(a)
+            assert str(a.dtype) == str(g[f"f64_new_{name}_dtype"]) and tuple(a.shape) == tuple(g[f"f64_new_{name}_shape"]), name
+            assert hashlib.sha256(a.tobytes()).digest() == bytes(g[f"f64_new_{name}_sha256"]), f"{name} differs"
+    pj.close()
