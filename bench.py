@@ -487,20 +487,29 @@ def main():
         torch.cuda.synchronize()
         t_w = time.perf_counter() - t_w
         if do_gather:
-            # Gather the images on rank 0, or leave them sharded?  Each peer's images travel over its own xGMI link into
-            # the root: when bytes per scan x scans/s of a rank (measured on the warm-up steps, the slowest rank's figure
-            # so that all ranks decide alike) exceeds the headroom of a link, every rank keeps its scans and only per-scan
-            # metadata is gathered (lidar_transfer_amd.dist.choose_gather; LT_BENCH_GATHER=root|sharded overrides).
-            from lidar_transfer_amd.dist import choose_gather
+            # The north star's job: ONE RCCL gather of the rendered images on rank 0 -- the default (`root`; issued in pieces
+            # that overlap the rendering).  Each peer's images travel over its own xGMI link into the root, so the link rate
+            # bounds a rank at link / bytes-per-scan scans per second: the line reports what the links sustain (MEASURED here
+            # with all peers sending at once, lidar_transfer_amd.dist.measure_link_gbs, before the clock) and what the ranks
+            # produce (the slowest rank's warm-up rate, all-reduced), so a link-bound job says so.  LT_BENCH_GATHER=auto
+            # leaves the images on the ranks that rendered them (only per-scan metadata is gathered) when the images would
+            # exceed 0.9 of the measured link rate; =sharded forces that mode.
+            from lidar_transfer_amd.dist import XGMI_LINK_GBS, choose_gather, measure_link_gbs
             tw = torch.tensor([t_w], dtype=torch.float64, device=dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             rate = Wm / max(float(tw.item()), 1e-9)
             per_scan = R * (4 + (2 if label_dtype == torch.int16 else 4))
-            mode = os.environ.get("LT_BENCH_GATHER", "auto")
+            link = measure_link_gbs(dev) if world > 1 else None
+            mode = os.environ.get("LT_BENCH_GATHER", "root")
             if mode not in ("root", "sharded"):
-                mode = choose_gather(world, per_scan, rate)
+                mode = choose_gather(world, per_scan, rate, link_gbs=link)
+            need = per_scan * rate / 1e9
             gather_info.update(mode=mode, warmup_scans_per_s_per_rank=round(rate, 1), bytes_per_scan=per_scan,
-                               per_link_GBs=round(per_scan * rate / 1e9, 2))
+                               per_link_GBs_needed=round(need, 2),
+                               per_link_GBs_measured=round(link, 2) if link else None,
+                               per_link_GBs_nominal=XGMI_LINK_GBS,
+                               link_bound_scans_per_s_per_rank=round((link or XGMI_LINK_GBS) * 1e9 / per_scan, 1),
+                               link_bound=bool(world > 1 and mode == "root" and need > (link or XGMI_LINK_GBS)))
             if mode == "sharded":
                 do_gather = False
                 sharded_meta = True
@@ -967,6 +976,39 @@ def main():
         n_written = 0
         for x0 in range(0, tv.shape[0], 250):   # (in slabs: the masks of the whole volume would be 1.6 GB)
             n_written += int(((tv[x0:x0 + 250] != 1) | (wv[x0:x0 + 250] != 0)).sum().item())
+        # where the reference's scikit-image (Lewiner) table COULD give another surface: the share of ambiguous cases among
+        # the active cells of this very volume, and of cells whose polygons leave a choice of diagonals (outside the clock;
+        # tools/gen_mc_table.py classifies the 256 cases -- checker infrastructure, used here as such)
+        mc_cases = None
+        try:
+            from tools import gen_mc_table as gmt
+            cls = gmt.case_classes()
+            hist = np.zeros(256, np.int64)
+            X = tv.shape[0]
+            for x0 in range(0, X - 1, 100):
+                ins = tv[x0:min(x0 + 101, X)] < 0
+                if not bool(ins.any()):
+                    continue
+                sx, sy, sz = ins.shape
+                idx = torch.zeros((sx - 1, sy - 1, sz - 1), dtype=torch.int32, device=dev)
+                for c_ in range(8):
+                    dx, dy, dz = c_ & 1, (c_ >> 1) & 1, (c_ >> 2) & 1
+                    idx += ins[dx:sx - 1 + dx, dy:sy - 1 + dy, dz:sz - 1 + dz].to(torch.int32) << c_
+                hist += torch.bincount(idx.reshape(-1), minlength=256).cpu().numpy()
+                del ins, idx
+            act = int(hist[1:255].sum())
+            fa = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["face_ambiguous"]))
+            ia = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["interior_ambiguous_only"]))
+            sp = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["splits_a_polygon"]))
+            mc_cases = {"active_cells": act, "face_ambiguous": fa, "interior_ambiguous_only": ia,
+                        "ambiguous_share": round((fa + ia) / max(act, 1), 5), "cells_with_a_choice_of_diagonals": sp,
+                        "diagonal_choice_share": round(sp / max(act, 1), 4),
+                        "triangles_by_table": int(sum(int(hist[c_]) * cls[c_]["n_triangles"] for c_ in range(256))),
+                        "note": "parity of the triangulation is unpinned (scikit-image absent); ambiguous cases are where "
+                                "a Lewiner table can differ in topology, the others only in diagonals -- bounded by "
+                                "tests/test_mc_gpu.py::test_other_diagonals_bound_what_a_different_case_table_can_change"}
+        except Exception as e:  # noqa: BLE001
+            mc_cases = {"error": repr(e)[:200]}
         del tv, wv
         mesh.close()
         vol.close()
@@ -983,7 +1025,7 @@ def main():
                "observations": nscans,
                "ms_per_scan": round(t * 1e3, 3), "scans_per_s": round(1.0 / t, 1), "value": round(R / t / 1e6, 2),
                "unit": "Mrays/s", "voxels": nvox, "voxels_written": n_written, "mesh_verts": nv, "mesh_faces": nf,
-               "hit_fraction": round(hits_c / R, 4),
+               "hit_fraction": round(hits_c / R, 4), "marching_cubes_cases": mc_cases,
                "phase_ms": {"reset": round(float(m[0]), 3), "integrate": round(float(m[1]), 3),
                             "marching_cubes": round(float(m[2]), 3), "render": round(float(m[3]), 3)},
                "roofline": {

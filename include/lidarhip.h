@@ -370,6 +370,14 @@ int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float
  * pointers stay valid until the next extraction into this mesh or lt_mesh_destroy.  Any argument may be NULL. */
 int lt_mesh_get(lt_mesh* mesh, int* n_verts, int* n_faces, float** verts, int** faces, int** colors, float** rem);
 
+/* The 256-case triangulation table of the extraction, in the layout of LT_MC_PACKED (csrc/lt_mc_table.h: two 64-bit words
+ * per case -- bits 0..2 the number of triangles, bits 8 + 5 i .. 12 + 5 i the lattice-edge code of corner i of the triangle
+ * list).  `packed` = HOST [512] words, copied; NULL restores the built-in table.  A replacement may only RE-TRIANGULATE the
+ * polygons of a case (same triangle count, same set of crossing edges: checked).  This is how the divergence from the
+ * reference's scikit-image table is bounded while that table cannot be obtained: render the mesh of
+ * the built-in table and of the table with every polygon's OTHER diagonals (tools/gen_mc_table.py --variant). */
+int lt_mesh_set_case_table(lt_mesh* mesh, const unsigned long long* packed);
+
 /* lt_scene_set_mesh_dev with the arrays of `mesh` (borrowed until the next extraction): the render reads the
  * mesh where marching cubes wrote it -- no PCIe traffic between fusion and range image. */
 int lt_scene_set_mesh(lt_scene* scene, lt_mesh* mesh);

@@ -23,7 +23,7 @@
 //                 (8 neighbour records staged in LDS per wave): base + popcount of the edge masks below the bit
 //
 // Vertex order = (owner voxel x, y, z ascending, edge axis); face order = (cell ascending, table order):
-// deterministic, no atomics anywhere.  Case table: lt_mc_table.h (generated, oracle/gen_mc_table.py).
+// deterministic, no atomics anywhere.  Case table: lt_mc_table.h (generated, tools/gen_mc_table.py).
 // PARITY: unpinned against scikit-image (not importable here); bit-identical to the CPU oracle
 // (oracle/lt_mc_oracle.c) -- DESIGN.md section 7c.
 #include "lt_internal.h"
@@ -34,6 +34,14 @@
 #include <string.h>
 #define LT_TABLE_ATTR __device__
 #include "lt_mc_table.h"
+// ... and once more for the HOST (the emit kernels read the table through a pointer: every mesh object owns a 4 KB device
+// copy that lt_mesh_set_case_table can replace; the symbol API cannot resolve a static __device__ array)
+namespace lt_mc_host {
+#undef LT_MC_TABLE_H
+#undef LT_TABLE_ATTR
+#define LT_TABLE_ATTR
+#include "lt_mc_table.h"
+}  // namespace lt_mc_host
 
 // debug (-DLT_MC_STAMP=1: k_mc_words, =2: k_mc_compact; tools/mc_wave_times.py): wall clock (100 MHz) at the start of a wave,
 // after its stamp ballot and at its end, and the number of blocks it walked
@@ -88,6 +96,8 @@ struct lt_mesh {
   int* wave_na; size_t cap_wave_na;     // active words per wave of 64 rows (k_mc_words -> k_mc_compact)
   float ms_signs, ms_rest;              // last extraction (when timed)
   hipEvent_t ev[3];
+  const u64* case_table;                // [512] the 256-case triangulation the emit kernels read (LT_MC_PACKED's layout):
+  u64* case_table_own;                  //   the built-in table, or this mesh's own copy (lt_mesh_set_case_table)
 };
 
 // ---- k_mc_signs ----------------------------------------------------------------------------------------------------
@@ -515,7 +525,8 @@ __global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, 
                                                 const mc_rec* __restrict__ rec, int n_active, float voxel_size,
                                                 float ox, float oy, float oz, float* __restrict__ verts,
                                                 int* __restrict__ faces, int* __restrict__ colors,
-                                                float* __restrict__ rem, int cap_v, int cap_f) {
+                                                float* __restrict__ rem, int cap_v, int cap_f,
+                                                const ulonglong2* __restrict__ case_table) {
   // One wave per workgroup (the barrier below is a wave barrier); the kernel is a chain of dependent memory round
   // trips per wave, so the loads that depend on the record only -- sign words, neighbour indices, field values -- are
   // all issued before the first of them is needed: record -> {bits, cmap, tsdf} -> {neighbour records, attributes} ->
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, 
   // the lane's whole cell in one 128-bit load: triangle count + 15 five-bit edge codes (LT_MC_PACKED)
   u64 pk0 = 0, pk1 = 0;
   if ((M.ac >> b) & 1ull) {
-    const ulonglong2 pk = ((const ulonglong2*)LT_MC_PACKED)[mc_case(M, b)];
+    const ulonglong2 pk = case_table[mc_case(M, b)];
     pk0 = pk.x; pk1 = pk.y;
   }
   const int nt = (int)(pk0 & 7ull);
@@ -651,7 +662,8 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
                                                       const mc_rec* __restrict__ rec, int n_active, float voxel_size,
                                                       float ox, float oy, float oz, float* __restrict__ verts,
                                                       int* __restrict__ faces, int* __restrict__ colors,
-                                                      float* __restrict__ rem, int cap_v, int cap_f) {
+                                                      float* __restrict__ rem, int cap_v, int cap_f,
+                                                      const ulonglong2* __restrict__ case_table) {
   static_assert(K <= 16, "list entries hold the word in 4 bits");
   __shared__ mc_rec s_rec[K];
   __shared__ int s_xyz[K][3];       // x, y, wz of the words
@@ -881,7 +893,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     for (int j = lane; j < nwin; j += 64) {
       const unsigned e = s_tl[j];
       const int k = e & 15, b = (e >> 4) & 63, t = (e >> 10) & 7, cs = (e >> 13) & 255;
-      const ulonglong2 pk = ((const ulonglong2*)LT_MC_PACKED)[cs];
+      const ulonglong2 pk = case_table[cs];
       const int tid = tbase0 + tb + j;
       int id[3];
 #pragma unroll
@@ -930,7 +942,54 @@ extern "C" int lt_mesh_create(lt_mesh** out, int device) {
     return LT_ERR_NO_MEMORY;
   }
   for (int k = 0; k < 3; ++k) (void)hipEventCreate(&m->ev[k]);
+  if (hipMalloc((void**)&m->case_table_own, sizeof(lt_mc_host::LT_MC_PACKED)) != hipSuccess ||
+      hipMemcpy(m->case_table_own, lt_mc_host::LT_MC_PACKED, sizeof(lt_mc_host::LT_MC_PACKED), hipMemcpyHostToDevice) != hipSuccess) {
+    lt_set_error("lt_mesh_create: cannot upload the case table");
+    if (m->case_table_own) (void)hipFree(m->case_table_own);
+    (void)hipHostFree(m->totals_host);
+    (void)hipGetLastError();
+    free(m);
+    return LT_ERR_NO_MEMORY;
+  }
+  m->case_table = m->case_table_own;
   *out = m;
+  return LT_OK;
+}
+
+// see include/lidarhip.h
+extern "C" int lt_mesh_set_case_table(lt_mesh* m, const unsigned long long* packed) {
+  if (!m) {
+    lt_set_error("lt_mesh_set_case_table: NULL mesh");
+    return LT_ERR_INVALID_ARG;
+  }
+  LT_HIP(hipSetDevice(m->device));
+  const u64* own = (const u64*)lt_mc_host::LT_MC_PACKED;
+  if (!packed) packed = own;
+  // a replacement may re-triangulate the polygons of a case, nothing else: the same number of triangles (the counting
+  // kernels keep using the built-in counts) over the same crossing edges (the vertices exist per crossing edge)
+  for (int c = 0; c < 256; ++c) {
+    const int nt = (int)(own[2 * c] & 7ull);
+    if ((int)(packed[2 * c] & 7ull) != nt) {
+      lt_set_error("lt_mesh_set_case_table: case %d has %d triangles, the table given says %d", c, nt, (int)(packed[2 * c] & 7ull));
+      return LT_ERR_INVALID_ARG;
+    }
+    unsigned have = 0, want = 0;
+    for (int i = 0; i < 3 * nt; ++i) {
+      const int sh = 8 + 5 * i;
+      auto code = [&](const u64* t) {
+        const u64 raw = sh < 64 ? ((t[2 * c] >> sh) | (sh > 59 ? (t[2 * c + 1] << (64 - sh)) : 0ull)) : (t[2 * c + 1] >> (sh - 64));
+        return (unsigned)(raw & 31ull);
+      };
+      want |= 1u << code(own);
+      have |= 1u << code(packed);
+    }
+    if (have != want) {
+      lt_set_error("lt_mesh_set_case_table: case %d references lattice edges that do not cross the surface", c);
+      return LT_ERR_INVALID_ARG;
+    }
+  }
+  LT_HIP(hipDeviceSynchronize());  // (an extraction in flight may still read the previous contents)
+  LT_HIP(hipMemcpy(m->case_table_own, packed, 512 * sizeof(u64), hipMemcpyHostToDevice));
   return LT_OK;
 }
 
@@ -938,7 +997,7 @@ extern "C" int lt_mesh_destroy(lt_mesh* m) {
   if (!m) return LT_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na};
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na, m->case_table_own};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   if (m->totals_host) (void)hipHostFree(m->totals_host);
@@ -1106,7 +1165,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     return e && strcmp(e, "waves") == 0;
   }();
 #define LT_MC_EMIT_ARGS tsdf, color_vol, rem_vol, bits, D, m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], \
-                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f
+                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, (const ulonglong2*)m->case_table
   if (n_active > 0 && emit_waves)
     hipLaunchKernelGGL(k_mc_emit, dim3(n_active), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
   else if (n_active > 0)

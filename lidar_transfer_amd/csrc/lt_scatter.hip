@@ -470,70 +470,126 @@ __global__ __launch_bounds__(256) void k_rs_grid(const int* __restrict__ bin_sta
 #define LT_SC_CAP_BATCH 8192
 #define LT_SC_SLICE 512  // candidates per queued slice (k_sc_rest)
 
-// LDS state of one workgroup = 256 consecutive triangles
+// Triangles per workgroup of k_sc_tris / k_sc_rest.  A workgroup's life is a chain of dependent round trips -- index triple
+// -> three vertices -> bounds -> prefix sum (two barriers) -> phase B -- at the hardware's 8 waves per SIMD (DESIGN.md section
+// 5d), so the lever is how much work a wave has in flight per round trip: lanes 0 .. LT_SC_T - 257 take a SECOND triangle,
+// both index triples are loaded first and then all six vertices, before the first of them is used.  448, not 512: the LDS
+// of a workgroup must stay <= 20 KB for 8 workgroups (= 32 waves) per CU, which 448 records of 40 B + the prefix array are
+// (20 000 B); -DLT_SC_T=256 is round 3's kernel (A/B).
+#ifndef LT_SC_T
+#define LT_SC_T 448
+#endif
+#define LT_SC_T2 (LT_SC_T - 256)  // lanes with a second triangle (a multiple of 64: whole waves)
+static_assert(LT_SC_T >= 256 && LT_SC_T <= 512 && LT_SC_T2 % 64 == 0, "LT_SC_T: 256, 320, 384, 448 or 512");
+
+// LDS state of one workgroup = LT_SC_T consecutive triangles; slot s = triangle first + s, owned by lane s & 255
 struct sc_shared {
-  // triangle record = three 16-B words (one ds_read_b128 each; phase B is sensitive to the NUMBER of LDS
-  // instructions -- a 4-ary search with 12 reads instead of the binary search's 9 cost 9 %):
-  //   q0 = (v0.x, v0.y, v0.z, e1.x)   q1 = (e1.y, e1.z, e2.x, e2.y)   q2 = (e2.z, a0 | na << 16, e0, 1 / na)
-  float4 q0[256], q1[256], q2[256];
-  int pre[257];           // exclusive prefix sum of the candidate counts
-  int wsum[4];
+  // triangle record = 40 B in three arrays (one ds_read each; phase B is sensitive to the NUMBER of LDS instructions -- a
+  // 4-ary search with 12 reads instead of the binary search's 9 cost 9 %):
+  //   q0 = (v0.x, v0.y, v0.z, e1.x)   q1 = (e1.y, e1.z, e2.x, e2.y)   q2 = (e2.z, (na - 1) | e0 << 9)
+  float4 q0[LT_SC_T], q1[LT_SC_T];
+  float2 q2[LT_SC_T];
+  // exclusive prefix sum of the candidate counts << 13 | a0 (first azimuth column of the slot's rectangle, < 8192); entry
+  // LT_SC_T holds the total, the entries beyond are all-ones: the search below is a branch-free descent over 512 entries
+  unsigned pre[513];
+  unsigned wsum[4];
   int kept;
+  int slice_base;  // first queue entry of this workgroup's slices (-1: none queued)
 };
 
-// Phase A: thread tid sets up triangle first_face + tid (record + bin rectangle) in LDS; returns its number
-// of candidate bins (0 for none / invalid / big; big triangles are queued when PUSH)
-template <bool PUSH, bool WIDE>
-__device__ __forceinline__ int sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
-                                        int n_verts, int n_faces, int f, float ox, float oy, float oz,
-                                        const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
-                                        unsigned* __restrict__ flags) {
-  const int tid = threadIdx.x;
-  int cnt = 0;
-  if (f < n_faces) {
-    const i3 idx = *at<WIDE>((const i3*)faces, (unsigned)f);
-    const int a = idx.x, b = idx.y, c = idx.z;
-    if ((unsigned)a < (unsigned)n_verts && (unsigned)b < (unsigned)n_verts && (unsigned)c < (unsigned)n_verts) {
-      const f3 A = *at<WIDE>((const f3*)verts, (unsigned)a);
-      const f3 B = *at<WIDE>((const f3*)verts, (unsigned)b);
-      const f3 C = *at<WIDE>((const f3*)verts, (unsigned)c);
-      const float v0x = A.x, v0y = A.y, v0z = A.z, v1x = B.x, v1y = B.y, v1z = B.z;
-      const float v2x = C.x, v2y = C.y, v2z = C.z;
-#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads only
-      return (v0x + v1y + v2z == 12345.f) ? 1 : 0;
-#endif
-      const float e1x = v1x - v0x, e1y = v1y - v0y, e2x = v2x - v0x, e2y = v2y - v0y;
-      const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
-                                  v2z - oz, e1x, e1y, e2x, e2y);
-      if (R.na > 0) {  // (rows e0..e1 are non-empty whenever na > 0)
-        const int c32 = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
-        if (c32 > LT_SC_BIG) {
-          if (PUSH) large[atomicAdd(large_count, 1)] = f;
-        } else {
-          cnt = c32;
-          S.q0[tid] = make_float4(v0x, v0y, v0z, e1x);
-          S.q1[tid] = make_float4(e1y, v1z - v0z, e2x, e2y);
-          // a0 < 8192, na <= LT_SC_BIG; 1-ulp reciprocal is enough, see sc_round_robin
-          S.q2[tid] = make_float4(v2z - v0z, __int_as_float(R.a0 | (R.na << 16)), __int_as_float(R.e0),
-                                  f_rcp((float)R.na));
-        }
-      }
-    } else if (PUSH) {
-      atomicOr(flags, LT_FLAG_BAD_INDEX);
+struct sc_one { int cnt; unsigned a0; };  // phase A's result for one triangle: candidate bins (0: none / invalid / big), a0
+
+// bounds + LDS record of one triangle whose vertices are in registers
+template <bool PUSH>
+__device__ __forceinline__ sc_one sc_record_into(float4* s_q0, float4* s_q1, float2* s_q2, int slot, int f, const f3 A,
+                                                 const f3 Bv, const f3 C, float ox, float oy, float oz, const rs_params& P,
+                                                 int* __restrict__ large, int* __restrict__ large_count) {
+  sc_one r;
+  r.cnt = 0; r.a0 = 0;
+  const float v0x = A.x, v0y = A.y, v0z = A.z, v1x = Bv.x, v1y = Bv.y, v1z = Bv.z;
+  const float v2x = C.x, v2y = C.y, v2z = C.z;
+  const float e1x = v1x - v0x, e1y = v1y - v0y, e2x = v2x - v0x, e2y = v2y - v0y;
+  const bin_rect R = tri_bins(P, v0x - ox, v0y - oy, v0z - oz, v1x - ox, v1y - oy, v1z - oz, v2x - ox, v2y - oy,
+                              v2z - oz, e1x, e1y, e2x, e2y);
+  if (R.na > 0) {  // (rows e0..e1 are non-empty whenever na > 0)
+    const int c32 = R.na * (R.e1 - R.e0 + 1);  // <= 8192 x 4096 bins (lt_rayset_create_dev)
+    if (c32 > LT_SC_BIG) {
+      if (PUSH) large[atomicAdd(large_count, 1)] = f;
+    } else {
+      r.cnt = c32;
+      r.a0 = (unsigned)R.a0;  // < 8192
+      s_q0[slot] = make_float4(v0x, v0y, v0z, e1x);
+      s_q1[slot] = make_float4(e1y, v1z - v0z, e2x, e2y);
+      s_q2[slot] = make_float2(v2z - v0z, __int_as_float((R.na - 1) | (R.e0 << 9)));  // na <= LT_SC_BIG = 512, e0 < 4096
     }
   }
-  return cnt;
+  return r;
+}
+template <bool PUSH>
+__device__ __forceinline__ sc_one sc_record(sc_shared& S, int slot, int f, const f3 A, const f3 Bv, const f3 C, float ox,
+                                            float oy, float oz, const rs_params& P, int* __restrict__ large,
+                                            int* __restrict__ large_count) {
+  return sc_record_into<PUSH>(S.q0, S.q1, S.q2, slot, f, A, Bv, C, ox, oy, oz, P, large, large_count);
 }
 
-// exclusive prefix sum of cnt over the workgroup -> S.pre[0..256]; returns this thread's prefix.  Contains one
-// barrier; the caller issues the second one (after any extra LDS it wants published with it).
-__device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
+// Phase A: lane tid sets up triangle first + tid and (tid < LT_SC_T2) triangle first + 256 + tid: record + bin rectangle in
+// LDS, candidate counts in rA / rB (big triangles are queued when PUSH)
+template <bool PUSH, bool WIDE>
+__device__ __forceinline__ void sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
+                                         int n_verts, int n_faces, int first, float ox, float oy, float oz,
+                                         const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
+                                         unsigned* __restrict__ flags, sc_one& rA, sc_one& rB) {
+  const int tid = threadIdx.x;
+  rA.cnt = 0; rA.a0 = 0; rB.cnt = 0; rB.a0 = 0;
+  const int fA = first + tid, fB = first + 256 + tid;
+  const bool hasA = fA < n_faces, hasB = LT_SC_T2 > 0 && tid < LT_SC_T2 && fB < n_faces;
+  if (n_verts <= 0) {  // (uniform) every index is out of range
+    if (PUSH && (hasA || hasB)) atomicOr(flags, LT_FLAG_BAD_INDEX);
+    return;
+  }
+  // Every load below is unconditional (a lane without a triangle, or with a bad index, reads element 0): nothing the
+  // compiler could want to wait for stands between the two index loads and the six vertex loads.
+#ifdef LT_SC_PRIO  // experiment: a wave that is about to issue its gathers goes first (the others are computing)
+  __builtin_amdgcn_s_setprio(3);
+#endif
+  const i3 iA = *at<WIDE>((const i3*)faces, (unsigned)(hasA ? fA : 0));
+  i3 iB = iA;
+  if (LT_SC_T2 > 0) iB = *at<WIDE>((const i3*)faces, (unsigned)(hasB ? fB : 0));
+  const unsigned nv = (unsigned)n_verts;
+  const bool okA = hasA && (unsigned)iA.x < nv && (unsigned)iA.y < nv && (unsigned)iA.z < nv;
+  const bool okB = hasB && (unsigned)iB.x < nv && (unsigned)iB.y < nv && (unsigned)iB.z < nv;
+  const f3 A0 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.x : 0u);
+  const f3 A1 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.y : 0u);
+  const f3 A2 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.z : 0u);
+  f3 B0 = A0, B1 = A1, B2 = A2;
+  if (LT_SC_T2 > 0) {
+    B0 = *at<WIDE>((const f3*)verts, okB ? (unsigned)iB.x : 0u);
+    B1 = *at<WIDE>((const f3*)verts, okB ? (unsigned)iB.y : 0u);
+    B2 = *at<WIDE>((const f3*)verts, okB ? (unsigned)iB.z : 0u);
+  }
+#ifdef LT_SC_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  if (PUSH && ((hasA && !okA) || (hasB && !okB))) atomicOr(flags, LT_FLAG_BAD_INDEX);
+#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads only
+  rA.cnt = (A0.x + A1.y + A2.z + B0.x + B1.y + B2.z == 12345.f) ? 1 : 0;
+  return;
+#endif
+  if (okA) rA = sc_record<PUSH>(S, tid, fA, A0, A1, A2, ox, oy, oz, P, large, large_count);
+  if (LT_SC_T2 > 0 && okB) rB = sc_record<PUSH>(S, 256 + tid, fB, B0, B1, B2, ox, oy, oz, P, large, large_count);
+}
+
+// exclusive prefix sums of the candidate counts over the workgroup's slots (0 .. 255: the lanes' first triangles, 256 ..:
+// their second ones) -> S.pre[0 .. 512]; returns the lane's two prefixes.  Contains one barrier; the caller issues the
+// second one (after any extra LDS it wants published with it).
+__device__ __forceinline__ void sc_prefix(sc_shared& S, const sc_one rA, const sc_one rB, int& preA, int& preB, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // inclusive wave scan with six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31 across
   // rows).  Written as v_add_u32_dpp so that a step is ONE instruction: lanes whose DPP source does not exist add
   // 0 (bound_ctrl:0), rows deselected by row_mask keep their value.  The s_nop is the VALU-write -> DPP-read
   // hazard of gfx9 (2 wait states), which the assembler does not insert inside inline asm.
-  int inc = cnt;
+  // Both counts ride in one word: a count is <= LT_SC_BIG = 512, a wave's sum <= 2^15 -- the halves never carry.
+  unsigned inc = (unsigned)rA.cnt | ((unsigned)rB.cnt << 16);
   asm volatile(
       "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
       "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
@@ -545,13 +601,21 @@ __device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
       : "+v"(inc));
   if (lane == 63) S.wsum[wave] = inc;
   __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += S.wsum[w];
-  total = (S.wsum[0] + S.wsum[1]) + (S.wsum[2] + S.wsum[3]);
-  const int mypre = woff + inc - cnt;
-  S.pre[tid] = mypre;
-  if (tid == 255) S.pre[256] = total;
-  return mypre;
+  int woffA = 0, woffB = 0, totA = 0, totB = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned ws = S.wsum[w];
+    const int a = (int)(ws & 0xFFFFu), b = (int)(ws >> 16);
+    if (w < wave) { woffA += a; woffB += b; }
+    totA += a; totB += b;
+  }
+  total = totA + totB;  // <= 512 x 512 = 2^18: the << 13 below fits
+  preA = woffA + (int)(inc & 0xFFFFu) - rA.cnt;
+  preB = totA + woffB + (int)(inc >> 16) - rB.cnt;
+  S.pre[tid] = ((unsigned)preA << 13) | rA.a0;
+  if (LT_SC_T2 > 0 && tid < LT_SC_T2) S.pre[256 + tid] = ((unsigned)preB << 13) | rB.a0;
+  else S.pre[256 + tid] = (256 + tid == LT_SC_T) ? ((unsigned)total << 13) : 0xFFFFFFFFu;
+  if (tid == 255) S.pre[512] = LT_SC_T == 512 ? ((unsigned)total << 13) : 0xFFFFFFFFu;
 }
 
 // Phase B over the candidates [c_begin, c_end) of the workgroup, dealt ROUND-ROBIN: in every iteration the 64
@@ -561,47 +625,60 @@ __device__ __forceinline__ int sc_prefix(sc_shared& S, int cnt, int& total) {
 // per thread needs no search but made every lane touch its own lines: L2 bound.)  The loop is
 // software-pipelined: the search and the grid load of the NEXT candidate are issued before the triangle test
 // of the current one.
-template <bool COUNT, bool WIDE>
-__device__ __forceinline__ void sc_round_robin(const sc_shared& S, const rs_params& P, const float4* __restrict__ grid,
+// NT = lanes sharing the candidates (256: a workgroup; 64: one wave of k_sc_rest), NE = entries of the prefix array the
+// descent covers (a power of two; the array has NE + 1 entries, all-ones beyond the slots in use), tix = this lane's index
+template <bool COUNT, bool WIDE, int NT, int NE>
+__device__ __forceinline__ void sc_round_robin(const unsigned* s_pre, const float4* s_q0, const float4* s_q1,
+                                               const float2* s_q2, const rs_params& P, const float4* __restrict__ grid,
                                                const float4* __restrict__ sdirs, unsigned long long* __restrict__ cell,
-                                               int first_face, int c_begin, int c_end, float ox, float oy, float oz,
+                                               int first_face, int c_begin, int c_end, int tix, float ox, float oy, float oz,
                                                unsigned& n_tests, unsigned& n_cand) {
   // LDS slots are addressed by BYTE offset j4 = 4 * j throughout (one shift less per search step / array read)
-  auto ldi = [](const int* arr, unsigned j4) { return *(const int*)((const char*)arr + j4); };
+  auto ldu = [](const unsigned* arr, unsigned j4) { return *(const unsigned*)((const char*)arr + j4); };
   auto ldq = [](const float4* arr, unsigned j4) { return *(const float4*)((const char*)arr + 4u * j4); };
-  // triangle j = largest j with pre[j] <= c; returns the bin and the record's third word
-  auto locate = [&](int c, unsigned& j4, float4& q2) -> int {
+  auto ld2 = [](const float2* arr, unsigned j4) { return *(const float2*)((const char*)arr + 2u * j4); };
+  const unsigned pre0 = s_pre[0];
+  // slot j = largest j with prefix[j] <= c (pre = prefix << 13 | a0: compare against c << 13 | all-ones); the entry found is
+  // carried along, so the descent needs no read of pre[j] afterwards; returns the bin and the record's third word
+  auto locate = [&](int c, unsigned& j4, float2& q2) -> int {
+    const unsigned ck = ((unsigned)c << 13) | 0x1FFFu;
     j4 = 0;
+    unsigned base = pre0;
 #pragma unroll
-    for (unsigned step4 = 512; step4 >= 4; step4 >>= 1)
-      if (ldi(S.pre, j4 + step4) <= c) j4 += step4;
-    const int local = c - ldi(S.pre, j4);
-    q2 = ldq(S.q2, j4);
-    const int ab = __float_as_int(q2.y);
-    const int na = ab >> 16;
+    for (unsigned step4 = 2u * NE; step4 >= 4; step4 >>= 1) {
+      const unsigned v = ldu(s_pre, j4 + step4);
+      const bool take = v <= ck;
+      j4 = take ? j4 + step4 : j4;
+      base = take ? v : base;
+    }
+    const int local = c - (int)(base >> 13);
+    q2 = ld2(s_q2, j4);
+    const int pk = __float_as_int(q2.y);
+    const int na = (pk & 511) + 1;
     // local / na: (local + 0.5) / na is >= 0.5 / na away from an integer and local / na <= LT_SC_BIG / na, so
-    // a relative error of 2^-22 in the product cannot cross one
-    const int row = (int)(((float)local + 0.5f) * q2.w);
+    // a relative error of 2^-22 in the product (a 1-ulp reciprocal) cannot cross one
+    const int row = (int)(((float)local + 0.5f) * f_rcp((float)na));
     // rows < 4096 and columns <= 8192 (lt_rayset_create_dev): 24-bit multiplies, full rate (v_mul_lo_u32 is 1/4)
-    int az = (ab & 0xFFFF) + (local - __mul24(row, na));
+    int az = (int)(base & 0x1FFFu) + (local - __mul24(row, na));
     if (az >= P.nb_az) az -= P.nb_az;
-    return __mul24(__float_as_int(q2.z) + row, P.nb_az) + az;
+    return __mul24((pk >> 9) + row, P.nb_az) + az;
   };
-  int c = c_begin + (int)threadIdx.x;
+  int c = c_begin + tix;
   if (c < c_end) {
     unsigned j4;
-    float4 q2;
+    float2 q2;
     float4 g = *at<false>(grid, (unsigned)locate(c, j4, q2));  // <= 8192 x 4096 bins x 16 B: always < 4 GB
     for (;;) {
       // prefetch of the next candidate (index clamped to the last one: no lane-level branch, the load stays in flight
       // across the test) -- unless NO lane of the wave has one: round-robin dealing makes that wave-uniform up to the
       // one wave holding c_end, and the search + bin arithmetic of a prefetch nobody uses were 9 % of the kernel's
       // vector instructions
-      const int cn = c + 256;
+      const int cn = c + NT;
       unsigned jn4 = 0;
-      float4 q2n = make_float4(0.f, 0.f, 0.f, 0.f), gn = make_float4(0.f, 0.f, 0.f, 0.f);
+      float2 q2n = make_float2(0.f, 0.f);
+      float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
       if (__ballot(cn < c_end) != 0ull) gn = *at<false>(grid, (unsigned)locate(min(cn, c_end - 1), jn4, q2n));
-      const float4 q0 = ldq(S.q0, j4), q1 = ldq(S.q1, j4);
+      const float4 q0 = ldq(s_q0, j4), q1 = ldq(s_q1, j4);
       tri_rec T;
       T.v0x = q0.x; T.v0y = q0.y; T.v0z = q0.z;
       T.e1x = q0.w; T.e1y = q1.x; T.e1z = q1.y;
@@ -633,79 +710,122 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
 struct sc_job {
   const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
   rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
-  unsigned long long* cell; int* large; int* large_count; int2* slices;
+  unsigned long long* cell; int* large; int* large_count; int4* slices;
   unsigned* flags; unsigned long long* counters;
   float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
   float ox, oy, oz;
   int n_verts, n_faces, n_rays, cap_slices;
   unsigned out_flags;
-  int tris_block0;     // first workgroup of this scan in k_sc_tris
-  int resolve_block0;  // ... in k_sc_resolve
 };
 struct sc_batch {
   int n;
   int tris_blocks, resolve_blocks;  // grid sizes
   int cap;                          // LT_SC_CAP_SINGLE / LT_SC_CAP_BATCH
+  // first workgroup of every scan in k_sc_tris / k_sc_resolve (INT_MAX beyond n).  Side by side at the head of the
+  // argument block: a workgroup finds its scan with ONE scalar load + compares -- walking job[k].tris_block0 was a
+  // chain of up to seven dependent scalar loads before the first vector load of the workgroup could be issued
+  int tris_block0[LT_SC_MAX_BATCH];
+  int resolve_block0[LT_SC_MAX_BATCH];
   sc_job job[LT_SC_MAX_BATCH];
 };
+__device__ __forceinline__ int sc_find_job(const int (&block0)[LT_SC_MAX_BATCH], int block) {
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < LT_SC_MAX_BATCH; ++k) j += block >= block0[k] ? 1 : 0;
+  return j;
+}
 
-// One workgroup = 256 consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~B.cap
+// One workgroup = LT_SC_T consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~B.cap
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   __shared__ sc_shared S;
-  int j = 0;
-  while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].tris_block0) ++j;
+  const int j = sc_find_job(B.tris_block0, (int)blockIdx.x);
   const sc_job& J = B.job[j];
-  const int lb = (int)blockIdx.x - J.tris_block0;  // workgroup index inside the scan
+  const int lb = (int)blockIdx.x - B.tris_block0[j];  // workgroup index inside the scan
   const int tid = threadIdx.x;
-  const int first = lb * 256;
+  const int first = lb * LT_SC_T;
   const rs_params P = J.P;
   const float ox = J.ox, oy = J.oy, oz = J.oz;
-  const int cnt = sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first + tid, ox, oy, oz, P, J.large,
-                                       J.large_count, J.flags);
+  sc_one rA, rB;
+  sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, J.large, J.large_count, J.flags, rA,
+                       rB);
 #if defined(LT_SC_STOP) && LT_SC_STOP <= 2  // ... up to the angular bounds and the LDS record
-  if (cnt == 0x7fffffff) J.counters[7] = 1;
+  if (rA.cnt + rB.cnt == 0x7fffffff) J.counters[7] = 1;
   return;
 #endif
-  int total;
-  const int mypre = sc_prefix(S, cnt, total);
-  // The workgroup keeps the triangles that start below the cap; exactly one thread sees the crossing and
-  // queues the rest in slices (large_count[1] = number of slices; if the queue is full the workgroup keeps all).
+  int total, preA, preB;
+  sc_prefix(S, rA, rB, preA, preB, total);
+  // The workgroup keeps the triangles that start below the cap; exactly one slot sees the crossing and its lane reserves
+  // queue entries for the rest, in slices of LT_SC_SLICE candidates (large_count[1] = number of slices; if the queue is
+  // full the workgroup keeps all).  The entries are written after the barrier, one lane per slice: a slice names its
+  // first triangle and that triangle's prefix, so that k_sc_rest redoes phase A for the slice's OWN triangles only.
   if (total < B.cap) {
-    if (tid == 255) S.kept = total;
-  } else if (mypre < B.cap && mypre + cnt >= B.cap) {
-    int kept = mypre + cnt;
-    const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
-    if (n_sl > 0) {
-      const int base = atomicAdd(&J.large_count[1], n_sl);
-      if (base + n_sl <= J.cap_slices) {
-        for (int k = 0; k < n_sl; ++k) J.slices[base + k] = make_int2(lb, kept + k * LT_SC_SLICE);
-      } else {
-        atomicSub(&J.large_count[1], n_sl);
-        kept = total;
+    if (tid == 255) { S.kept = total; S.slice_base = -1; }
+  } else {
+    const bool crossA = preA < B.cap && preA + rA.cnt >= B.cap;
+    const bool crossB = LT_SC_T2 > 0 && tid < LT_SC_T2 && preB < B.cap && preB + rB.cnt >= B.cap;
+    if (crossA || crossB) {
+      int kept = crossA ? preA + rA.cnt : preB + rB.cnt;
+      int sbase = -1;
+      const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
+      if (n_sl > 0) {
+        sbase = atomicAdd(&J.large_count[1], n_sl);
+        if (sbase + n_sl > J.cap_slices) {
+          atomicSub(&J.large_count[1], n_sl);
+          kept = total;
+          sbase = -1;
+        }
       }
+      S.kept = kept;
+      S.slice_base = sbase;
     }
-    S.kept = kept;
   }
   __syncthreads();
 #if defined(LT_SC_STOP) && LT_SC_STOP == 3  // ... up to the prefix sums and the cap
   if (S.kept == 0x7fffffff) J.counters[7] = 1;
   return;
 #endif
+  const int kept = S.kept;
+  if (S.slice_base >= 0) {
+    const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
+    for (int k = tid; k < n_sl; k += 256) {
+      const int c0 = kept + k * LT_SC_SLICE;
+      const unsigned ck = ((unsigned)c0 << 13) | 0x1FFFu;
+      int jj = 0;
+#pragma unroll
+      for (int step = 256; step >= 1; step >>= 1)
+        if (S.pre[jj + step] <= ck) jj += step;
+      // (tri_bins takes wave-uniform short cuts -- ballots over the 64 triangles a wave holds --, so a triangle's bounds,
+      // hence its candidate count, are only reproduced when it is evaluated in the SAME group of 64 slots: the slice
+      // starts at the group's first slot)
+      jj &= ~63;
+      J.slices[S.slice_base + k] = make_int4(lb, c0, jj, (int)(S.pre[jj] >> 13));
+    }
+  }
   unsigned n_tests = 0, n_cand = 0;
-  sc_round_robin<COUNT, WIDE>(S, P, J.grid, J.sdirs, J.cell, first, 0, S.kept, ox, oy, oz, n_tests, n_cand);
+  sc_round_robin<COUNT, WIDE, 256, (LT_SC_T > 256 ? 512 : 256)>(S.pre, S.q0, S.q1, S.q2, P, J.grid, J.sdirs, J.cell, first, 0,
+                                                                kept, tid, ox, oy, oz, n_tests, n_cand);
   sc_count<COUNT>(n_tests, n_cand, J.counters);
 }
 
-// The rest, LT_SC_REST_BLOCKS workgroups per scan: (1) queued slices of heavy workgroups -- a workgroup redoes
-// phase A of that triangle block (same code, same prefix sums) and tests one slice of its candidates; (2) big
+// The rest, LT_SC_REST_BLOCKS workgroups per scan: (1) queued slices of heavy workgroups -- ONE WAVE per slice: it redoes
+// phase A for the slice's own triangles, 64 at a time in k_sc_tris' groups of 64 slots (same code on the same lanes,
+// hence the same counts: the slice's candidate numbers mean the same here), and tests the slice's candidates; no workgroup barrier anywhere; (2) big
 // triangles, up to LT_SC_PARTS waves each, lanes stride over the candidate bins.
+// (Until round 4 a slice was a WORKGROUP redoing phase A of the whole triangle block: deferring work cost as much as a
+// k_sc_tris workgroup per 512 candidates, so the batch call kept up to 8192 candidates per workgroup -- and its heavy
+// workgroups were a quarter of the launch's exclusive duration.)
 #define LT_SC_REST_BLOCKS 512
 #define LT_SC_PARTS 8
+struct sc_wave_shared {  // per wave of k_sc_rest: 64 triangle records + their prefix (sc_shared's layout)
+  float4 q0[64], q1[64];
+  float2 q2[64];
+  unsigned pre[65];
+};
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
-  __shared__ sc_shared S;
+  __shared__ sc_wave_shared SW[4];
   const sc_job& J = B.job[blockIdx.x / LT_SC_REST_BLOCKS];
   const int rb = blockIdx.x % LT_SC_REST_BLOCKS;
   if (J.n_faces <= 0) return;
@@ -719,20 +839,48 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
   if (COUNT && rb == 0 && threadIdx.x == 0) J.counters[3] = (unsigned long long)n_large | ((unsigned long long)n_slices << 32);
   unsigned n_tests = 0, n_cand = 0;
-  for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
-    const int2 sl = J.slices[q];
-    const int first = sl.x * 256;
-    const int cnt = sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first + (int)threadIdx.x, ox, oy, oz, P,
-                                          nullptr, nullptr, nullptr);
-    int total;
-    (void)sc_prefix(S, cnt, total);
-    __syncthreads();
-    sc_round_robin<COUNT, WIDE>(S, P, grid, sdirs, cell, first, sl.y, min(sl.y + LT_SC_SLICE, total), ox, oy, oz, n_tests,
-                                n_cand);
-    __syncthreads();  // LDS is reused by the next slice
-  }
   const int lane = threadIdx.x & 63;
   const int wave0 = rb * 4 + (threadIdx.x >> 6), nwaves = LT_SC_REST_BLOCKS * 4;
+  sc_wave_shared& S = SW[threadIdx.x >> 6];
+  const unsigned nv = (unsigned)J.n_verts;
+  for (int q = wave0; q < n_slices && J.n_verts > 0; q += nwaves) {
+    const int4 sl = J.slices[q];  // (workgroup of k_sc_tris, first candidate, first triangle slot, that slot's prefix)
+    const int first = sl.x * LT_SC_T, c_end = sl.y + LT_SC_SLICE;
+    int run = sl.w;
+    for (int jb = sl.z; jb < LT_SC_T && run < c_end; jb += 64) {
+      const int slot = jb + lane, f = first + slot;
+      const bool has = slot < LT_SC_T && f < J.n_faces;
+      const i3 idx = *at<WIDE>((const i3*)faces, (unsigned)(has ? f : 0));
+      const bool ok = has && (unsigned)idx.x < nv && (unsigned)idx.y < nv && (unsigned)idx.z < nv;
+      const f3 A = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.x : 0u);
+      const f3 Bv = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.y : 0u);
+      const f3 C = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.z : 0u);
+      sc_one r;
+      r.cnt = 0; r.a0 = 0;
+      if (ok) r = sc_record_into<false>(S.q0, S.q1, S.q2, lane, f, A, Bv, C, ox, oy, oz, P, nullptr, nullptr);
+      unsigned inc = (unsigned)r.cnt;  // inclusive scan over the wave (sc_prefix's DPP sequence)
+      asm volatile(
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+          "s_nop 1"
+          : "+v"(inc));
+      const int chunk = __builtin_amdgcn_readlane((int)inc, 63);
+      S.pre[lane] = ((unsigned)(run + (int)inc - r.cnt) << 13) | r.a0;
+      if (lane == 0) S.pre[64] = (unsigned)(run + chunk) << 13;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's LDS writes before its LDS reads below
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      sc_round_robin<COUNT, WIDE, 64, 64>(S.pre, S.q0, S.q1, S.q2, P, grid, sdirs, cell, first + jb, max(sl.y, run),
+                                          min(c_end, run + chunk), lane, ox, oy, oz, n_tests, n_cand);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and its reads before the next chunk's writes
+      __builtin_amdgcn_wave_barrier();
+      run += chunk;
+    }
+  }
   // A big triangle is shared by up to LT_SC_PARTS waves (a ground triangle under the sensor of a low-poly
   // scene covers tens of thousands of bins): work item v = (triangle q, part p); every wave of a triangle
   // recomputes its bounds, part p takes the candidates p*64 + lane, stride 64 * (parts this triangle needs).
@@ -767,10 +915,9 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
 // one thread per ray: unpack the winning (t, face), write back as RayTracer.cpp:73-90, re-arm the cell
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_sc_resolve(const sc_batch B) {
-  int j = 0;
-  while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].resolve_block0) ++j;
+  const int j = sc_find_job(B.resolve_block0, (int)blockIdx.x);
   const sc_job& J = B.job[j];
-  const int ray = ((int)blockIdx.x - J.resolve_block0) * 256 + threadIdx.x;
+  const int ray = ((int)blockIdx.x - B.resolve_block0[j]) * 256 + threadIdx.x;
   unsigned long long* __restrict__ cell = J.cell;
   const int* __restrict__ faces = J.faces;
   float* __restrict__ endpoints = J.endpoints;
@@ -966,8 +1113,8 @@ extern "C" int lt_rayset_create_dev(lt_rayset** out, const float* rays, int n_ra
 
 // Per-scene state of a render: the z-min cells (one per ray, armed = all-ones; k_sc_resolve re-arms what it reads,
 // so they are set once per allocation) and the queues of k_sc_tris -- every triangle is queued at most once as
-// "big", and a block of 256 triangles with <= LT_SC_BIG candidates each leaves at most
-// 256 * LT_SC_BIG / LT_SC_SLICE = 256 slices.
+// "big", and a block of LT_SC_T triangles with <= LT_SC_BIG candidates each leaves at most
+// LT_SC_T * LT_SC_BIG / LT_SC_SLICE = LT_SC_T slices.
 static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) {
   if (!s->sc_large_count) {
     LT_HIP(hipMalloc((void**)&s->sc_large_count, 4 * sizeof(int)));
@@ -995,7 +1142,7 @@ static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) 
     }
     const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
     LT_HIP(hipMalloc((void**)&s->sc_large, cap * sizeof(int)));
-    LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int2)));
+    LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int4)));
     s->sc_cap_queue = (int)cap;
   }
   return LT_OK;
@@ -1015,6 +1162,7 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
                            lt_scene* probe) {
   sc_batch B;
   memset(&B, 0, sizeof(B));
+  for (int k = 0; k < LT_SC_MAX_BATCH; ++k) B.tris_block0[k] = B.resolve_block0[k] = 0x7fffffff;
   // LIDARHIP_FORCE_WIDE=1 selects the 64-bit addressing variants on any input (they are otherwise only reached
   // with > 357 M triangles): a test hook
   static const bool force_wide = getenv("LIDARHIP_FORCE_WIDE") != nullptr;
@@ -1036,9 +1184,9 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     J.ox = it[i].origin[0]; J.oy = it[i].origin[1]; J.oz = it[i].origin[2];
     J.n_verts = s->n_verts; J.n_faces = n; J.n_rays = R; J.cap_slices = s->sc_cap_queue;
     J.out_flags = flags;
-    J.tris_block0 = tb;
-    J.resolve_block0 = rb;
-    tb += (n + 255) / 256;
+    B.tris_block0[B.n - 1] = tb;
+    B.resolve_block0[B.n - 1] = rb;
+    tb += (n + LT_SC_T - 1) / LT_SC_T;
     rb += (R + 255) / 256;
     // 32-bit byte offsets unless an array of the launch reaches 4 GB (> 357 M triangles / vertices, > 268 M rays)
     wide = wide || (size_t)n * 12 >= (1ull << 32) || (size_t)s->n_verts * 12 >= (1ull << 32) ||

@@ -11,12 +11,69 @@ from typing import Callable, Dict, List, Optional, Sequence
 
 #: xGMI: every pair of the 8 GPUs of a node has its own link, ~64 GB/s per direction (7 links x ~153 GB/s bidirectional
 #: minus protocol).  A gather to ONE root moves each peer's images over that peer's own link into
-#: the root: the per-link rate bounds it, and the root's HBM takes the sum.
+#: the root: the per-link rate bounds it, and the root's HBM takes the sum.  NOMINAL figure, used only when nothing was
+#: measured: a job with peers times a gather before its clock starts (:func:`measure_link_gbs`, bench.py) and decides on that.
 XGMI_LINK_GBS = 64.0
 
 
+class _StagedWork:
+    """A transfer of device tensors over a backend that only moves host memory (gloo): the payload is staged through
+    host buffers, `wait()` completes the transport and -- on the receiving side -- copies into the device tensors.  This
+    is how the whole of this module runs on ONE GPU with several ranks (tests/test_multigpu_gpu.py): everything but the
+    RCCL transport itself."""
+
+    def __init__(self, works, copies):
+        self._works, self._copies = works, copies
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        for dst, host in self._copies:
+            dst.copy_(host, non_blocking=False)
+        self._works, self._copies = [], []
+        return True
+
+
+def _host_transport(group) -> bool:
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
+def measure_link_gbs(device, megabytes: int = 64, reps: int = 3, dst: int = 0, group=None):
+    """GB/s each peer's link into the root sustains while ALL peers send at once (what the gather of the images does):
+    every rank sends `megabytes` to `dst` with :func:`gather_to_root`, the slowest rank's time counts (all-reduced, so that
+    every rank holds the same figure).  ``None`` at world size 1 (no link)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world <= 1:
+        return None
+    rank = dist.get_rank(group)
+    n = megabytes * (1 << 20) // 4
+    src = torch.zeros(n, dtype=torch.float32, device=device)
+    recv = [torch.empty(n, dtype=torch.float32, device=device) for _ in range(world)] if rank == dst else None
+    best = None
+    for i in range(reps + 1):
+        if src.is_cuda:
+            torch.cuda.synchronize(device)
+        dist.barrier(group)
+        t0 = time.perf_counter()
+        for w in gather_to_root(src, recv, dst, group, copy_self=False):
+            w.wait()
+        if src.is_cuda:
+            torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=device if not _host_transport(group) else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if i:  # (the first round sets the channels up)
+            best = float(t.item()) if best is None else min(best, float(t.item()))
+    return n * 4 / best / 1e9
+
+
 def choose_gather(world_size: int, bytes_per_scan: float, scans_per_s_per_rank: float,
-                  link_gbs: float = XGMI_LINK_GBS, headroom: float = 0.7) -> str:
+                  link_gbs: Optional[float] = None, headroom: float = 0.9) -> str:
     """``"root"`` or ``"sharded"``: can the images of a job be gathered on one rank while they are rendered?
 
     Each peer produces ``bytes_per_scan * scans_per_s_per_rank`` bytes per second for the root, over its own
@@ -27,7 +84,7 @@ def choose_gather(world_size: int, bytes_per_scan: float, scans_per_s_per_rank: 
     if world_size <= 1:
         return "root"
     per_link = float(bytes_per_scan) * float(scans_per_s_per_rank) / 1e9
-    return "sharded" if per_link > headroom * link_gbs else "root"
+    return "sharded" if per_link > headroom * float(link_gbs or XGMI_LINK_GBS) else "root"
 
 
 def scan_indices(n_scan_files: int, nscans: int = 1, offset: int = 0, batch_interval: int = 1) -> List[int]:
@@ -64,15 +121,26 @@ def gather_to_root(src, recv=None, dst: int = 0, group=None, copy_self: bool = T
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ops = []
+    staged = []  # (device tensor, host buffer) pairs to fill once the transport is done (host-memory backends only)
+    host = _host_transport(group)
     if rank == dst:
         if recv is None:
             raise ValueError("gather_to_root: the destination rank needs receive buffers")
         if copy_self and src is not None and src.numel() > 0:
             recv[rank].copy_(src, non_blocking=True)
-        ops = [dist.P2POp(dist.irecv, recv[r], r, group) for r in range(world) if r != dst and recv[r].numel() > 0]
+        for r in range(world):
+            if r == dst or recv[r].numel() == 0:
+                continue
+            buf = recv[r]
+            if host and buf.is_cuda:
+                import torch
+                buf = torch.empty(recv[r].shape, dtype=recv[r].dtype, device="cpu")
+                staged.append((recv[r], buf))
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
     elif src is not None and src.numel() > 0:
-        ops = [dist.P2POp(dist.isend, src, dst, group)]
-    return list(dist.batch_isend_irecv(ops)) if ops else []
+        ops = [dist.P2POp(dist.isend, src.cpu() if (host and src.is_cuda) else src, dst, group)]
+    works = list(dist.batch_isend_irecv(ops)) if ops else []
+    return [_StagedWork(works, staged)] if staged else works
 
 
 def render_scans(indices: Sequence[int], render_fn: Callable[[int], Dict[str, "object"]], keys: Sequence[str],

@@ -15,7 +15,7 @@
  * shared by all cells around the edge, placed by the centre-of-mass rule
  *     w_i = 1 / (eps + |v_i - level|)   (double, eps = np.spacing(1.0)),   p = (p_1 w_1 + p_2 w_2) / (w_1 + w_2),
  * stored as float32.  The triangulation comes from the generated table oracle/lt_mc_table.h (classic marching
- * cubes with a face-consistent, watertight disambiguation -- oracle/gen_mc_table.py); on ambiguous cells
+ * cubes with a face-consistent, watertight disambiguation -- tools/gen_mc_table.py); on ambiguous cells
  * scikit-image's Lewiner variant may connect differently, and the ORDER of vertices / faces is this
  * implementation's (owner voxel x, y, z ascending, then edge axis; cells ascending, then table order).
  * Lines :409-:423 (index rounding, world transform, colour unfolding, uint8 wrap) are restated operation by

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_tables_are_what_the_generator_emits():
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_mc_table.py"), "--check"],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_mc_table.py"), "--check"],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
 

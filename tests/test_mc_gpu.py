@@ -327,3 +327,82 @@ def test_bare_lt_fusion_scan_dev_symbol_edge_cases():
     assert mesh.n_faces == 0 and int((out["range"] != 0).sum()) == 0
     del none
     mesh.close(); sc.close(); vol.close(); rs.close()
+
+
+def test_other_diagonals_bound_what_a_different_case_table_can_change(oracle):
+    """Parity of the triangulation is UNPINNED (scikit-image's Lewiner table cannot be read here).  What CAN be bounded: on
+    every case whose polygons are the same -- everything but the ambiguous cases, counted below -- another table can only
+    choose other diagonals inside the same polygons.  Extract the fused street scene twice, with the built-in table and with
+    the table of every polygon's OTHER diagonals (tools/gen_mc_table.py, `triangulate_other`), render both with the target
+    sensor: same vertices, same face count; the hit / miss pattern, the label image and the range all but identical -- a
+    polygon of a cell is within a voxel of flat, so its diagonals move the surface by less than half a voxel; what remains
+    are the rays that graze a silhouette and slip past the surface with one diagonal but not the other (they then hit
+    whatever lies behind: up to metres), a fraction of a per cent that the assertions below bound."""
+    import torch
+    from tools import gen_mc_table as g
+    from lidar_transfer_amd.laserscan import create_rays
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    vol, (H, W, fu, fd) = _fused_volume()
+    voxel = 0.1
+    dev = torch.device("cuda", 0)
+    HT, WT = 64, 2048
+    rays = torch.from_numpy(create_rays(3.0, -25.0, HT, WT)).to(dev)
+    rs = RaySet(rays, HT)
+    sc = Scene(0)
+    res = {}
+    mesh = None
+    for name, table in (("built_in", None), ("other", g.packed_words("other")), ("built_in_again", None)):
+        mesh = vol.extract_mesh(mesh)
+        if name == "built_in":
+            with pytest.raises(RuntimeError, match="triangles"):     # a table with another triangle count is refused
+                bad = g.packed_words()
+                bad[2 * 1] = (bad[2 * 1] & ~7) | 2
+                mesh.set_case_table(bad)
+        mesh.set_case_table(table)
+        mesh = vol.extract_mesh(mesh)
+        sc.set_device_mesh(mesh)
+        o = sc.render(rs, (0.0, 0.0, 0.0))
+        torch.cuda.synchronize()
+        v, f, c, r = [t.cpu().numpy().copy() for t in mesh.tensors()]
+        res[name] = dict(v=v, f=f, c=c, rng=o["range"].cpu().numpy(), lab=o["endcolors"].cpu().numpy()[:, 2],
+                         tri=o["tri"].cpu().numpy())
+    a, b = res["built_in"], res["other"]
+    assert np.array_equal(a["v"].view(np.int32), b["v"].view(np.int32)) and np.array_equal(a["c"], b["c"])
+    assert a["f"].shape == b["f"].shape and not np.array_equal(a["f"], b["f"])
+    assert np.array_equal(a["f"], res["built_in_again"]["f"])                 # NULL restores the built-in table
+    hit_a, hit_b = a["tri"] >= 0, b["tri"] >= 0
+    both = hit_a & hit_b
+    flips = int((hit_a != hit_b).sum())
+    dr = np.abs(a["rng"][both] - b["rng"][both])
+    lab_diff = int((a["lab"][both] != b["lab"][both]).sum())
+    n = int(both.sum())
+    assert n > 50000
+    # measured on this scene (MI355X): see the assertion messages when they fail; the bounds carry a margin
+    far = int((dr > voxel / 2).sum())
+    print(f"other-diagonal table: {n} rays hit both meshes, {flips} hit/miss flips, {lab_diff} labels differ, "
+          f"{int((dr > 0).sum())} rays with another range: |d range| median {float(np.median(dr)):.6f} m, p99 "
+          f"{float(np.quantile(dr, 0.99)):.5f} m, p99.9 {float(np.quantile(dr, 0.999)):.5f} m, max {float(dr.max()):.4f} m, "
+          f"{far} rays beyond half a voxel")
+    # measured on MI355X (profiles/r04/mc_other_diagonals.txt): 126 263 rays hit both meshes; 187 hit / miss flips (0.15 %),
+    # 887 labels differ (0.70 %: class borders, where the hit face's first vertex is another one), |d range| median 12 um,
+    # p99 9.3 cm, p99.9 25 cm, max 0.99 m (a silhouette ray that slips past the surface); 1 958 rays (1.55 %) beyond half a
+    # voxel.  The bounds below carry a margin of about two.
+    assert flips <= 0.004 * n, f"{flips} hit/miss flips of {n}"
+    assert far <= 0.03 * n, f"{far} of {n} rays differ by more than half a voxel"
+    assert float(np.median(dr)) <= 1e-3 and float(np.quantile(dr, 0.99)) <= 1.5 * voxel
+    assert lab_diff <= 0.015 * n, f"{lab_diff} labels differ of {n}"
+    # and how much of the mesh could differ in TOPOLOGY: the ambiguous cases among the active cells
+    tsdf = vol.get_volume_tensors()[0]
+    ins = (tsdf < 0)
+    idx = torch.zeros(tuple(s - 1 for s in ins.shape), dtype=torch.int32, device=ins.device)
+    for i in range(8):
+        dx, dy, dz = i & 1, (i >> 1) & 1, (i >> 2) & 1
+        idx += ins[dx:ins.shape[0] - 1 + dx, dy:ins.shape[1] - 1 + dy, dz:ins.shape[2] - 1 + dz].to(torch.int32) << i
+    hist = torch.bincount(idx.reshape(-1), minlength=256).cpu().numpy()
+    cls = g.case_classes()
+    active = int(hist[1:255].sum())
+    amb = int(sum(hist[c] for c in range(1, 255) if cls[c]["face_ambiguous"] or cls[c]["interior_ambiguous_only"]))
+    assert active > 10000 and sum(int(hist[c]) * cls[c]["n_triangles"] for c in range(256)) == a["f"].shape[0]
+    assert amb <= 0.03 * active, f"{amb} ambiguous cells of {active}"
+    print(f"active cells {active}, ambiguous (face or interior) {amb} = {100.0 * amb / active:.2f} %")
+    rs.close(); sc.close(); vol.close()

@@ -81,6 +81,71 @@ def test_two_ranks_gather_equals_one_rank_bytewise():
     assert (got["range"] > 0).any()
 
 
+def _worker_one_gpu(rank, world, port, indices, gather, q):
+    """A rank of a job whose ranks SHARE cuda:0: backend gloo (RCCL refuses two ranks on one device), device tensors --
+    lidar_transfer_amd.dist stages them through host buffers for a host-memory transport; everything else is the code the
+    RCCL job runs: partition, the real HIP render per scan, gather_to_root with real peers, the sharded mode's metadata."""
+    import torch
+    import torch.distributed as dist
+    from lidar_transfer_amd.dist import choose_gather, measure_link_gbs, render_scans
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = render_scans(indices, _render_fn_factory(0), ("range", "label", "tri"), gather=gather)
+    link = measure_link_gbs(torch.device("cuda", 0), megabytes=4, reps=1)
+    # the all-reduced decision of the bench (every rank must come to the same answer from the same measured figures)
+    modes = [choose_gather(world, 786432.0, 80000.0, link_gbs=link), choose_gather(world, 786432.0, 10.0, link_gbs=link)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (modes, round(link, 6)))
+    assert all(g == gathered[0] for g in gathered), gathered
+    if gather == "root":
+        if rank == 0:
+            q.put({k: v.cpu().numpy() for k, v in out.items()})
+        else:
+            assert all(out[k] is None for k in out)
+    else:
+        q.put((rank, {k: v.cpu().numpy() for k, v in out["local"].items() if v is not None}, out["indices"],
+               out["meta"].cpu().numpy() if out["meta"] is not None else None, out["counts"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,gather", [(2, "root"), (3, "root"), (2, "sharded")])
+def test_ranks_sharing_the_one_gpu_equal_the_single_process_run(world, gather):
+    """N > 1 on the hardware that exists: `world` processes on cuda:0, the real HIP render per scan, lidar_transfer_amd.dist
+    with real peers -- byte-identical to the single-process run, in both gather modes."""
+    import torch.multiprocessing as mp
+    from lidar_transfer_amd.dist import partition, render_scans
+    indices = list(range(7))
+    single = render_scans(indices, _render_fn_factory(0), ("range", "label", "tri"))
+    single = {k: v.cpu().numpy() for k, v in single.items()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_one_gpu, args=(r, world, port, indices, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(1 if gather == "root" else world)]
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    if gather == "root":
+        for k in ("range", "label", "tri"):
+            assert single[k].shape == got[0][k].shape and single[k].tobytes() == got[0][k].tobytes(), k
+    else:
+        meta0 = None
+        for rank, local, mine, meta, counts in got:
+            assert mine == partition(indices, world, rank) and counts == [len(partition(indices, world, r)) for r in range(world)]
+            for k in ("range", "label", "tri"):
+                assert local[k].tobytes() == single[k][mine[0]:mine[-1] + 1].tobytes(), (rank, k)
+            if rank == 0:
+                meta0 = meta
+        assert meta0 is not None and meta0.shape == (len(indices), 1)
+        assert np.array_equal(meta0[:, 0], (single["range"] != 0).sum(axis=1))
+
+
 @pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs on the node")
 def test_bench_gpus_2_prints_two_ranks():
     env = dict(os.environ)

@@ -23,8 +23,8 @@ Cline 1987) with a face rule that makes the surface watertight by construction:
 Interior ambiguities (Lewiner's case 4/6/7/10/12/13 sub-cases, centre vertex) are not resolved differently from the
 faces -- topology may differ from scikit-image's there; DESIGN.md section 7c, "parity unpinned".
 
-    python oracle/gen_mc_table.py            # writes both headers
-    python oracle/gen_mc_table.py --check    # exit 1 if the committed headers differ
+    python tools/gen_mc_table.py            # writes both headers
+    python tools/gen_mc_table.py --check    # exit 1 if the committed headers differ
 """
 import itertools
 import os
@@ -179,12 +179,75 @@ def triangulate(loop):
     return [(loop[i], loop[j], loop[k]) for (i, j, k) in best], best_bad
 
 
-def triangles(case):
+def triangulate_other(loop):
+    """The triangulation that shares the FEWEST diagonals with triangulate()'s choice (a quad: its other diagonal; a
+    pentagon: a fan from another vertex, no diagonal in common; ...), whether or not a diagonal lies in a cube face.  The
+    variant table built from it bounds what ANY other choice of diagonals -- scikit-image's Lewiner table included -- can
+    change on the cases whose polygons are the same (tests/test_mc_gpu.py)."""
+    n = len(loop)
+    if n < 4:
+        return triangulate(loop)[0]
+    base, _ = triangulate(loop)
+    pos = {code: i for i, code in enumerate(loop)}
+
+    def diagonals(tri_idx):
+        d = set()
+        for (i, j, k) in tri_idx:
+            for a, b in ((i, j), (j, k), (i, k)):
+                if (b - a) % n not in (1, n - 1):
+                    d.add((min(a, b), max(a, b)))
+        return d
+    base_d = diagonals([tuple(pos[c] for c in t) for t in base])
+    best, best_shared = None, None
+    for tri in triangulations(n):
+        shared = len(diagonals(tri) & base_d)
+        if best is None or shared < best_shared:
+            best, best_shared = tri, shared
+    return [(loop[i], loop[j], loop[k]) for (i, j, k) in best]
+
+
+def triangles(case, variant="default"):
     tris = []
     for loop in polygons(case):
-        t, _ = triangulate(loop)
-        tris.extend(t)
+        tris.extend(triangulate(loop)[0] if variant == "default" else triangulate_other(loop))
     return tris
+
+
+def packed_words(variant="default"):
+    """The table in LT_MC_PACKED's layout (two 64-bit words per case) as a list of 512 ints."""
+    out = []
+    for c in range(256):
+        rows = triangles(c, variant)
+        v = len(rows)
+        for i, code in enumerate(x for t in rows for x in t):
+            v |= code << (8 + 5 * i)
+        out += [v & ((1 << 64) - 1), v >> 64]
+    return out
+
+
+def case_classes():
+    """Per case: is it where a Lewiner table (the reference's scikit-image call, fusion_lidar.py:407) CAN differ in
+    topology -- a face with its two inside corners on a diagonal (face ambiguity: Lewiner's cases 3, 6, 7, 10, 12, 13) or two
+    inside / outside corners on a space diagonal and nothing else (interior ambiguity alone: case 4) -- or only in the choice
+    of diagonals (a polygon with more than three vertices), or not at all (triangles only)."""
+    out = []
+    for c in range(256):
+        inside = [(c >> i) & 1 for i in range(8)]
+        face_amb = False
+        for quad in FACES:
+            ins = [inside[q] for q in quad]
+            if sum(ins) == 2 and ins[0] == ins[2]:
+                face_amb = True
+        n_in = sum(inside)
+        diag4 = False
+        if n_in in (2, 6):
+            minority = [i for i in range(8) if inside[i] == (1 if n_in == 2 else 0)]
+            diag4 = (minority[0] ^ minority[1]) == 7
+        polys = polygons(c) if 0 < c < 255 else []
+        out.append({"face_ambiguous": face_amb, "interior_ambiguous_only": diag4 and not face_amb,
+                    "splits_a_polygon": any(len(p) > 3 for p in polys), "n_polygons": len(polys),
+                    "n_triangles": sum(len(p) - 2 for p in polys)})
+    return out
 
 
 def check_orientation():
@@ -200,9 +263,10 @@ def check_orientation():
 def render():
     assert check_orientation(), "orientation convention broken"
     rows = [triangles(c) for c in range(256)]
+    assert all(len(triangles(c, "other")) == len(rows[c]) for c in range(256))
     max_t = max(len(r) for r in rows)
     lines = []
-    lines.append("/* GENERATED by oracle/gen_mc_table.py -- do not edit.  256-case marching-cubes table, face-consistent")
+    lines.append("/* GENERATED by tools/gen_mc_table.py -- do not edit.  256-case marching-cubes table, face-consistent")
     lines.append(" * (watertight) disambiguation; see the generator for the conventions:")
     lines.append(" *   corner i at offset (i & 1, (i >> 1) & 1, (i >> 2) & 1) along (x, y, z); case bit i = corner i inside (< level);")
     lines.append(" *   a triangle vertex is a lattice edge code = lower corner | axis << 3 (owner voxel offset, edge axis);")
