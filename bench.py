@@ -91,7 +91,10 @@ def parse():
                     help="distinct scenes cycled through per rank; faces + vertices of all of them (18.3 MB each on C2) must "
                          "exceed twice the 256 MiB Infinity Cache so that no scan finds its mesh cached from the last time "
                          "round (profiles/r04/scenes_sweep.jsonl)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "16")),
+    # 24 = three batch calls of 8 scans in flight: with round 4's 448-triangle workgroups three launches fill each other's
+    # ramps and tails better than two (profiles/r04/streams_sweep.txt: 16 / 24 / 32 -> 10.2 / 10.9 / 9.7 Grays/s; round 3's
+    # kernel: 8.24 / 8.28 / 7.74)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LT_BENCH_STREAMS", "24")),
                     help="scans in flight per GPU (HIP streams)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("LT_BENCH_BATCH", "8")),
                     help="scans per lt_scene_render_batch_dev call (scatter strategy, at most 8; 1 = one call per scan); "
