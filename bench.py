@@ -945,6 +945,9 @@ def main():
         sp = vp(st.cuda_stream)
         org = (C.c_float * 3)(*origin)
         out = scratch[0]
+        obs_c = (vp * len(obs))(*[o_[0].data_ptr() for o_ in obs])
+        obs_d = (vp * len(obs))(*[o_[1].data_ptr() for o_ in obs])
+        obs_r = (vp * len(obs))(*[o_[2].data_ptr() for o_ in obs])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ms = np.zeros((n, 4))
         t_wall = []
@@ -953,9 +956,10 @@ def main():
             ev[0].record()
             _lib.check(lib.lt_tsdf_reset(vol._h, sp), "reset")
             ev[1].record()
-            for f_k, d_k, r_k in obs:
-                _lib.check(lib.lt_tsdf_integrate_dev(vol._h, f_k.data_ptr(), d_k.data_ptr(), r_k.data_ptr(), H, W, 1.0,
-                                                     _lib.LT_TSDF_MERGE, sp), "integrate")
+            # all observations of the fresh volume in ONE call (lt_tsdf_integrate_multi_dev: one fused pass, bit-identical to
+            # one lt_tsdf_integrate_dev per observation -- tests/test_tsdf_gpu.py)
+            _lib.check(lib.lt_tsdf_integrate_multi_dev(vol._h, len(obs), obs_c, obs_d, obs_r, H, W, 1.0, _lib.LT_TSDF_MERGE, sp),
+                       "integrate")
             ev[2].record()
             _lib.check(lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None), "marching cubes")
             ev[3].record()
@@ -1091,17 +1095,21 @@ def main():
         ms = np.zeros((n, 6))
         t_wall = []
         packed = None
+        src_keep = None  # (the source images are allocated once: a production caller keeps its buffers too)
         for i in range(n + 2):
             t0 = time.perf_counter()
             ev[0].record()
-            src = dd.projector.project(clouds, dd.fov_up, dd.fov_down, H, W, new=True, remove=True,
+            src = dd.projector.project(clouds, dd.fov_up, dd.fov_down, H, W, new=True, remove=True, out=src_keep,
                                        outputs=("range", "rem", "label_folded"), stream=st)
+            src_keep = src
             ev[1].record()
             _lib.check(lib.lt_tsdf_reset(dd.vol._h, sp), "reset")
             ev[2].record()
-            for s_ in src:
-                _lib.check(lib.lt_tsdf_integrate_dev(dd.vol._h, s_["label_folded"].data_ptr(), s_["range"].data_ptr(),
-                                                     s_["rem"].data_ptr(), H, W, 1.0, _lib.LT_TSDF_MERGE, sp), "integrate")
+            oc = (vp * nscans)(*[s_["label_folded"].data_ptr() for s_ in src])
+            od = (vp * nscans)(*[s_["range"].data_ptr() for s_ in src])
+            orr = (vp * nscans)(*[s_["rem"].data_ptr() for s_ in src])
+            _lib.check(lib.lt_tsdf_integrate_multi_dev(dd.vol._h, nscans, oc, od, orr, H, W, 1.0, _lib.LT_TSDF_MERGE, sp),
+                       "integrate")
             ev[3].record()
             _lib.check(lib.lt_tsdf_extract_mesh_dev(dd.vol._h, dd.mesh_obj._h, sp, None), "marching cubes")
             ev[4].record()

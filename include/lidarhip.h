@@ -334,6 +334,16 @@ int lt_tsdf_reset(lt_tsdf* vol, void* stream);
  * `integrate` (fusion_lidar.py:66-229) and its launch loop (:267-287); like that kernel it ignores cam_pose. */
 int lt_tsdf_integrate_dev(lt_tsdf* vol, const float* color_im, const float* depth_im, const float* rem_im,
                           int im_h, int im_w, float obs_weight, unsigned flags, void* stream);
+/* `n_obs` observations in order -- the `number_of_scans` range images the reference's `mesh` adaption fuses into ONE new
+ * volume, all re-projected into the primary pose (laserscan.py:874-897).  Same result, bit for bit, as n_obs calls of
+ * lt_tsdf_integrate_dev; on a volume that holds no observation yet (after lt_tsdf_reset) the class-aware update of up to 8
+ * observations runs as ONE pass: every observation projects a voxel into the same pixel, so a voxel's geometry is
+ * evaluated once and the updates are applied in order on its state in registers.  color_ims / depth_ims / rem_ims: HOST
+ * arrays of n_obs DEVICE image pointers [im_h * im_w] f32 (colour folded as for lt_tsdf_integrate_dev). */
+int lt_tsdf_integrate_multi_dev(lt_tsdf* vol, int n_obs, const float* const* color_ims, const float* const* depth_ims,
+                                const float* const* rem_ims, int im_h, int im_w, float obs_weight, unsigned flags,
+                                void* stream);
+
 /* Device pointers of the volumes (TSDFVolume.get_volume, fusion_lidar.py:395-400, without the copies). */
 int lt_tsdf_volumes(lt_tsdf* vol, int* dims, float* origin, float** tsdf, float** weight, float** color,
                     float** rem);

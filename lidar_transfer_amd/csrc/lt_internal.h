@@ -141,6 +141,8 @@ struct lt_tsdf {
   int rowtab_for_h;     // image height the table holds (the field of view is fixed per volume)
   unsigned* zw_snap;    // [2][dim_x * dim_y] col_zw as it stood before the observation being integrated (non-fresh volumes)
   unsigned* chunk_epoch;  // [ceil(dim_x * dim_y / 64)] == epoch: a column of this chunk of 64 was written since the last reset
+  float4* obs4;         // [cap_obs4] transposed (depth, colour, remission, -) of the observations of lt_tsdf_integrate_multi_dev
+  size_t cap_obs4;
 };
 
 #define LT_BOUNDS_BLOCKS 256

@@ -1249,8 +1249,8 @@ extern "C" int lt_fusion_scan_dev(lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, 
     return LT_ERR_INVALID_ARG;
   }
   LT_CHECK(lt_tsdf_reset(vol, stream));
-  for (int k = 0; k < n_obs; ++k)
-    LT_CHECK(lt_tsdf_integrate_dev(vol, color_ims[k], depth_ims[k], rem_ims[k], im_h, im_w, obs_weight, tsdf_flags, stream));
+  // (all observations of the fresh volume in one pass where the class-aware update allows it: lt_tsdf.hip)
+  LT_CHECK(lt_tsdf_integrate_multi_dev(vol, n_obs, color_ims, depth_ims, rem_ims, im_h, im_w, obs_weight, tsdf_flags, stream));
   LT_CHECK(lt_tsdf_extract_mesh_dev(vol, mesh, stream, nullptr));
   LT_CHECK(lt_scene_set_mesh(scene, mesh));
   LT_CHECK(lt_scene_render_dev(scene, rayset, origin, endpoints, endcolors, range, endrem, tri, trace_flags, stream, nullptr));

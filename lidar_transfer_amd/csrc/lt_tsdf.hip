@@ -977,6 +977,440 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
   }
 }
 
+// ---- several observations of a FRESH volume in ONE pass (lt_tsdf_integrate_multi_dev) --------------------------------------
+// The reference's `mesh` adaption fuses `number_of_scans` range images into one new volume, all of them re-projected into
+// the primary pose (laserscan.py:874-897): every observation projects a voxel into the SAME pixel, and the update of a voxel
+// depends on that voxel's own state and its pixel only.  So instead of n passes -- the second one onwards with a snapshot of
+// the written ranges, a pass over every voxel inside them and the pixel pass beside it (0.11 ms each) -- ONE pixel pass over
+// the union of the observations' candidate intervals: a voxel's geometry (depth, pitch, row: the costly part) is evaluated
+// once, then the n updates run IN ORDER on the voxel's state in registers (the expressions of tsdf_update, operation by
+// operation) and the four fields are stored once.  Bit-identical to n calls of lt_tsdf_integrate_dev
+// (tests/test_tsdf_gpu.py).  Class-aware branch only (the plain average writes the whole frustum: the column walk).
+#define LT_TSDF_MULTI_MAX 8
+struct tsdf_obs_ptrs {  // the images of the observations, by value (kernel arguments)
+  const float* color[LT_TSDF_MULTI_MAX];
+  const float* depth[LT_TSDF_MULTI_MAX];
+  const float* rem[LT_TSDF_MULTI_MAX];
+};
+
+// (depth, colour, remission, -) of pixel (row, px) of observation k at obs4[(k * im_w + px) * im_h + row]: the transposed,
+// packed copy the kernels read (one 16-B load per observation and voxel; rows of one image column contiguous)
+__global__ __launch_bounds__(256) void k_tsdf_dct4(tsdf_obs_ptrs O, int n_obs, int im_h, int im_w, float4* __restrict__ obs4) {
+  const int n_pix = im_h * im_w;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pix * n_obs) return;
+  const int k = i / n_pix, p = i - k * n_pix;
+  const int y = p / im_w, x = p - y * im_w;
+  float d = 0.f, c = 0.f, r = 0.f;
+#pragma unroll
+  for (int q = 0; q < LT_TSDF_MULTI_MAX; ++q)  // (the pointer table lives in scalar registers: select, do not index)
+    if (q == k) { d = O.depth[q][p]; c = O.color[q][p]; r = O.rem[q][p]; }
+  obs4[(size_t)k * n_pix + (size_t)x * im_h + y] = make_float4(d, c, r, 0.f);
+}
+
+// the n class-aware updates of one voxel of a FRESH volume (fusion_lidar.py:177, :191-228; tsdf_update<true> above, on
+// registers): returns 0 untouched, 1 written (not negative), 2 written negative
+__device__ __forceinline__ int tsdf_updates_fresh(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
+                                                   float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
+                                                   float depth, float trunc_margin, float obs_weight,
+                                                   const float4* __restrict__ obs4, size_t pix, size_t n_pix, int n_obs) {
+  float tv = 1.0f, wv = 0.0f, cv = 0.0f, rv = 0.0f;  // the initial volume (fusion_lidar.py:47-63)
+  bool written = false;
+  for (int k = 0; k < n_obs; ++k) {
+    const float4 o = obs4[(size_t)k * n_pix + pix];
+    const float depth_value = o.x, new_color = o.y, new_rem = o.z;
+    if (depth_value == 0.f) continue;
+    const float depth_diff = depth_value - depth;
+    if (depth_diff < -trunc_margin) continue;
+    const float dist = fminf(1.0f, depth_diff / trunc_margin);
+    const float dist_old = wv;  // sic: the reference compares against the weight volume
+    if (cv == new_color) {      // same class: integrate
+      const float w_old = wv;
+      const float w_new = w_old + obs_weight;
+      wv = w_new;
+      tv = __fmaf_rn(tv, w_old, dist) / w_new;
+      rv = __fmaf_rn(rv, w_old, new_rem) / w_new;
+      written = true;
+    } else if (dist < dist_old) {  // other class: the closer observation wins
+      tv = dist;
+      const float new_b = floorf(new_color / (256 * 256));
+      const float new_g = floorf((new_color - new_b * 256 * 256) / 256);
+      const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
+      cv = new_b * 256 * 256 + new_g * 256 + new_r;
+      rv = new_rem;
+      written = true;
+    }
+  }
+  if (!written) return 0;
+  tsdf_vol[voxel_idx] = tv;
+  weight_vol[voxel_idx] = wv;
+  color_vol[voxel_idx] = cv;
+  rem_vol[voxel_idx] = rv;
+  return tv < 0.0f ? 2 : 1;
+}
+
+// tsdf_voxel's geometry (the reference's expressions, :95-146), then the n updates; want_py as there
+__device__ __forceinline__ int tsdf_voxel_multi(
+    int voxel_idx, float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const int* __restrict__ colinfo, const col_plain& C, int z_plain,
+    const float4* __restrict__ obs4, int n_obs, int want_py = -1) {
+  int px = -2;
+  float rho2, pt_z;
+  if (C.plain) {
+    px = C.px;
+    rho2 = C.rho2;
+    pt_z = __fmaf_rn((float)z_plain, voxel_size, oz);
+  } else {
+    const float voxel_x = floorf(((float)voxel_idx) / ((float)(vol_dim_y * vol_dim_z)));
+    const float voxel_y = floorf(((float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z)) / ((float)vol_dim_z));
+    const float voxel_z = (float)(voxel_idx - ((int)voxel_x) * vol_dim_y * vol_dim_z - ((int)voxel_y) * vol_dim_z);
+    const int ix = (int)voxel_x, iy = (int)voxel_y;
+    const bool in_table = ix >= 0 && ix < vol_dim_x && iy >= 0 && iy < vol_dim_y;
+    if (in_table) {
+      px = colinfo[ix * vol_dim_y + iy];
+      if (px == -1) return 0;
+      if (px >= 0) px &= 0x3FFFFFFF;
+    }
+    const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
+    const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
+    pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
+    rho2 = __fmaf_rn(pt_y, pt_y, pt_x * pt_x);
+    if (px < 0) {
+      const float yaw = -atan2f(pt_y, pt_x);
+      float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
+      proj_x *= (float)im_w;
+      px = (int)floorf(proj_x);
+      px = min(im_w - 1, px);
+      px = max(0, px);
+    }
+  }
+  const float fov = fabsf(fov_up) + fabsf(fov_down);
+  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, rho2));  // norm3df
+  const float s = pt_z / depth;
+  if (s > sin_up_hi || s < sin_down_lo) return 0;
+  const float pitch = asinf(s);
+  if (pitch > fov_up || pitch < fov_down) return 0;
+  float proj_y = (float)(1.0 - (double)((pitch + fabsf(fov_down)) / fov));
+  proj_y *= (float)im_h;
+  int py = (int)floorf(proj_y);
+  py = min(im_h - 1, py);
+  py = max(0, py);
+  if (want_py >= 0 && py != want_py) return 0;
+  return tsdf_updates_fresh(tsdf_vol, weight_vol, color_vol, rem_vol, voxel_idx, depth, trunc_margin, obs_weight, obs4,
+                            (size_t)px * im_h + py, (size_t)im_h * im_w, n_obs);
+}
+
+template <bool VCOUNT>
+__global__ __launch_bounds__(256) void k_tsdf_integrate_pix_multi(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, float inv_vs, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up,
+    float fov_down, float sin_up_hi, float sin_down_lo, const float4* __restrict__ obs4, int n_obs,
+    const int* __restrict__ wd_px,
+    unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
+    unsigned* __restrict__ col_zw, unsigned* __restrict__ chunk_epoch,
+    const float4* __restrict__ rowtab, const int* __restrict__ wd_start, const int2* __restrict__ wd_ent, const uint32_t* __restrict__ wd_key, int rho_bits,
+    float qscale, unsigned long long* __restrict__ dbg) {
+  // k_tsdf_integrate_pix for n_obs observations of a FRESH volume at once (see above): a pixel's candidate interval is the
+  // UNION of the observations' -- a voxel an observation can write lies in that observation's interval while it still holds
+  // its initial values, and once written (by an earlier observation: inside an earlier interval) anywhere in front of the band.
+  const size_t n_pix_all = (size_t)im_h * im_w;
+  // per pixel of the workgroup
+  __shared__ int p_k0[64], p_pre[65], p_r[64], p_px[64];
+  __shared__ float p_tlo[64], p_thi[64], p_dlo[64], p_dhi[64];
+  // per pair of the chunk (one block: phase A borrows it as the staging area of the wedge's rho quanta)
+  __shared__ int c_buf[LT_PIX_STAGE > 4 * LT_PIX_CHUNK + 1 ? LT_PIX_STAGE : 4 * LT_PIX_CHUNK + 1];
+  int* const c_col = c_buf;
+  int* const c_z0 = c_buf + LT_PIX_CHUNK;
+  int* const c_src = c_buf + 2 * LT_PIX_CHUNK;
+  int* const c_pre = c_buf + 3 * LT_PIX_CHUNK;  // [LT_PIX_CHUNK + 1]
+  __shared__ float c_rho2[LT_PIX_CHUNK];
+  __shared__ int wsum[4];
+  // the columns' written ranges, merged in LDS first: the pairs of a workgroup fall on a few dozen table entries of ONE
+  // wedge (a wall's column is visited by dozens of rows), and two global atomics + two stores per PAIR were 43 of the
+  // kernel's 92 us (tools/pix_sections.sh).  a_lo / a_hi are indexed by table entry - a_k0 and hold the col_zw encoding
+  // (0x7fff - lo, hi + 1; 0 = nothing); a workgroup whose pairs span more than LT_PIX_AGG entries marks directly.
+  __shared__ unsigned a_lo[LT_PIX_AGG], a_hi[LT_PIX_AGG];
+  __shared__ int a_k0, a_span;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t qmax = (1u << rho_bits) - 2u;
+  const int n_pix = im_h * im_w;
+  const uint32_t* const skey = (const uint32_t*)c_buf;  // staged quanta of [stage0, stage0 + n_stage)
+  int stage0 = 0, n_stage = 0;
+  // first table index in [a, b) whose rho quantum is >= q (b if none): the wedges are sorted by it.  The 64 pixels of a
+  // workgroup search the SAME wedge(s): 22 dependent global loads per pixel became one coalesced copy into LDS
+  bool staged = false;  // (workgroup-uniform: the whole search range is in LDS)
+  auto lower = [&](int a, int b, uint32_t q) {
+    if (staged) {
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (skey[m - stage0] < q) a = m + 1;
+        else b = m;
+      }
+    } else {
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (wd_key[m] < q) a = m + 1;
+        else b = m;
+      }
+    }
+    return a;
+  };
+  for (int p0 = blockIdx.x * 64; p0 < n_pix; p0 += gridDim.x * 64) {  // (workgroup-uniform)
+    const unsigned long long tm0 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;  // (100 MHz; debug)
+    LT_PIX_MARK(0);
+    // ---- A: the pixels' runs of table entries ------------------------------------------------------------------------
+    {  // stage the quanta of the wedges these 64 pixels search (one image column when im_h is a multiple of 64)
+      const int px_a = p0 / im_h, px_b = min(p0 + 63, n_pix - 1) / im_h;
+      stage0 = wd_start[px_a];
+      n_stage = wd_start[px_b + 1] - stage0;
+      staged = n_stage <= LT_PIX_STAGE;  // (a longer run of wedges is searched in global memory)
+#ifdef LT_PIX_NO_STAGE  // (timing experiment)
+      staged = false;
+#endif
+      if (staged)
+        for (int i = tid; i < n_stage; i += 256) c_buf[i] = (int)wd_key[stage0 + i];
+      __syncthreads();
+    }
+    if (wave != 0) {
+      for (int i = tid - 64; i < LT_PIX_AGG; i += 192) { a_lo[i] = 0u; a_hi[i] = 0u; }
+    }
+    if (wave == 0) {
+      const int p = p0 + lane;  // pixel (row r, column px) at [px * im_h + r] of the transposed images
+      const bool in = p < n_pix;
+      const int px = in ? p / im_h : 0, r = in ? p - px * im_h : 0;
+      const float4 row = rowtab[r];  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
+      const bool row_ok = row.x <= row.y;
+      // per observation as in k_tsdf_integrate_pix; the union: [min d_lo, max d_hi]
+      bool any = false;
+      float d_lo = 3e38f, d_hi = 0.f;
+      for (int kk = 0; kk < n_obs; ++kk) {
+        const float4 o4 = in ? obs4[(size_t)kk * n_pix_all + p] : make_float4(0.f, 1.f, 0.f, 0.f);
+        const float D = o4.x;
+        const bool finite = D == D && fabsf(D) < 1e30f;
+        const bool zero_class_k = in && row_ok && D != 0.f && o4.y == 0.0f;
+        const bool normal_k = in && row_ok && D != 0.f && o4.y != 0.0f && finite;
+        if (normal_k || zero_class_k) {
+          const float eps = __fmaf_rn(4e-6f, fabsf(D) + trunc_margin, 1e-6f);
+          const float hi_k = finite ? D + trunc_margin + eps : 3e38f;
+          // (once a voxel has been written -- by an earlier observation, inside an earlier interval -- a later one updates it
+          // anywhere in front of ITS band: a later observation's band further out extends the union's upper end, and the
+          // voxels in front of it that earlier observations wrote are inside the union already)
+          const float lo_k = zero_class_k ? 0.f : D - eps;
+          if (hi_k > 0.f) { any = true; d_lo = fminf(d_lo, lo_k); d_hi = fmaxf(d_hi, hi_k); }
+        }
+      }
+      const bool normal = any, zero_class = false;
+      const int s0 = wd_start[px], s1 = wd_start[px + 1];
+      int k = 0, kend = 0;
+      if ((normal || zero_class) && d_hi > 0.f) {
+        const float rho1 = fmaxf(d_lo, 0.f) * row.z * 0.999999f;
+        const float f1 = floorf(rho1 * qscale) - 2.f;
+        const uint32_t q1 = (uint32_t)fminf(fmaxf(f1, 0.f), (float)qmax);
+        k = lower(s0, s1, q1);
+        kend = s1;
+        if (d_hi < 3e38f) {
+          const float f2 = floorf(d_hi * row.w * 1.000001f * qscale) + 2.f;
+          const uint32_t q2 = (uint32_t)fminf(fmaxf(f2, 0.f), (float)qmax);
+          kend = lower(k, s1, q2 + 1u);
+        }
+      }
+      const int cnt = kend - k;
+      int inc = cnt;  // inclusive wave scan
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      p_k0[lane] = k; p_pre[lane] = inc - cnt; p_r[lane] = r; p_px[lane] = px;
+      p_tlo[lane] = row.x; p_thi[lane] = row.y; p_dlo[lane] = d_lo; p_dhi[lane] = d_hi;
+      if (lane == 63) p_pre[64] = inc;
+      // the span of table entries the workgroup's pairs fall on
+      int kmin = cnt > 0 ? k : 0x7fffffff, kmax = cnt > 0 ? kend : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, __shfl_xor(kmin, o, 64));
+        kmax = max(kmax, __shfl_xor(kmax, o, 64));
+      }
+      if (lane == 0) { a_k0 = kmin; a_span = kmax > kmin ? kmax - kmin : 0; }
+    }
+    __syncthreads();
+    const int T = p_pre[64];
+    const int agg_k0 = a_k0, agg_span = a_span;
+    const bool agg = agg_span <= LT_PIX_AGG;  // (workgroup-uniform)
+    if (VCOUNT && tid == 0) atomicAdd(&dbg[4], (unsigned long long)wall_clock64() - tm0);  // phase A
+    LT_PIX_MARK(1);
+    // ---- B: chunks of pairs ---------------------------------------------------------------------------------------------
+    for (int base = 0; base < T; base += LT_PIX_CHUNK) {
+      constexpr int PPT = LT_PIX_CHUNK / 256;  // pairs per thread
+      int len[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int slot = u * 256 + tid, i = base + slot;
+        len[u] = 0;
+        if (i < T) {
+          int sidx = 0;  // largest s with p_pre[s] <= i
+#pragma unroll
+          for (int st = 32; st >= 1; st >>= 1)
+            if (p_pre[sidx + st] <= i) sidx += st;
+          const int kk = p_k0[sidx] + (i - p_pre[sidx]);
+          const int2 e = wd_ent[kk];
+          int z = 1, zend = 0;
+          if (e.x >= 0) {  // (the quirk tail of the last wedge carries column -1)
+            const float rho2 = __int_as_float(e.y), rho = sqrtf(rho2);
+            const float d_lo = p_dlo[sidx], d_hi = p_dhi[sidx];
+            const float hi2 = d_hi * d_hi - rho2;
+            if (hi2 >= 0.f) {  // (else the whole column lies beyond the band; false also for NaN)
+              const float zmax = sqrtf(hi2) * 1.000001f + 1e-6f;
+              const float lo2 = d_lo > 0.f ? d_lo * d_lo - rho2 : -1.f;
+              const float zmin = lo2 > 0.f ? fmaxf(sqrtf(lo2) * 0.999999f - 1e-6f, 0.f) : 0.f;
+              const float za = rho * p_tlo[sidx], zb = rho * p_thi[sidx];  // pt_z of the row in this column
+              float lo, hi;
+              if (za >= 0.f) { lo = fmaxf(za, zmin); hi = fminf(zb, zmax); }
+              else if (zb <= 0.f) { lo = fmaxf(za, -zmax); hi = fminf(zb, -zmin); }
+              else { lo = fmaxf(za, -zmax); hi = fminf(zb, zmax); }
+              if (lo <= hi) {
+                const float fz0 = ceilf((lo - oz) * inv_vs - 0.02f), fz1 = floorf((hi - oz) * inv_vs + 0.02f);
+                z = (int)fmaxf(fz0, 0.f);
+                zend = (int)fminf(fz1, (float)(vol_dim_z - 1));
+              }
+            }
+          }
+          const int partial = 0;
+          len[u] = max(zend - z + 1, 0);
+          c_col[slot] = e.x; c_rho2[slot] = __int_as_float(e.y); c_z0[slot] = z; c_src[slot] = sidx | partial;
+          // the column's written range and stamp once per PAIR, for the whole candidate interval (a superset is safe, as in
+          // the column walk) -- per written voxel, the ten threads holding one column's band voxels fought over one word
+#ifndef LT_PIX_NO_MARK  // (timing experiment)
+          if (len[u] > 0) {
+            if (agg) {
+              atomicMax(&a_lo[kk - agg_k0], (unsigned)(0x7FFF - z));
+              atomicMax(&a_hi[kk - agg_k0], (unsigned)(zend + 1));
+            } else {
+              col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, e.x, z, zend);
+            }
+          }
+#endif
+        }
+      }
+      // exclusive prefix of the interval lengths over the chunk's slots (slot = u * 256 + tid: strided passes)
+      int run = 0;  // voxels of the passes before
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        int inc = len[u];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        c_pre[u * 256 + tid] = run + woff + inc - len[u];
+        run += tot;
+        __syncthreads();
+      }
+      if (tid == 0) c_pre[LT_PIX_CHUNK] = run;
+      __syncthreads();
+      const int V = run, n_slots = min(T - base, LT_PIX_CHUNK);
+      const unsigned long long tm1 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;
+      if (VCOUNT && tid == 0 && base == 0) atomicAdd(&dbg[5], tm1 - tm0);  // ... + first chunk's pairs and scan
+      if (base == 0) LT_PIX_MARK(2);
+      // the chunk's voxels, one per thread and round
+      for (int jb = 0; jb < V; jb += 256) {  // (workgroup-uniform trips: the run aggregation below shuffles)
+        const int j = jb + tid;
+        int code = 0, col = 0, z = 0;
+        if (j < V) {
+        int sl = 0;  // largest slot < n_slots with c_pre[slot] <= j
+#pragma unroll
+        for (int st = LT_PIX_CHUNK / 2; st >= 1; st >>= 1)
+          if (sl + st < n_slots && c_pre[sl + st] <= j) sl += st;
+        const int sflag = c_src[sl], sidx = sflag & 63;
+        col = c_col[sl]; z = c_z0[sl] + (j - c_pre[sl]);
+        bool mine = true;
+        col_plain Cq;
+        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+#ifdef LT_PIX_NO_EVAL  // timing experiment: everything but the evaluation (nothing is written)
+        mine = false;
+#endif
+        if (mine)
+        code = tsdf_voxel_multi(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y, vol_dim_z,
+                                ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down, sin_up_hi,
+                                sin_down_lo, wd_px, Cq, z, obs4, n_obs, p_r[sidx]);
+        }
+        // sign bits: the volume is fresh, every bit is 0 -- only negative values need a write; the voxels of a pair sit in
+        // neighbouring lanes and (mostly) in one 64-bit word: OR them together over the run, one atomic per run
+#ifdef LT_PIX_NO_BITS  // timing experiment: no sign bits (marching cubes would see nothing)
+        code = 0;
+#endif
+        const int wkey = code == 2 ? col * words_z + (z >> 6) : -1 - lane;  // (unique when there is nothing to write)
+        unsigned long long bits = code == 2 ? 1ull << (z & 63) : 0ull;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // runs of up to 16 lanes (a run is one column's interval: ~10 voxels)
+          const unsigned long long ob = __shfl_down(bits, o, 64);
+          const int ok = __shfl_down(wkey, o, 64);
+          if (lane + o < 64 && ok == wkey) bits |= ob;
+        }
+        const int prev = __shfl_up(wkey, 1, 64);
+        if (code == 2 && (lane == 0 || prev != wkey || (lane & 15) == 0))  // (lane & 15: a run longer than 16 lanes)
+          atomicOr(sign_bits + (size_t)wkey, bits);
+        if (VCOUNT) {  // (one atomic per wave and round: a per-voxel atomic on one address would be the whole kernel)
+          const unsigned long long wr = __ballot(code != 0);
+          if (lane == 0 && wr) atomicAdd(&dbg[2], (unsigned long long)__popcll(wr));
+        }
+      }
+      if (VCOUNT && tid == 0) {
+        atomicAdd(&dbg[0], (unsigned long long)n_slots); atomicAdd(&dbg[1], (unsigned long long)V);
+        atomicAdd(&dbg[6], (unsigned long long)wall_clock64() - tm1);  // the voxel rounds
+        atomicAdd(&dbg[7], 1ull);
+      }
+      __syncthreads();  // the chunk's arrays are reused
+    }
+    LT_PIX_MARK(3);
+    // the merged ranges -> col_zw, stamps: once per column (all pairs of all chunks have merged: the barrier above)
+    if (agg)
+      for (int i = tid; i < agg_span; i += 256) {
+        const unsigned hi1 = a_hi[i];
+        if (hi1) {
+          const int c = wd_ent[agg_k0 + i].x;
+          const int n_cols = vol_dim_x * vol_dim_y;
+          atomicMax(&col_zw[c], a_lo[i]);  // (atomic: with an image height that does not divide 64 two workgroups share a wedge)
+          atomicMax(&col_zw[n_cols + c], hi1);
+          col_epoch[c] = epoch;
+          chunk_epoch[c >> 6] = epoch;
+        }
+      }
+    LT_PIX_MARK(4);
+    __syncthreads();  // ... and the pixels'
+  }
+}
+
+// the quirk columns (not in the wedge table) for the n observations at once, one thread per voxel
+__global__ __launch_bounds__(256) void k_tsdf_integrate_quirk_multi(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
+    float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
+    float voxel_size, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up, float fov_down,
+    float sin_up_hi, float sin_down_lo, const float4* __restrict__ obs4, int n_obs, const int* __restrict__ wd_px,
+    unsigned* __restrict__ col_epoch, unsigned epoch, unsigned long long* __restrict__ sign_bits, int words_z,
+    unsigned* __restrict__ col_zw, unsigned* __restrict__ chunk_epoch, const uint32_t* __restrict__ qcols, int n_q) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_q * vol_dim_z) return;
+  const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
+  col_plain C;
+  C.plain = false; C.px = -2; C.rho2 = 0.f;
+  const int code = tsdf_voxel_multi(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
+                                    vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down,
+                                    sin_up_hi, sin_down_lo, wd_px, C, z, obs4, n_obs);
+  if (code) {
+    if (code == 2) atomicOr(sign_bits + (size_t)col * words_z + (z >> 6), 1ull << (z & 63));  // (fresh volume: the bit is 0)
+    col_mark_written(col_zw, col_epoch, chunk_epoch, epoch, vol_dim_x * vol_dim_y, col, z, z);
+  }
+}
+
 // A volume that already holds observations: every voxel inside a column's written range [lo, hi] -- as it stood before this
 // observation (zw_snap) -- runs the reference's expressions with its stored values loaded (`fresh` = false): a voxel written
 // earlier can be written again anywhere in front of the band (same class: the running average; another class: the closer
@@ -1145,7 +1579,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
-                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap, t->chunk_epoch};
+                t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap, t->chunk_epoch, t->obs4};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   free(t);
@@ -1539,6 +1973,81 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
                        t->epoch, G, t->bits, (t->dim[2] + 63) / 64, t->col_zw, t->dct, kA, kB, t->colinfo + n_cols, colz, colrho2, t->all_dirty, dbg,
                        t->chunk_epoch);
   LT_HIP(hipGetLastError());
+  return LT_OK;
+}
+
+// see include/lidarhip.h
+extern "C" int lt_tsdf_integrate_multi_dev(lt_tsdf* t, int n_obs, const float* const* color_ims, const float* const* depth_ims,
+                                           const float* const* rem_ims, int im_h, int im_w, float obs_weight, unsigned flags,
+                                           void* stream_) {
+  if (!t || n_obs < 0 || (n_obs > 0 && (!color_ims || !depth_ims || !rem_ims)) || im_h <= 0 || im_w <= 0) {
+    lt_set_error("lt_tsdf_integrate_multi_dev: invalid argument");
+    return LT_ERR_INVALID_ARG;
+  }
+  for (int k = 0; k < n_obs; ++k)
+    if (!color_ims[k] || !depth_ims[k] || !rem_ims[k]) {
+      lt_set_error("lt_tsdf_integrate_multi_dev: observation %d has a NULL image", k);
+      return LT_ERR_INVALID_ARG;
+    }
+  hipStream_t stream = (hipStream_t)stream_;
+  LT_HIP(hipSetDevice(t->device));
+  const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
+  const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
+  static const bool pix_off = []() { const char* e = getenv("LIDARHIP_TSDF_PIX"); return e && e[0] != 0 && strcmp(e, "2") != 0; }();
+  static const bool multi_off = []() { const char* e = getenv("LIDARHIP_TSDF_MULTI"); return e && strcmp(e, "0") == 0; }();
+  const bool tan_ok = fabs((double)fu) < 1.39 && fabs((double)fd) < 1.39;
+  int px_bits = 1;
+  while ((1 << px_bits) < im_w) ++px_bits;
+  // the fused pass: the class-aware update of a FRESH volume, under the conditions of the pixel-centric integrate
+  const bool fuse = !pix_off && !multi_off && (flags & LT_TSDF_MERGE) && t->n_obs == 0 && !t->all_dirty && tan_ok &&
+                    30 - px_bits >= 12 && fabsf(fu) + fabsf(fd) > 0.f && n_obs >= 2;
+  int done = 0;
+  if (fuse) {
+    const int n = n_obs < LT_TSDF_MULTI_MAX ? n_obs : LT_TSDF_MULTI_MAX;
+    const int rho_bits = 30 - px_bits;
+    if (t->wd_w != im_w || t->wd_rho_bits != rho_bits) LT_CHECK(tsdf_wedge_build(t, im_w, rho_bits, stream));
+    if (t->rowtab_for_h != im_h || !t->rowtab) {
+      t->rowtab_for_h = 0;
+      LT_CHECK(tsdf_rowtab(t, im_h, fu, fd, stream));
+      t->rowtab_for_h = im_h;
+    }
+    const size_t n_pix = (size_t)im_h * im_w;
+    if ((size_t)n * n_pix > t->cap_obs4) {
+      if (t->obs4) { LT_HIP(hipStreamSynchronize(stream)); (void)hipFree(t->obs4); t->obs4 = nullptr; t->cap_obs4 = 0; }
+      LT_HIP(hipMalloc((void**)&t->obs4, (size_t)LT_TSDF_MULTI_MAX * n_pix * sizeof(float4)));
+      t->cap_obs4 = (size_t)LT_TSDF_MULTI_MAX * n_pix;
+    }
+    tsdf_obs_ptrs O;
+    for (int k = 0; k < LT_TSDF_MULTI_MAX; ++k) {
+      const int q = k < n ? k : 0;
+      O.color[k] = color_ims[q]; O.depth[k] = depth_ims[q]; O.rem[k] = rem_ims[q];
+    }
+    hipLaunchKernelGGL(k_tsdf_dct4, dim3((unsigned)((n * n_pix + 255) / 256)), dim3(256), 0, stream, O, n, im_h, im_w, t->obs4);
+    const float su = (float)(sin((double)fu) + 1e-5), sd = (float)(sin((double)fd) - 1e-5);
+    const int words_z = (t->dim[2] + 63) / 64;
+    static const int env_wgs = []() { const char* e = getenv("LIDARHIP_PIX_WGS"); return e ? atoi(e) : -1; }();
+    const int res_wgs = lt_cu_count(t->device) * 5;
+    const int groups = (int)((n_pix + 63) / 64);
+    const unsigned nb = (unsigned)min(groups, env_wgs > 0 ? env_wgs : (env_wgs == 0 ? (1 << 20) : res_wgs));
+    hipLaunchKernelGGL((k_tsdf_integrate_pix_multi<false>), dim3(nb), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem,
+                       t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2], t->voxel_size,
+                       1.0f / t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, (const float4*)t->obs4, n,
+                       t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->chunk_epoch, t->rowtab, t->wd_start,
+                       t->wd_ent, t->wd_key, t->wd_rho_bits, t->wd_qscale, (unsigned long long*)nullptr);
+    if (t->wd_n_quirk > 0) {
+      const long long nv = (long long)t->wd_n_quirk * t->dim[2];
+      hipLaunchKernelGGL(k_tsdf_integrate_quirk_multi, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->tsdf,
+                         t->weight, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->origin[0], t->origin[1], t->origin[2],
+                         t->voxel_size, im_h, im_w, t->trunc_margin, obs_weight, fu, fd, su, sd, (const float4*)t->obs4, n,
+                         t->wd_px, t->col_epoch, t->epoch, t->bits, words_z, t->col_zw, t->chunk_epoch, t->wd_qcols,
+                         t->wd_n_quirk);
+    }
+    LT_HIP(hipGetLastError());
+    t->n_obs += n;
+    done = n;
+  }
+  for (int k = done; k < n_obs; ++k)
+    LT_CHECK(lt_tsdf_integrate_dev(t, color_ims[k], depth_ims[k], rem_ims[k], im_h, im_w, obs_weight, flags, stream_));
   return LT_OK;
 }
 

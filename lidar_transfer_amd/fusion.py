@@ -145,6 +145,41 @@ class TSDFVolume:
                                                            C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_dev")
         st.synchronize()  # the temporaries above must outlive the kernel
 
+    def integrate_multi(self, observations, obs_weight=1.):
+        """``integrate`` for a list of ``(color_im, depth_im, rem_im)`` observations, in order -- the loop of
+        ``deform``'s mesh adaption (laserscan.py:889-897) as ONE native call (``lt_tsdf_integrate_multi_dev``): same
+        volume, bit for bit, as one ``integrate`` per observation; on a fresh volume the class-aware update of up to
+        eight observations runs as one pass over the union of their candidate voxels."""
+        torch, C = self._torch, self._C
+
+        def dev(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(self.device, torch.float32).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+        n = len(observations)
+        if n == 0:
+            return
+        keep = []
+        vp = C.c_void_p
+        cp, dp, rp = (vp * n)(), (vp * n)(), (vp * n)()
+        h = w = 0
+        for k, (color_im, depth_im, rem_im) in enumerate(observations):
+            c = dev(color_im)
+            if c.dim() == 3:
+                c = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()
+            d, r = dev(depth_im), dev(rem_im)
+            if k and tuple(d.shape) != (h, w):
+                raise ValueError("observations of one call must have one image shape")
+            h, w = int(d.shape[0]), int(d.shape[1])
+            keep += [c, d, r]
+            cp[k], dp[k], rp[k] = c.data_ptr(), d.data_ptr(), r.data_ptr()
+        st = torch.cuda.current_stream(self.device)
+        self._libmod.check(self._lib.lt_tsdf_integrate_multi_dev(self._h, n, cp, dp, rp, h, w, float(obs_weight),
+                                                                 self._libmod.LT_TSDF_MERGE if self.merge else 0,
+                                                                 C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_multi_dev")
+        st.synchronize()  # the temporaries above must outlive the kernels
+
     def reset(self):
         """Back to the initial volume (what ``TSDFVolume(...)`` of the reference starts from); only the voxel columns
         written since the last reset are re-initialised."""

@@ -21,7 +21,7 @@ def _source_scans(n_scans, dtype, seed=5):
     from lidar_transfer_amd.laserscan import create_rays
     from lidar_transfer_amd.raytracer import RaySet, Scene
     from lidar_transfer_amd.synth import synth_scene
-    v, f, c, r = synth_scene(seed, 30000, bounds=(-12, 12, -12, 12, -3, 3))
+    v, f, c, r = synth_scene(seed, 30000, bounds=(-12, 12, -12, 12, -3, 3), n_boxes=10, n_poles=8)
     H, W, fu, fd = SRC
     rays = torch.from_numpy(create_rays(fu, fd, H, W)).cuda()
     sc = Scene(0)

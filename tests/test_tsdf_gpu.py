@@ -259,3 +259,60 @@ def test_column_aware_integrate_equals_dense_kernel_bit_for_bit(tmp_path, merge,
     assert (t < 0).sum() > (10000 if voxel < 0.1 else 1000) and (t != 1).mean() < 0.5
     if voxel > 0.2:   # voxels next to the sensor written through the all -1 image columns (trunc_margin 1.25 m > 1)
         assert (res["dense"]["first1"] != 0).sum() > 0
+
+
+@pytest.mark.parametrize("fu,fd,voxel,hw,n_obs", [(10.0, -25.0, 0.05, (32, 256), 4), (5.0, -30.0, 0.25, (70, 97), 3),
+                                                    (10.0, -25.0, 0.05, (32, 256), 11), (40.0, -50.0, 0.05, (32, 256), 2)])
+def test_fused_observations_equal_one_integrate_per_observation(fu, fd, voxel, hw, n_obs):
+    """lt_tsdf_integrate_multi_dev -- all observations of a fresh volume in ONE pixel pass, the updates applied in order on
+    the voxel's state in registers -- against one lt_tsdf_integrate_dev per observation (itself bit-identical to the
+    one-thread-per-voxel restatement of the reference kernel, test above): the four fields bit for bit, the mesh extracted
+    from the kept sign bits, and once more after a reset.  The observations differ from each other the way re-projected
+    neighbouring scans do -- centimetre noise, holes, other labels (the "other class" branch), label 0 (the fresh volume's
+    own class: long runs), no-data columns, NaN / infinite pixels -- plus one observation whose surface lies a metre in front
+    of the others' and one a metre behind (bands that do not overlap).  11 observations: more than one fused pass holds
+    (8), the rest take the single-observation path on the then non-fresh volume."""
+    import torch
+    from lidar_transfer_amd.fusion import TSDFVolume
+    H, W = hw
+    rng = np.random.default_rng(17)
+    yaw = np.linspace(-np.pi, np.pi, W)
+    half = 15.0 if voxel < 0.1 else 20.0
+    bnds = np.array([[-half, half], [-half, half], [-5.0, 5.0]])
+    base = (6.0 + 3.0 * np.sin(3 * yaw)[None, :] + 0.2 * rng.random((H, W))).astype(np.float32)
+    lab0 = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W), p=[0.1, 0.6, 0.3]).astype(np.float32)
+    obs = []
+    for k in range(n_obs):
+        depth = (base + 0.02 * rng.standard_normal((H, W))).astype(np.float32)
+        if k == 1:
+            depth = (depth - 1.0).astype(np.float32)       # a surface a metre closer
+        if k == 2:
+            depth = (depth + 1.0).astype(np.float32)       # ... and a metre further
+        depth[rng.random((H, W)) < 0.05] = 0.0
+        depth[:, 40 * W // 256:60 * W // 256] = 0.0
+        depth[:, 100 * W // 256:110 * W // 256] = -1.0
+        depth[rng.random((H, W)) < 0.003] = np.nan
+        depth[rng.random((H, W)) < 0.003] = np.inf
+        lab = lab0.copy()
+        flip = rng.random((H, W)) < 0.05
+        lab[flip] = rng.choice(np.array([0.0, 40.0, 50.0, 10.0]), int(flip.sum()))
+        label3 = np.stack([lab, np.zeros_like(lab), np.zeros_like(lab)], 2)
+        obs.append((label3, depth, rng.random((H, W)).astype(np.float32)))
+    seq = TSDFVolume(bnds, voxel, fu, fd)
+    fused = TSDFVolume(bnds, voxel, fu, fd)
+    for rnd in range(2):
+        for o in obs:
+            seq.integrate(*o, np.eye(4))
+        fused.integrate_multi(obs)
+        torch.cuda.synchronize()
+        a, b = seq.get_volume_tensors(), fused.get_volume_tensors()
+        for name, x, y in zip(("tsdf", "weight", "color", "rem"), a, b):
+            same = torch.equal(x.view(torch.int32), y.view(torch.int32))
+            assert same, f"round {rnd}: {name} differs in {int((x.view(torch.int32) != y.view(torch.int32)).sum())} voxels"
+        ma = [t.cpu().numpy() for t in seq.extract_mesh().tensors()]
+        mb = [t.cpu().numpy() for t in fused.extract_mesh().tensors()]
+        assert ma[1].shape == mb[1].shape and all(np.array_equal(p, q) for p, q in zip(ma, mb))
+        if rnd == 0:
+            assert int((a[0] < 0).sum()) > 1000 and int((a[1] > 1.5).sum()) > 1000, "the observations did not overlap"
+            seq.reset(); fused.reset()
+    seq.close(); fused.close()
