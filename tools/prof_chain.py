@@ -32,8 +32,14 @@ for k in range(1, n_obs):
                 torch.where(hole | (depth == 0), torch.zeros_like(depth), depth + noise).contiguous()))
 for i in range(n):
     assert lib.lt_tsdf_reset(vol._h, sp) == 0
-    for f_k, d_k in obs:
-        assert lib.lt_tsdf_integrate_dev(vol._h, f_k.data_ptr(), d_k.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
+    if os.environ.get("LT_CHAIN_SEQUENTIAL") == "1":   # one lt_tsdf_integrate_dev per observation (rounds 1-3)
+        for f_k, d_k in obs:
+            assert lib.lt_tsdf_integrate_dev(vol._h, f_k.data_ptr(), d_k.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
+    else:                                               # all observations of the fresh volume in one fused pass
+        vpn = C.c_void_p * len(obs)
+        assert lib.lt_tsdf_integrate_multi_dev(vol._h, len(obs), vpn(*[f_k.data_ptr() for f_k, _ in obs]),
+                                               vpn(*[d_k.data_ptr() for _, d_k in obs]), vpn(*[remi.data_ptr()] * len(obs)),
+                                               H, W, 1.0, 1, sp) == 0
     assert lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None) == 0
     assert lib.lt_scene_set_mesh(sc._h, mesh._h) == 0
     assert lib.lt_scene_render_dev(sc._h, rs._h, org, o["endpoints"].data_ptr(), o["endcolors"].data_ptr(), o["range"].data_ptr(),

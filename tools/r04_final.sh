@@ -10,9 +10,6 @@ bash tools/r04_profile.sh > gpurun_out/r04/profile.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r04/chain5 -o s -- python $GRAFT_REPO_ROOT/tools/prof_chain.py 6 5 > /dev/null 2>&1)
 cp $(ls gpurun_out/r04/chain5/*/s_kernel_stats.csv gpurun_out/r04/chain5/s_kernel_stats.csv 2>/dev/null | head -1) gpurun_out/r04/chain5_kernel_stats.csv
 find gpurun_out/r04 -name "*kernel_trace.csv" -size +2M -delete
-bash tools/tlb_probe.sh > /dev/null 2>&1
-bash tools/atomic_probe.sh > /dev/null 2>&1
-bash tools/occ_probe.sh > /dev/null 2>&1
 for c in 2 3 4; do python tools/chain_pipeline.py $c 16 1 2>&1 | tail -1; done > gpurun_out/r04/chain_pipeline.txt
 python tools/chain_pipeline.py 3 8 5 2>&1 | tail -1 >> gpurun_out/r04/chain_pipeline.txt
 # the gather modes of the timed region at world size 1 under torchrun (RCCL communicator, gather path executed)

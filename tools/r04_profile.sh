@@ -31,6 +31,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso_scatter -o s -- python $R/tools/prof_render.py --reps 40 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso_lbvh -o s -- python $R/tools/prof_scan.py --reps 40 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain -o s -- python $R/tools/prof_chain.py 12 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain5f -o s -- python $R/tools/prof_chain.py 8 5 > /dev/null 2>&1
 cd $R
 python tools/pmc_to_json.py gpurun_out/r04/pmc_bench gpurun_out/r04/pmc.json --command "python bench.py --no-cpu-baseline --no-other --no-e2e --no-chain --steps 16 --warmup 2" > gpurun_out/r04/pmc_to_json.log 2>&1
 python tools/pmc_to_json.py gpurun_out/r04/pmc_lbvh gpurun_out/r04/pmc_lbvh.json --command "python tools/prof_scan.py --reps 5" >> gpurun_out/r04/pmc_to_json.log 2>&1
@@ -41,7 +42,7 @@ python tools/pmc_summary.py gpurun_out/r04/pmc_lbvh > gpurun_out/r04/pmc_lbvh.tx
 python tools/pmc_summary.py gpurun_out/r04/pmc_chain > gpurun_out/r04/pmc_chain.txt 2>&1
 # bench.py reads pmc*.json from profiles/: put them there before the final line is measured
 cp gpurun_out/r04/pmc.json gpurun_out/r04/pmc_lbvh.json gpurun_out/r04/pmc_chain.json gpurun_out/r04/ea_requests.json $P/ 2>/dev/null
-for d in serial_probe stats iso_scatter iso_lbvh chain; do
+for d in serial_probe stats iso_scatter iso_lbvh chain chain5f; do
   f=$(ls $O/$d/*/s_kernel_stats.csv $O/$d/s_kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
 done
