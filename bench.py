@@ -1330,7 +1330,7 @@ def main():
             return None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import chain_pipeline
-        return chain_pipeline.run_cases(chains, ((12, 1), (6, 5)), local_rank, args.workload)
+        return chain_pipeline.run_cases(chains, ((12, 1), (12, 5)), local_rank, args.workload)
 
     pipelined = guarded("fusion_chain_pipelined", fusion_chain_pipelined) if (rank == 0 and not args.no_chain and world == 1) else None
     chain = guarded("fusion_chain", fusion_chain) if (rank == 0 and not args.no_chain and world == 1) else None

@@ -92,7 +92,7 @@ struct lt_scene {
   // during a render and one ray set (one sensor model) serves any number of scenes and streams at once
   unsigned long long* sc_cell;  // [sc_cap_cells] packed (t, face) z-min per ray; all-ones = empty, re-armed by k_sc_resolve
   int* sc_large;                // [sc_cap_queue] queue of big triangles
-  int4* sc_slices;              // [sc_cap_queue] queue of (block, first candidate, first triangle slot, its prefix) slices
+  int2* sc_slices;              // [sc_cap_queue] queue of (block, first candidate) slices
   int* sc_large_count;          // [4]: [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
   int sc_cap_cells, sc_cap_queue;
   int built;

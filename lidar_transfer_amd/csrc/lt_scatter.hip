@@ -461,14 +461,18 @@ __global__ __launch_bounds__(256) void k_rs_grid(const int* __restrict__ bin_sta
 
 #define LT_SC_BIG 512    // candidate bins above which a triangle goes to the wave-per-triangle queue
 // Candidates a k_sc_tris workgroup tests itself; the rest of a heavier workgroup is queued in slices for k_sc_rest.
-//   single-scan call: 1024 (4 rounds) -- a few near-field workgroups with 10-20 rounds would otherwise run long
-//     after the rest of the grid has drained (measured: a 20 us tail on a 37 us kernel);
+//   single-scan call: 1536 (6 rounds of 256; 1024 with round 3's 256-triangle workgroups: the same share of a
+//     workgroup's candidates) -- a few near-field workgroups with 10-20 rounds would otherwise run long after the rest of
+//     the grid has drained (measured: a 20 us tail on a 37 us kernel; round 4, k_sc_tris + k_sc_rest + k_sc_resolve of one
+//     C2 scan: cap 1024 / 1536 / 8192 -> 37.6 / 34.7 / 40.4 us, profiles/r04/cap_iso.txt);
 //   batch call: 8192 -- with the triangles of 8 scans in one grid there is no tail to speak of, and what is
 //     deferred costs a second pass over its triangle block in k_sc_rest (7.6 -> 8.3 Grays/s on C2, where no
 //     workgroup reaches 8192; the bound is there for a near field full of medium-sized triangles).
-#define LT_SC_CAP_SINGLE 1024
+#define LT_SC_CAP_SINGLE 1536
 #define LT_SC_CAP_BATCH 8192
+#ifndef LT_SC_SLICE
 #define LT_SC_SLICE 512  // candidates per queued slice (k_sc_rest)
+#endif
 
 // Triangles per workgroup of k_sc_tris / k_sc_rest.  A workgroup's life is a chain of dependent round trips -- index triple
 // -> three vertices -> bounds -> prefix sum (two barriers) -> phase B -- at the hardware's 8 waves per SIMD (DESIGN.md section
@@ -494,7 +498,6 @@ struct sc_shared {
   unsigned pre[513];
   unsigned wsum[4];
   int kept;
-  int slice_base;  // first queue entry of this workgroup's slices (-1: none queued)
 };
 
 struct sc_one { int cnt; unsigned a0; };  // phase A's result for one triangle: candidate bins (0: none / invalid / big), a0
@@ -710,7 +713,7 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
 struct sc_job {
   const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
   rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
-  unsigned long long* cell; int* large; int* large_count; int4* slices;
+  unsigned long long* cell; int* large; int* large_count; int2* slices;
   unsigned* flags; unsigned long long* counters;
   float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
   float ox, oy, oz;
@@ -756,29 +759,27 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
 #endif
   int total, preA, preB;
   sc_prefix(S, rA, rB, preA, preB, total);
-  // The workgroup keeps the triangles that start below the cap; exactly one slot sees the crossing and its lane reserves
-  // queue entries for the rest, in slices of LT_SC_SLICE candidates (large_count[1] = number of slices; if the queue is
-  // full the workgroup keeps all).  The entries are written after the barrier, one lane per slice: a slice names its
-  // first triangle and that triangle's prefix, so that k_sc_rest redoes phase A for the slice's OWN triangles only.
+  // The workgroup keeps the triangles that start below the cap; exactly one slot sees the crossing and its lane queues
+  // the rest in slices of LT_SC_SLICE candidates (large_count[1] = number of slices; if the queue is full the workgroup
+  // keeps all).
   if (total < B.cap) {
-    if (tid == 255) { S.kept = total; S.slice_base = -1; }
+    if (tid == 255) S.kept = total;
   } else {
     const bool crossA = preA < B.cap && preA + rA.cnt >= B.cap;
     const bool crossB = LT_SC_T2 > 0 && tid < LT_SC_T2 && preB < B.cap && preB + rB.cnt >= B.cap;
     if (crossA || crossB) {
       int kept = crossA ? preA + rA.cnt : preB + rB.cnt;
-      int sbase = -1;
       const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
       if (n_sl > 0) {
-        sbase = atomicAdd(&J.large_count[1], n_sl);
-        if (sbase + n_sl > J.cap_slices) {
+        const int base = atomicAdd(&J.large_count[1], n_sl);
+        if (base + n_sl <= J.cap_slices) {
+          for (int k = 0; k < n_sl; ++k) J.slices[base + k] = make_int2(lb, kept + k * LT_SC_SLICE);
+        } else {
           atomicSub(&J.large_count[1], n_sl);
           kept = total;
-          sbase = -1;
         }
       }
       S.kept = kept;
-      S.slice_base = sbase;
     }
   }
   __syncthreads();
@@ -787,45 +788,25 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   return;
 #endif
   const int kept = S.kept;
-  if (S.slice_base >= 0) {
-    const int n_sl = (total - kept + LT_SC_SLICE - 1) / LT_SC_SLICE;
-    for (int k = tid; k < n_sl; k += 256) {
-      const int c0 = kept + k * LT_SC_SLICE;
-      const unsigned ck = ((unsigned)c0 << 13) | 0x1FFFu;
-      int jj = 0;
-#pragma unroll
-      for (int step = 256; step >= 1; step >>= 1)
-        if (S.pre[jj + step] <= ck) jj += step;
-      // (tri_bins takes wave-uniform short cuts -- ballots over the 64 triangles a wave holds --, so a triangle's bounds,
-      // hence its candidate count, are only reproduced when it is evaluated in the SAME group of 64 slots: the slice
-      // starts at the group's first slot)
-      jj &= ~63;
-      J.slices[S.slice_base + k] = make_int4(lb, c0, jj, (int)(S.pre[jj] >> 13));
-    }
-  }
   unsigned n_tests = 0, n_cand = 0;
   sc_round_robin<COUNT, WIDE, 256, (LT_SC_T > 256 ? 512 : 256)>(S.pre, S.q0, S.q1, S.q2, P, J.grid, J.sdirs, J.cell, first, 0,
                                                                 kept, tid, ox, oy, oz, n_tests, n_cand);
   sc_count<COUNT>(n_tests, n_cand, J.counters);
 }
 
-// The rest, LT_SC_REST_BLOCKS workgroups per scan: (1) queued slices of heavy workgroups -- ONE WAVE per slice: it redoes
-// phase A for the slice's own triangles, 64 at a time in k_sc_tris' groups of 64 slots (same code on the same lanes,
-// hence the same counts: the slice's candidate numbers mean the same here), and tests the slice's candidates; no workgroup barrier anywhere; (2) big
+// The rest, LT_SC_REST_BLOCKS workgroups per scan: (1) queued slices of heavy workgroups -- a workgroup redoes
+// phase A of that triangle block (same code, same prefix sums) and tests one slice of its candidates; (2) big
 // triangles, up to LT_SC_PARTS waves each, lanes stride over the candidate bins.
-// (Until round 4 a slice was a WORKGROUP redoing phase A of the whole triangle block: deferring work cost as much as a
-// k_sc_tris workgroup per 512 candidates, so the batch call kept up to 8192 candidates per workgroup -- and its heavy
-// workgroups were a quarter of the launch's exclusive duration.)
+// (Round 4 also built ONE WAVE per slice -- the slice naming its own triangles, aligned to the group of 64 slots a wave of
+// k_sc_tris held, because tri_bins takes wave-uniform short cuts and a triangle's candidate count is only reproduced inside
+// the same group -- to make deferring cheap and the batch cap low: bit-identical, but a single-scan k_sc_rest took 15-20 us
+// instead of 10 (a wave's slice is a serial chain of two gathers, the bounds and eight rounds of 64 candidates), and lower
+// batch caps did not pay either: deferred work is conserved, not saved.  DESIGN.md section 5d, profiles/r04.)
 #define LT_SC_REST_BLOCKS 512
 #define LT_SC_PARTS 8
-struct sc_wave_shared {  // per wave of k_sc_rest: 64 triangle records + their prefix (sc_shared's layout)
-  float4 q0[64], q1[64];
-  float2 q2[64];
-  unsigned pre[65];
-};
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
-  __shared__ sc_wave_shared SW[4];
+  __shared__ sc_shared S;
   const sc_job& J = B.job[blockIdx.x / LT_SC_REST_BLOCKS];
   const int rb = blockIdx.x % LT_SC_REST_BLOCKS;
   if (J.n_faces <= 0) return;
@@ -839,48 +820,21 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
   if (COUNT && rb == 0 && threadIdx.x == 0) J.counters[3] = (unsigned long long)n_large | ((unsigned long long)n_slices << 32);
   unsigned n_tests = 0, n_cand = 0;
+  for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
+    const int2 sl = J.slices[q];
+    const int first = sl.x * LT_SC_T;
+    sc_one rA, rB;
+    sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, nullptr, nullptr, nullptr, rA, rB);
+    int total, preA, preB;
+    sc_prefix(S, rA, rB, preA, preB, total);
+    __syncthreads();
+    sc_round_robin<COUNT, WIDE, 256, (LT_SC_T > 256 ? 512 : 256)>(S.pre, S.q0, S.q1, S.q2, P, grid, sdirs, cell, first, sl.y,
+                                                                  min(sl.y + LT_SC_SLICE, total), (int)threadIdx.x, ox, oy,
+                                                                  oz, n_tests, n_cand);
+    __syncthreads();  // LDS is reused by the next slice
+  }
   const int lane = threadIdx.x & 63;
   const int wave0 = rb * 4 + (threadIdx.x >> 6), nwaves = LT_SC_REST_BLOCKS * 4;
-  sc_wave_shared& S = SW[threadIdx.x >> 6];
-  const unsigned nv = (unsigned)J.n_verts;
-  for (int q = wave0; q < n_slices && J.n_verts > 0; q += nwaves) {
-    const int4 sl = J.slices[q];  // (workgroup of k_sc_tris, first candidate, first triangle slot, that slot's prefix)
-    const int first = sl.x * LT_SC_T, c_end = sl.y + LT_SC_SLICE;
-    int run = sl.w;
-    for (int jb = sl.z; jb < LT_SC_T && run < c_end; jb += 64) {
-      const int slot = jb + lane, f = first + slot;
-      const bool has = slot < LT_SC_T && f < J.n_faces;
-      const i3 idx = *at<WIDE>((const i3*)faces, (unsigned)(has ? f : 0));
-      const bool ok = has && (unsigned)idx.x < nv && (unsigned)idx.y < nv && (unsigned)idx.z < nv;
-      const f3 A = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.x : 0u);
-      const f3 Bv = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.y : 0u);
-      const f3 C = *at<WIDE>((const f3*)verts, ok ? (unsigned)idx.z : 0u);
-      sc_one r;
-      r.cnt = 0; r.a0 = 0;
-      if (ok) r = sc_record_into<false>(S.q0, S.q1, S.q2, lane, f, A, Bv, C, ox, oy, oz, P, nullptr, nullptr);
-      unsigned inc = (unsigned)r.cnt;  // inclusive scan over the wave (sc_prefix's DPP sequence)
-      asm volatile(
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-          "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-          "s_nop 1"
-          : "+v"(inc));
-      const int chunk = __builtin_amdgcn_readlane((int)inc, 63);
-      S.pre[lane] = ((unsigned)(run + (int)inc - r.cnt) << 13) | r.a0;
-      if (lane == 0) S.pre[64] = (unsigned)(run + chunk) << 13;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's LDS writes before its LDS reads below
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      sc_round_robin<COUNT, WIDE, 64, 64>(S.pre, S.q0, S.q1, S.q2, P, grid, sdirs, cell, first + jb, max(sl.y, run),
-                                          min(c_end, run + chunk), lane, ox, oy, oz, n_tests, n_cand);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and its reads before the next chunk's writes
-      __builtin_amdgcn_wave_barrier();
-      run += chunk;
-    }
-  }
   // A big triangle is shared by up to LT_SC_PARTS waves (a ground triangle under the sensor of a low-poly
   // scene covers tens of thousands of bins): work item v = (triangle q, part p); every wave of a triangle
   // recomputes its bounds, part p takes the candidates p*64 + lane, stride 64 * (parts this triangle needs).
@@ -1142,7 +1096,7 @@ static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) 
     }
     const size_t cap = (size_t)n_faces + n_faces / 4 + 1024;
     LT_HIP(hipMalloc((void**)&s->sc_large, cap * sizeof(int)));
-    LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int4)));
+    LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int2)));
     s->sc_cap_queue = (int)cap;
   }
   return LT_OK;
