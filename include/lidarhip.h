@@ -406,6 +406,17 @@ int lt_fusion_scan_dev(lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* 
                        float* endpoints, int* endcolors, float* range, float* endrem, int* tri, unsigned trace_flags,
                        void* stream, int sync);
 
+/* The same from the POINT CLOUDS of the source scans (MultiSemLaserScan.deform's mesh branch, laserscan.py:874-914, in one
+ * call): do_range_projection_new(fov, remove=True) + do_label_projection_new per cloud (lt_range_projection_batch_dev, into
+ * images the projector owns) -> lt_fusion_scan_dev.  fov_up / fov_down (degrees) and H x W are the SOURCE sensor's, i.e. the
+ * volume's; clouds / is_f64 / beam_angles as for lt_range_projection_batch_dev; the rest as for lt_fusion_scan_dev.  At most
+ * 64 clouds. */
+int lt_deform_scan_dev(lt_projector* projector, lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* rayset,
+                       int n_clouds, const lt_cloud* clouds, int is_f64, double fov_up, double fov_down, int H, int W,
+                       const double* beam_angles, int n_beams, float obs_weight, unsigned tsdf_flags, const float* origin,
+                       float* endpoints, int* endcolors, float* range, float* endrem, int* tri, unsigned trace_flags,
+                       void* stream, int sync);
+
 /* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
 
 /* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new

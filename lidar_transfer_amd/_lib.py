@@ -31,7 +31,7 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_fusion_scan_dev", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
            "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free", "lt_projector_create",
            "lt_projector_destroy", "lt_range_projection_batch_dev", "lt_mesh_set_case_table",
-           "lt_tsdf_integrate_multi_dev"]
+           "lt_tsdf_integrate_multi_dev", "lt_deform_scan_dev"]
 
 
 class Stats(C.Structure):
@@ -174,6 +174,9 @@ def load():
     lib.lt_range_projection_batch_dev.argtypes = [vp, C.c_int, C.POINTER(Cloud), C.c_int, C.c_double, C.c_double, C.c_int,
                                                   C.c_int, vp, C.c_int, C.c_uint, vp, C.c_int, C.POINTER(ProjImages),
                                                   C.c_float, C.c_float, C.c_float, vp]
+    lib.lt_deform_scan_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(Cloud), C.c_int, C.c_double, C.c_double, C.c_int,
+                                       C.c_int, vp, C.c_int, C.c_float, C.c_uint, fp, vp, vp, vp, vp, vp, C.c_uint, vp, C.c_int]
+    lib.lt_deform_scan_dev.restype = C.c_int
     for name in ("lt_projector_create", "lt_projector_destroy", "lt_range_projection_batch_dev"):
         getattr(lib, name).restype = C.c_int
     _lib = lib

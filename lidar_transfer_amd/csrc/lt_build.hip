@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void k_morton(const float* __restrict__ verts,
 // ---- LSD radix sort: 3 passes of 10-bit digits over the 30-bit Morton key --------------------------------
 // One workgroup owns LT_SORT_TILE consecutive keys per pass.  hist is digit-major: hist[d * nb + b],
 // followed by the LT_RD digit totals.
-#define LT_RB 10
+#ifndef LT_RB
+#define LT_RB 10   // digit width of the LSD radix sort (A/B: -DLT_RB=8 -> four passes of 256 digits)
+#endif
 #define LT_RD (1 << LT_RB)
 #define LT_DPT (LT_RD / LT_SORT_THREADS)  // digits owned per thread (4)
 

@@ -564,6 +564,8 @@ struct lt_projector {
   double* beams = nullptr;                  // [1024]
   double beams_host[1024];
   int n_beams_cached = -1;
+  float* img = nullptr;                     // lt_deform_scan_dev: [n][3][H * W] source images (range, remission, folded label)
+  size_t img_cap = 0;                       // floats
   std::mutex mu;
 };
 
@@ -673,6 +675,7 @@ extern "C" int lt_projector_destroy(lt_projector* p) {
   pj_free(p);
   if (p->meta) (void)hipFree(p->meta);
   if (p->beams) (void)hipFree(p->beams);
+  if (p->img) (void)hipFree(p->img);
   delete p;
   return LT_OK;
 }
@@ -736,6 +739,45 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
   p->armed = true;  // k_pb_resolve re-armed every cell it looked at
   if (old_f64) p->dmin_armed = true;
   return LT_OK;
+}
+
+// One output scan of the `mesh` adaption FROM POINT CLOUDS in one call (see include/lidarhip.h): projection of the source
+// scans into images the projector owns, then lt_fusion_scan_dev on them.  One native call per output scan keeps a host
+// thread's share at a few microseconds -- from Python the interpreter lock is released for all of it.
+extern "C" int lt_deform_scan_dev(lt_projector* p, lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* rayset,
+                                  int n_clouds, const lt_cloud* clouds, int is_f64, double fov_up, double fov_down, int H,
+                                  int W, const double* beam_angles, int n_beams, float obs_weight, unsigned tsdf_flags,
+                                  const float* origin, float* endpoints, int* endcolors, float* range, float* endrem,
+                                  int* tri, unsigned trace_flags, void* stream, int sync) {
+  if (!p || n_clouds < 0 || n_clouds > 64 || H <= 0 || W <= 0) {
+    lt_set_error("lt_deform_scan_dev: invalid argument (n_clouds=%d H=%d W=%d)", n_clouds, H, W);
+    return LT_ERR_INVALID_ARG;
+  }
+  const size_t cells = (size_t)H * W, need = (size_t)(n_clouds > 0 ? n_clouds : 1) * 3 * cells;
+  {
+    std::lock_guard<std::mutex> lock(p->mu);
+    LT_HIP(hipSetDevice(p->device));
+    if (need > p->img_cap) {
+      if (p->img) { LT_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(p->img); p->img = nullptr; p->img_cap = 0; }
+      LT_HIP(hipMalloc((void**)&p->img, need * sizeof(float)));
+      p->img_cap = need;
+    }
+  }
+  lt_proj_images out[64];
+  const float* color_ims[64];
+  const float* depth_ims[64];
+  const float* rem_ims[64];
+  memset(out, 0, sizeof(out));
+  for (int k = 0; k < n_clouds; ++k) {
+    float* base = p->img + (size_t)k * 3 * cells;
+    out[k].range = base; out[k].rem = base + cells; out[k].label_folded = base + 2 * cells;
+    depth_ims[k] = base; rem_ims[k] = base + cells; color_ims[k] = base + 2 * cells;
+  }
+  // do_range_projection_new(fov, remove=True) + do_label_projection_new per source scan (laserscan.py:874-881)
+  LT_CHECK(lt_range_projection_batch_dev(p, n_clouds, clouds, is_f64, fov_up, fov_down, H, W, beam_angles, n_beams,
+                                         LT_PROJ_NEW | LT_PROJ_REMOVE, nullptr, 0, out, 0.0f, -1.0f, 0.0f, stream));
+  return lt_fusion_scan_dev(vol, mesh, scene, rayset, n_clouds, color_ims, depth_ims, rem_ims, H, W, obs_weight, tsdf_flags,
+                            origin, endpoints, endcolors, range, endrem, tri, trace_flags, stream, sync);
 }
 
 // Host-pointer convenience: stages everything through device buffers, same semantics.

@@ -724,6 +724,7 @@ struct sc_batch {
   int n;
   int tris_blocks, resolve_blocks;  // grid sizes
   int cap;                          // LT_SC_CAP_SINGLE / LT_SC_CAP_BATCH
+  int rest_blocks;                  // workgroups of k_sc_rest per scan
   // first workgroup of every scan in k_sc_tris / k_sc_resolve (INT_MAX beyond n).  Side by side at the head of the
   // argument block: a workgroup finds its scan with ONE scalar load + compares -- walking job[k].tris_block0 was a
   // chain of up to seven dependent scalar loads before the first vector load of the workgroup could be issued
@@ -802,13 +803,17 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
 // the same group -- to make deferring cheap and the batch cap low: bit-identical, but a single-scan k_sc_rest took 15-20 us
 // instead of 10 (a wave's slice is a serial chain of two gathers, the bounds and eight rounds of 64 candidates), and lower
 // batch caps did not pay either: deferred work is conserved, not saved.  DESIGN.md section 5d, profiles/r04.)
-#define LT_SC_REST_BLOCKS 512
+#define LT_SC_REST_BLOCKS 512        // single-scan call
+#define LT_SC_REST_BLOCKS_BATCH 128  // per scan of a batch call: its queues are all but empty (cap 8192), and 4096 workgroups that only look at
+                                    // two counters still wait for slots behind the other batches' k_sc_tris: 512 / 128 / 64 / 32 -> 10.79 / 10.93 / 10.93 /
+                                    // 10.96 Grays/s (profiles/r04/rest_blocks.txt); 128 keeps headroom for scenes that do queue
 #define LT_SC_PARTS 8
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   __shared__ sc_shared S;
-  const sc_job& J = B.job[blockIdx.x / LT_SC_REST_BLOCKS];
-  const int rb = blockIdx.x % LT_SC_REST_BLOCKS;
+  const int rest_blocks = B.rest_blocks;  // workgroups per scan (grid-stride loops below: any number works)
+  const sc_job& J = B.job[blockIdx.x / rest_blocks];
+  const int rb = blockIdx.x % rest_blocks;
   if (J.n_faces <= 0) return;
   const float* __restrict__ verts = J.verts;
   const int* __restrict__ faces = J.faces;
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
   const int n_large = J.large_count[0], n_slices = min(J.large_count[1], J.cap_slices);
   if (COUNT && rb == 0 && threadIdx.x == 0) J.counters[3] = (unsigned long long)n_large | ((unsigned long long)n_slices << 32);
   unsigned n_tests = 0, n_cand = 0;
-  for (int q = rb; q < n_slices; q += LT_SC_REST_BLOCKS) {
+  for (int q = rb; q < n_slices; q += rest_blocks) {
     const int2 sl = J.slices[q];
     const int first = sl.x * LT_SC_T;
     sc_one rA, rB;
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
     __syncthreads();  // LDS is reused by the next slice
   }
   const int lane = threadIdx.x & 63;
-  const int wave0 = rb * 4 + (threadIdx.x >> 6), nwaves = LT_SC_REST_BLOCKS * 4;
+  const int wave0 = rb * 4 + (threadIdx.x >> 6), nwaves = rest_blocks * 4;
   // A big triangle is shared by up to LT_SC_PARTS waves (a ground triangle under the sensor of a low-poly
   // scene covers tens of thousands of bins): work item v = (triangle q, part p); every wave of a triangle
   // recomputes its bounds, part p takes the candidates p*64 + lane, stride 64 * (parts this triangle needs).
@@ -1154,6 +1159,11 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     return e ? atoi(e) : 0;
   }();
   B.cap = env_cap > 0 ? env_cap : (n_items > 1 ? LT_SC_CAP_BATCH : LT_SC_CAP_SINGLE);
+  static const int env_rest = []() {
+    const char* e = getenv("LIDARHIP_SC_REST_BLOCKS");
+    return e ? atoi(e) : 0;
+  }();
+  B.rest_blocks = env_rest > 0 ? env_rest : (n_items > 1 ? LT_SC_REST_BLOCKS_BATCH : LT_SC_REST_BLOCKS);
   const dim3 b(256);
 #define SC_LAUNCH(KERNEL, GRID) \
   do { \
@@ -1169,7 +1179,7 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
       if (probe->probe[1]) LT_HIP(hipEventRecord(probe->probe[1], stream));
       probe->probe[0] = probe->probe[1] = nullptr;
     }
-    SC_LAUNCH(k_sc_rest, dim3(B.n * LT_SC_REST_BLOCKS));
+    SC_LAUNCH(k_sc_rest, dim3(B.n * B.rest_blocks));
   }
 #undef SC_LAUNCH
   if (count) hipLaunchKernelGGL(k_sc_resolve<true>, dim3(rb), b, 0, stream, B);

@@ -308,7 +308,7 @@ class FusionScanPipeline:
     (``lt_fusion_scan_dev``) on its chain's thread, so the interpreter lock is free while the GPU works."""
 
     def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, rays, H, chains=3, device=None, merge=True,
-                 label_image=False):
+                 label_image=False, source_hw=None, beam_angles=None):
         import queue
         import threading
         import weakref
@@ -328,10 +328,18 @@ class FusionScanPipeline:
         self.label_image = bool(label_image)
         self._flags = _lib.LT_TRACE_WRITE_MISSES | (_lib.LT_TRACE_LABEL_IMAGE if label_image else 0)
         self._merge = _lib.LT_TSDF_MERGE if merge else 0
+        # submit_clouds(): the source sensor's image shape (H, W) the clouds are projected into (laserscan.py:874-881); the
+        # field of view is the volume's.  Every chain then owns a Projector (its z-min workspace) as well.
+        self._src_hw = tuple(int(x) for x in source_hw) if source_hw is not None else None
+        self._src_fov = (float(fov_up), float(fov_down))
+        self._beam_angles = sorted(beam_angles) if beam_angles else None
         self._chains = []
         for _ in range(int(chains)):
             ch = dict(vol=TSDFVolume(vol_bnds, voxel_size, fov_up, fov_down, device=idx, merge=merge),
                       mesh=DeviceMesh(idx), scene=Scene(idx), stream=torch.cuda.Stream(self.device), q=queue.Queue())
+            if self._src_hw is not None:
+                from .laserscan import Projector
+                ch["projector"] = Projector(idx)
             # the worker holds a WEAK reference to the pipeline: a bound method as thread target would keep an un-closed
             # pipeline (and its chains' volumes: GBs of HBM each) alive for ever -- __del__ could never run
             ch["thread"] = threading.Thread(target=_fusion_chain_worker, args=(weakref.ref(self), ch["q"]), daemon=True)
@@ -356,6 +364,8 @@ class FusionScanPipeline:
             if out is None:
                 out = ch["scene"].alloc_outputs(self.n_rays, label_image=self.label_image)
             h = w = 0
+            if obs and len(obs[0]) == 4:  # ("clouds", points, rem, label) items: ONE native call (lt_deform_scan_dev)
+                return self._scan_clouds(ch, obs, origin, out)
             for k, (color_im, depth_im, rem_im) in enumerate(obs):
                 # float32 FIRST, then fold RGB into one channel -- the reference's order (fusion_lidar.py:260-264:
                 # color_im.astype(np.float32), then floor(b*256*256 + g*256 + r)); folding in the caller's dtype wraps a
@@ -389,6 +399,44 @@ class FusionScanPipeline:
         res["_done"] = (done, keep, obs)  # (temporaries and observations stay referenced until the event has passed)
         return res
 
+    def _scan_clouds(self, ch, items, origin, out):
+        """projection of the source scans + the fusion chain, one native call on this chain's stream"""
+        torch, lib = self._torch, self._lib
+        st = ch["stream"]
+        n = len(items)
+        cl = (_lib.Cloud * n)()
+        keep = []
+        dt = items[0][1].dtype
+        for k, (_, pts, rem, lab) in enumerate(items):
+            if pts.dtype != dt or dt not in (torch.float32, torch.float64):
+                raise TypeError("clouds: float32 or float64 points, one dtype per output scan")
+            pts = pts.contiguous()
+            rem = rem.contiguous() if rem.dtype == torch.float32 else rem.to(torch.float32).contiguous()
+            lab = lab.contiguous() if lab.dtype == torch.int32 else lab.to(torch.int32).contiguous()
+            keep += [pts, rem, lab]
+            cl[k].points, cl[k].rem, cl[k].label, cl[k].n = pts.data_ptr(), rem.data_ptr(), lab.data_ptr(), int(pts.shape[0])
+        beams = None
+        if self._beam_angles:
+            import numpy as np
+            beams = np.ascontiguousarray(self._beam_angles, dtype=np.float64)
+        org = (C.c_float * 3)(*[float(x) for x in origin])
+
+        def p(key):
+            a = out.get(key)
+            return a.data_ptr() if a is not None else None
+        _lib.check(lib.lt_deform_scan_dev(ch["projector"]._h, ch["vol"]._h, ch["mesh"]._h, ch["scene"]._h, self.rayset._h, n, cl,
+                                          int(dt == torch.float64), self._src_fov[0], self._src_fov[1], self._src_hw[0],
+                                          self._src_hw[1], beams.ctypes.data_as(C.c_void_p) if beams is not None else None,
+                                          0 if beams is None else len(beams), 1.0, self._merge, org, p("endpoints"),
+                                          p("endcolors"), p("range"), p("endrem"), p("tri"), self._flags,
+                                          C.c_void_p(st.cuda_stream), 0), "lt_deform_scan_dev")
+        done = torch.cuda.Event()
+        done.record(st)
+        res = dict(out)
+        res["n_verts"], res["n_faces"] = ch["mesh"].n_verts, ch["mesh"].n_faces
+        res["_done"] = (done, keep, items)
+        return res
+
     def _run_job(self, ch, job):
         ticket, obs, origin, out = job
         try:
@@ -413,6 +461,11 @@ class FusionScanPipeline:
         for o in obs:
             if len(o) != 3 or not all(isinstance(a, torch.Tensor) and a.is_cuda for a in o):
                 raise ValueError("observations: (color_im, depth_im, rem_im) CUDA tensors")
+        return self._submit(obs, origin, out, inputs_ready)
+
+    def _submit(self, obs, origin, out, inputs_ready):
+        import threading
+        torch = self._torch
         if not inputs_ready:
             torch.cuda.current_stream(self.device).synchronize()  # (see the class docstring)
         with self._lock:
@@ -421,6 +474,21 @@ class FusionScanPipeline:
             self._done[t] = threading.Event()
         self._chains[t % len(self._chains)]["q"].put((t, obs, tuple(origin), out))
         return t
+
+    def submit_clouds(self, clouds, origin=(0.0, 0.0, 0.0), out=None, inputs_ready=False):
+        """Queue one output scan from the POINT CLOUDS of its source scans: ``clouds`` = ``(points [n,3] f32|f64, remissions
+        [n] f32, label [n] i32)`` CUDA tensors per source scan, in the primary scan's frame (laserscan.py:876-879).  The
+        chain projects them (``lt_range_projection_batch_dev``, one launch sequence, nothing read back) and runs the fusion
+        chain on the images -- ``deform('mesh')`` without ``write``; needs ``source_hw`` at construction."""
+        torch = self._torch
+        if self._src_hw is None:
+            raise RuntimeError("FusionScanPipeline.submit_clouds: construct with source_hw=(H, W)")
+        items = []
+        for c in clouds:
+            if len(c) != 3 or not isinstance(c[0], torch.Tensor) or not c[0].is_cuda:
+                raise ValueError("clouds: (points, remissions, label) CUDA tensors")
+            items.append(("clouds", c[0], c[1], c[2]))
+        return self._submit(items, origin, out, inputs_ready)
 
     def wait(self, ticket):
         """Images of the scan with this ticket (complete when the call returns).  A ticket is handed out once."""
@@ -464,6 +532,8 @@ class FusionScanPipeline:
             ch["mesh"].close()
             ch["scene"].close()
             ch["vol"].close()
+            if ch.get("projector") is not None:
+                ch["projector"].close()
         if getattr(self, "rayset", None) is not None and chains:
             self.rayset.close()
 

@@ -129,3 +129,32 @@ def test_cp_adaption_from_point_clouds_equals_the_step_by_step_api(dtype, pf):
     assert np.array_equal(got["label_file"].cpu().numpy().view(np.uint32), want_lab)
     assert want_bin.shape[0] > 500
     dd.close()
+
+
+def test_cloud_pipeline_with_scans_in_flight_equals_the_single_chain():
+    """FusionScanPipeline.submit_clouds: output scans in flight on three chains (own projector, volume, mesh, scene, stream
+    and host thread each), each from the point clouds of its three source scans -- the images of every scan bit-equal to
+    DeviceDeform.mesh of the same clouds."""
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    from lidar_transfer_amd.laserscan import create_rays
+    from lidar_transfer_amd.pipeline import FusionScanPipeline
+    H, W, fu, fd = SRC
+    tH, tW, tfu, tfd = TGT
+    jobs = [_dev(_source_scans(3, np.float64, seed=s)) for s in (5, 9, 13)]
+    dd = DeviceDeform(SRC, TGT, BNDS, VOXEL)
+    want = []
+    for cl in jobs:
+        o = dd.mesh(cl, pack=False)
+        torch.cuda.synchronize()
+        want.append((o["range"].clone(), o["label"].clone(), o["n_faces"]))
+    dd.close()
+    rays = torch.from_numpy(create_rays(tfu, tfd, tH, tW)).cuda()
+    with FusionScanPipeline(BNDS, VOXEL, fu, fd, rays, tH, chains=3, label_image=True, source_hw=(H, W)) as pipe:
+        tickets = [pipe.submit_clouds(jobs[k % 3]) for k in range(9)]
+        for k, t in enumerate(tickets):
+            got = pipe.wait(t)
+            r, l, nf = want[k % 3]
+            assert got["n_faces"] == nf
+            assert torch.equal(got["range"].view(torch.int32), r.reshape(-1).view(torch.int32))
+            assert torch.equal(got["endcolors"], l.reshape(-1))
