@@ -294,7 +294,7 @@ def main():
     H, W = wl["H"], wl["W"]
     R = H * W
     S = max(1, args.streams)
-    args.batch = min(max(1, args.batch), 8)  # lt_scene_render_batch_dev takes at most 8 scans
+    args.batch = min(max(1, args.batch), int(os.environ.get("LT_BENCH_MAX_BATCH", "8")))  # lt_scene_render_batch_dev takes at most 8 scans
     S = (S + args.batch - 1) // args.batch * args.batch  # whole batches of workers
     # A STEP = one pass of the hot path over one batch of input = `--batch` scans, each with its own new mesh (one
     # lt_scene_render_batch_dev call for the scatter strategy).  Everything below counts scans: K timed, Wm untimed.

@@ -709,7 +709,9 @@ __device__ __forceinline__ void sc_count(unsigned n_tests, unsigned n_cand, unsi
 // between kernels than the kernels need.  Every kernel below therefore takes a BATCH of
 // scans: the per-scan arguments live in a job table passed by value (kernel arguments: scalar registers), and a
 // workgroup looks up its scan from its block index.  A batch of one is the single-scan API.
+#ifndef LT_SC_MAX_BATCH
 #define LT_SC_MAX_BATCH 8
+#endif
 struct sc_job {
   const float* verts; const int* faces; const int* colors; const float* rem;  // the scan's mesh
   rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
