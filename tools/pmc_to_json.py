@@ -81,6 +81,10 @@ def main():
             f = sum(r[1] * r[2] for r in rs) / n
             w = sum(r[1] * r[3] for r in rs) / n
             spl = ratio if STRATEGY_OF[kern] == "scatter" else 1
+            # k_sc_rest's grid is not proportional to the scans it holds (512 workgroups for a single-scan call, 128 per scan
+            # of a batch call since round 4): every launch above the smallest grid is a batch launch
+            if kern == "k_sc_rest" and ratio > 1:
+                spl = a.batch
             e = {"kernel": kern, "scans_per_launch": spl, "launches": n,
                  "grid_size_mean": int(sum(r[0] * r[1] for r in rs) / n), "fetch_kib": round(f, 1),
                  "write_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
