@@ -153,6 +153,21 @@ class DeviceDeform:
                                                            o["idx"].view(-1), self.n_rays, st)
         return res
 
+    @staticmethod
+    def write(out, out_dir, idx):
+        """``MultiSemLaserScan.write(out_dir, idx)`` (laserscan.py:1162-1178) for a result of :meth:`mesh` / :meth:`cp` that
+        was packed: ``velodyne/NNNNNN.bin`` ([N,4] float32 x, y, z, remission) and ``labels/NNNNNN.label`` ([N] uint32) --
+        the bytes the reference's per-point ``struct.pack`` loops write.  Returns the number of points."""
+        import os
+        if "bin" not in out or "label_file" not in out:
+            raise ValueError("DeviceDeform.write: the result was produced with pack=False")
+        os.makedirs(os.path.join(out_dir, "velodyne"), exist_ok=True)
+        os.makedirs(os.path.join(out_dir, "labels"), exist_ok=True)
+        b = out["bin"].cpu().numpy()
+        b.tofile(os.path.join(out_dir, "velodyne", str(idx).zfill(6) + ".bin"))
+        out["label_file"].cpu().numpy().view("uint32").tofile(os.path.join(out_dir, "labels", str(idx).zfill(6) + ".label"))
+        return int(b.shape[0])
+
     def close(self):
         for name in ("rayset", "scene", "mesh_obj", "vol", "projector"):
             obj = getattr(self, name, None)

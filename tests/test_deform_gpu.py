@@ -128,6 +128,13 @@ def test_cp_adaption_from_point_clouds_equals_the_step_by_step_api(dtype, pf):
     assert np.array_equal(got["bin"].cpu().numpy().view(np.uint8), want_bin.view(np.uint8))
     assert np.array_equal(got["label_file"].cpu().numpy().view(np.uint32), want_lab)
     assert want_bin.shape[0] > 500
+    # write(): the files of laserscan.py:1162-1178
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        n = dd.write(got, d, 7)
+        assert n == want_bin.shape[0]
+        assert np.fromfile(os.path.join(d, "velodyne", "000007.bin"), np.uint8).tobytes() == want_bin.tobytes()
+        assert np.fromfile(os.path.join(d, "labels", "000007.label"), np.uint8).tobytes() == want_lab.tobytes()
     dd.close()
 
 
