@@ -10,9 +10,11 @@
 //   0            (`merge == false`, :178-205) plain running average incl. per-channel colour average
 // The arithmetic follows the CUDA source expression by expression (float unless the source promotes to
 // double through the PI / 1.0 literals); `a + b * c` patterns are written as fused multiply-adds because
-// nvcc contracts them by default (-fmad=true).  CUDA's norm3df / atan2f / asinf are not available bit for bit
-// on any other platform: voxels whose projection falls within an ulp of a pixel or field-of-view boundary
-// may land differently -- tests bound that fraction.
+// nvcc contracts them by default (-fmad=true).  norm3df / atan2f / asinf are the device library's -- exactly what
+// the reference's own kernel source gets when hipcc compiles it for gfx950 (oracle/build_ref_tsdf.py ->
+// oracle/_ref/libref_tsdf_integrate.so): tests/test_tsdf_ref_kernel_gpu.py runs that build next to these kernels and
+// finds all four volumes bit-identical.  (CUDA's own last-ulp behaviour of the three functions exists on no other
+// platform; against a CUDA run voxels within an ulp of a pixel / field-of-view / truncation boundary may land differently.)
 //
 // The kernel is the reference's arithmetic, voxel by voxel; what is NOT the reference's is the amount of work spent
 // on voxels that cannot change -- 800 M voxels at the default volume, of which one observation updates a few per cent:
@@ -20,7 +22,8 @@
 //     dim_z voxels with the very expressions of the kernel (atan2f and the double-precision proj_x: the costly part),
 //     and marks a column DEAD when even its nearest possible depth sqrt(x^2 + y^2) lies more than the truncation
 //     margin behind the largest depth of that image column -- every voxel of it takes the kernel's
-//     `depth_diff < -trunc_margin` exit (float subtraction, fma and sqrt are monotonic, so the implication is exact);
+//     `depth_diff < -trunc_margin` exit (float subtraction is monotonic and the test leaves four ulp of room for the
+//     rounding of norm3df, so the implication holds);
 //   * a conservative sine test (|margin| 1e-5, far above asinf's error) drops voxels clearly outside the vertical
 //     field of view before asinf; the band around the limits takes the exact path;
 //   * columns written since the last reset are stamped with the volume's epoch: reset re-initialises those only, and
@@ -151,15 +154,33 @@ __global__ __launch_bounds__(256) void k_tsdf_dct(const float* __restrict__ dept
 // column's share of the per-voxel expressions is computed once: the two IEEE divisions, two fused multiply-adds, the
 // product and the table look-up were a quarter of the vector instructions of the column walk
 // (SQ_ACTIVE_INST_VALU: 71 % of its time; 439 -> 352 us on the default volume).
+// Columns on the sensor's vertical axis: norm3df(x, y, z) < |z| needs x^2 + y^2 below the rounding of z^2 and of the
+// 1-ulp square root, i.e. rho < 6e-4 |z|; columns with rho <= LT_AXIS_RHO * (largest |pt_z| of the volume) are taken out
+// of every candidate shortcut (whole z range, every voxel through the exact expressions).  A handful of columns at most.
+#define LT_AXIS_RHO 1e-3f
+__device__ __forceinline__ float axis_rho_limit(float oz, float voxel_size, int dim_z) {
+  return LT_AXIS_RHO * fmaxf(fabsf(oz), fabsf(__fmaf_rn((float)(dim_z - 1), voxel_size, oz)));
+}
+
 struct col_plain {
   bool plain;
   int px;      // colinfo[cx * dim_y + cy]
-  float rho2;  // fma(pt_y, pt_y, pt_x * pt_x)
+  float rho2;  // fma(pt_y, pt_y, pt_x * pt_x): the conservative candidate tests work on it
+  int col;     // cx * dim_y + cy: the exact evaluation takes pt_x, pt_y from it (col_xy)
 };
+// (pt_x, pt_y) of table column `col` -- the kernel's `vol_origin + voxel * voxel_size` on voxel_x = cx, voxel_y = cy (:101-103)
+__device__ __forceinline__ void col_xy(int col, int dim_y, float voxel_size, float ox, float oy, float& pt_x, float& pt_y) {
+  int cx = (int)((float)col * __builtin_amdgcn_rcpf((float)dim_y));  // (within one of col / dim_y for dim_x < 2^21)
+  int cy = col - cx * dim_y;
+  if (cy < 0) { cx -= 1; cy += dim_y; }
+  if (cy >= dim_y) { cx += 1; cy -= dim_y; }
+  pt_x = __fmaf_rn((float)cx, voxel_size, ox);
+  pt_y = __fmaf_rn((float)cy, voxel_size, oy);
+}
 __device__ __forceinline__ col_plain col_plain_of(int cx, int cy, int z0, int z1, int vol_dim_y, int vol_dim_z, float ox,
                                                   float oy, float voxel_size, const int* __restrict__ colinfo) {
   col_plain C;
-  C.plain = false; C.px = -2; C.rho2 = 0.f;
+  C.plain = false; C.px = -2; C.rho2 = 0.f; C.col = 0;
   if (z1 <= z0) return C;
   const int cc = cx * vol_dim_y + cy;
   const int i0 = cc * vol_dim_z + z0, i1 = cc * vol_dim_z + z1 - 1;
@@ -172,6 +193,7 @@ __device__ __forceinline__ col_plain col_plain_of(int cx, int cy, int z0, int z1
   C.plain = true;
   C.px = px;
   C.rho2 = __fmaf_rn(pt_y, pt_y, pt_x * pt_x);
+  C.col = cc;
   return C;
 }
 
@@ -184,12 +206,12 @@ __device__ __forceinline__ int tsdf_voxel(
     const float* __restrict__ rem_im, const int* __restrict__ colinfo, unsigned* __restrict__ col_epoch,
     unsigned epoch, bool fresh, const col_plain& C, int z_plain, const float2* __restrict__ dct, int want_py = -1) {
   int px = -2;
-  float rho2, pt_z;
+  float pt_x, pt_y, pt_z;
   if (C.plain) {
     // the reference's float decomposition of every voxel index of this walk gives (cx, cy, z) (see col_plain): the
     // column's share of the expressions below comes from the caller
     px = C.px;
-    rho2 = C.rho2;
+    col_xy(C.col, vol_dim_y, voxel_size, ox, oy, pt_x, pt_y);
     pt_z = __fmaf_rn((float)z_plain, voxel_size, oz);
   } else {
     // voxel grid coordinates -- float division exactly as the reference (:95-98); beyond 2^24 voxels (float)voxel_idx
@@ -204,10 +226,9 @@ __device__ __forceinline__ int tsdf_voxel(
       if (px == -1) return 0;
       if (px >= 0) px &= 0x3FFFFFFF;  // (the wedge table's per-column image column carries a flag bit: LT_WD_QUIRK_FLAG)
     }
-    const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
-    const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
+    pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
+    pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
     pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
-    rho2 = __fmaf_rn(pt_y, pt_y, pt_x * pt_x);
     if (px < 0) {
       const float yaw = -atan2f(pt_y, pt_x);
       float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
@@ -218,9 +239,12 @@ __device__ __forceinline__ int tsdf_voxel(
     }
   }
   const float fov = fabsf(fov_up) + fabsf(fov_down);
-  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, rho2));  // norm3df
+  const float depth = norm3df(pt_x, pt_y, pt_z);  // the device library's, as the reference's source gets it (header note)
   const float s = pt_z / depth;
-  if (s > sin_up_hi || s < sin_down_lo) return 0;  // clearly outside the vertical field of view (NaN passes on)
+  // clearly outside the vertical field of view (NaN passes on -- and so does |s| > 1: on the sensor's axis the device
+  // library's norm3df, a 1-ulp square root, can return less than |pt_z|; asinf is then NaN, no comparison of the
+  // reference holds and the voxel IS written through pixel row 0 -- LT_AXIS_RHO)
+  if ((s > sin_up_hi || s < sin_down_lo) && fabsf(s) <= 1.0f) return 0;
   const float pitch = asinf(s);
   if (pitch > fov_up || pitch < fov_down) return 0;
   float proj_y = (float)(1.0 - (double)((pitch + fabsf(fov_down)) / fov));
@@ -257,7 +281,8 @@ __device__ __forceinline__ bool tsdf_band_candidate(int z, const col_plain& C, f
   // their loads in flight together)
   const float pt_z = __fmaf_rn((float)z, voxel_size, oz);
   const float d2 = __fmaf_rn(pt_z, pt_z, C.rho2);
-  const bool odd = !(d2 > 0.f && d2 < 1e30f);  // the voxel at the sensor, NaN, overflow: the exact path decides
+  // the voxel at the sensor, NaN, overflow, a voxel on the sensor's axis (rho < 2e-3 |z|, LT_AXIS_RHO): the exact path decides
+  const bool odd = !(d2 > 0.f && d2 < 1e30f) || C.rho2 <= 4e-6f * d2;
   const float rinv = __builtin_amdgcn_rsqf(d2);
   const float s = pt_z * rinv, depth = d2 * rinv;
   const bool in_fov = !(s > sin_up_hi + 1e-4f || s < sin_down_lo - 1e-4f);  // (with margin)
@@ -291,9 +316,9 @@ struct col_geom {
 __device__ __forceinline__ void col_zrange(const col_geom& G, int cx, int cy, int& z0, int& z1) {
   z0 = 0;
   z1 = G.dim_z;
-  if (cy != G.dim_y - 1 && G.tan_ok) {
-    const float pt_x = __fmaf_rn((float)cx, G.voxel_size, G.ox), pt_y = __fmaf_rn((float)cy, G.voxel_size, G.oy);
-    const float rho = sqrtf(pt_x * pt_x + pt_y * pt_y);
+  const float pt_x = __fmaf_rn((float)cx, G.voxel_size, G.ox), pt_y = __fmaf_rn((float)cy, G.voxel_size, G.oy);
+  const float rho = sqrtf(pt_x * pt_x + pt_y * pt_y);
+  if (cy != G.dim_y - 1 && G.tan_ok && rho > axis_rho_limit(G.oz, G.voxel_size, G.dim_z)) {  // (LT_AXIS_RHO: whole column)
     const float pad = 2.0f * G.voxel_size + 1e-3f * rho;
     const float zl = (rho * G.tan_down - pad - G.oz) / G.voxel_size, zh = (rho * G.tan_up + pad - G.oz) / G.voxel_size;
     z0 = max(0, (int)floorf(fminf(fmaxf(zl, -1.0f), (float)G.dim_z)));
@@ -325,12 +350,15 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
   int px = (int)floorf(proj_x);
   px = min(im_w - 1, px);
   px = max(0, px);
-  // every voxel of the column has depth = sqrtf(fma(z, z, fma(y, y, x * x))) >= rho (fma and sqrtf are monotonic), so
-  // depth_value - depth <= colmax - rho for every non-zero pixel: if that is already < -trunc_margin the column is dead.
+  // every voxel of the column has depth = norm3df(x, y, z) >= rho_lo: the true norm is >= the true sqrt(x^2 + y^2), the
+  // device library's norm3df is within an ulp of the one and rho within an ulp of the other, and rho_lo sits four ulp
+  // below rho.  Float subtraction is monotonic, so depth_value - depth <= colmax - rho_lo for every non-zero pixel: if that
+  // is already < -trunc_margin the column is dead.
   // A column without a non-zero pixel has colmax = -inf (every voxel leaves at `depth_value == 0`): dead by the same test.
   const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
+  const float rho_lo = rho * 0.9999995f;
   const float cm = colmax[px];
-  const bool dead = (cm - rho) < -trunc_margin;
+  const bool dead = (cm - rho_lo) < -trunc_margin;
   // -2: a dead column with y = dim_y - 1 -- walked all the same, voxel by voxel (the reference's float index can put
   // voxels of the (x + 1, -1) "column" there), each finding its own px
   const int info = dead ? (y == vol_dim_y - 1 ? -2 : -1) : px;
@@ -390,7 +418,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
       const int e = qn - n + lane;
       const int col = q_col[wv][e], z = q_z[wv][e];
       col_plain Cq;
-      Cq.plain = true; Cq.px = q_px[wv][e]; Cq.rho2 = q_rho2[wv][e];
+      Cq.plain = true; Cq.px = q_px[wv][e]; Cq.rho2 = q_rho2[wv][e]; Cq.col = col;
       const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x,
                                          vol_dim_y, vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight,
                                          fov_up, fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, colinfo,
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
       if ((quad & 3) != wv) continue;  // (another wave of the workgroup)
       int z0 = 0, z1 = 0, cc = 0;
       col_plain C;
-      C.plain = false; C.px = -2; C.rho2 = 0.f;
+      C.plain = false; C.px = -2; C.rho2 = 0.f; C.col = 0;
       const bool fresh = bit >= 0 && !((wm >> bit) & 1ull);
       if (bit >= 0) {
         cc = chunk * 64 + bit;
@@ -436,6 +464,7 @@ __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
         C.plain = (zz >> 31) != 0u;
         C.px = colinfo[cc];
         C.rho2 = colrho2[cc];
+        C.col = cc;
       }
       int wz_lo = 0x7fff, wz_hi = -1;  // z range this launch writes in the column (any field; uniform over the group)
       // (uniform trip count over the wave: the ballots below need every lane)
@@ -634,9 +663,9 @@ __global__ __launch_bounds__(256) void k_wd_keys(wd_geom G, uint32_t* __restrict
   const float dyz = (float)(G.dim_y * G.dim_z);
   const int i0 = c * G.dim_z, i1 = c * G.dim_z + G.dim_z - 1;
   const bool plain = floorf(((float)i0) / dyz) == (float)x && floorf(((float)i1) / dyz) == (float)x;
-  const bool quirk = !plain || y == G.dim_y - 1;
-  wd_px[c] = px | (quirk ? LT_WD_QUIRK_FLAG : 0);
   const float rho = sqrtf(__fmaf_rn(pt_y, pt_y, pt_x * pt_x));
+  const bool quirk = !plain || y == G.dim_y - 1 || rho <= axis_rho_limit(G.oz, G.vs, G.dim_z);
+  wd_px[c] = px | (quirk ? LT_WD_QUIRK_FLAG : 0);
   const unsigned qmax = (1u << G.rho_bits) - 2u;  // (all-ones is left to LT_WD_QUIRK_KEY)
   const unsigned q = (unsigned)fminf(rho * G.qscale, (float)qmax);
   keys[c] = quirk ? LT_WD_QUIRK_KEY : (((unsigned)px << G.rho_bits) | q);
@@ -920,7 +949,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
         bool mine = true;
         if (sflag & 0x40000000) mine = z < LT_ZW_LO(zw_snap[col]) || z > LT_ZW_HI(zw_snap[n_cols_all + col]);
         col_plain Cq;
-        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl]; Cq.col = col;
 #ifdef LT_PIX_NO_EVAL  // timing experiment: everything but the evaluation (nothing is written)
         mine = false;
 #endif
@@ -1057,10 +1086,10 @@ __device__ __forceinline__ int tsdf_voxel_multi(
     float sin_up_hi, float sin_down_lo, const int* __restrict__ colinfo, const col_plain& C, int z_plain,
     const float4* __restrict__ obs4, int n_obs, int want_py = -1) {
   int px = -2;
-  float rho2, pt_z;
+  float pt_x, pt_y, pt_z;
   if (C.plain) {
     px = C.px;
-    rho2 = C.rho2;
+    col_xy(C.col, vol_dim_y, voxel_size, ox, oy, pt_x, pt_y);
     pt_z = __fmaf_rn((float)z_plain, voxel_size, oz);
   } else {
     const float voxel_x = floorf(((float)voxel_idx) / ((float)(vol_dim_y * vol_dim_z)));
@@ -1073,10 +1102,9 @@ __device__ __forceinline__ int tsdf_voxel_multi(
       if (px == -1) return 0;
       if (px >= 0) px &= 0x3FFFFFFF;
     }
-    const float pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
-    const float pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
+    pt_x = __fmaf_rn(voxel_x, voxel_size, ox);
+    pt_y = __fmaf_rn(voxel_y, voxel_size, oy);
     pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
-    rho2 = __fmaf_rn(pt_y, pt_y, pt_x * pt_x);
     if (px < 0) {
       const float yaw = -atan2f(pt_y, pt_x);
       float proj_x = (float)(0.5 * ((double)yaw / LT_PI_D + 1.0));
@@ -1087,9 +1115,9 @@ __device__ __forceinline__ int tsdf_voxel_multi(
     }
   }
   const float fov = fabsf(fov_up) + fabsf(fov_down);
-  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, rho2));  // norm3df
+  const float depth = norm3df(pt_x, pt_y, pt_z);  // the device library's, as the reference's source gets it (header note)
   const float s = pt_z / depth;
-  if (s > sin_up_hi || s < sin_down_lo) return 0;
+  if ((s > sin_up_hi || s < sin_down_lo) && fabsf(s) <= 1.0f) return 0;  // (|s| > 1: see tsdf_voxel)
   const float pitch = asinf(s);
   if (pitch > fov_up || pitch < fov_down) return 0;
   float proj_y = (float)(1.0 - (double)((pitch + fabsf(fov_down)) / fov));
@@ -1333,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix_multi(
         col = c_col[sl]; z = c_z0[sl] + (j - c_pre[sl]);
         bool mine = true;
         col_plain Cq;
-        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl];
+        Cq.plain = true; Cq.px = p_px[sidx]; Cq.rho2 = c_rho2[sl]; Cq.col = col;
 #ifdef LT_PIX_NO_EVAL  // timing experiment: everything but the evaluation (nothing is written)
         mine = false;
 #endif
@@ -1401,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk_multi(
   if (i >= (long long)n_q * vol_dim_z) return;
   const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
   col_plain C;
-  C.plain = false; C.px = -2; C.rho2 = 0.f;
+  C.plain = false; C.px = -2; C.rho2 = 0.f; C.col = 0;
   const int code = tsdf_voxel_multi(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
                                     vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down,
                                     sin_up_hi, sin_down_lo, wd_px, C, z, obs4, n_obs);
@@ -1508,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_written(
         cc = chunk * 64 + sidx;
         z = w_lo[sidx] + (j - w_pre[sidx]);
         col_plain C;
-        C.plain = true; C.px = w_px[sidx]; C.rho2 = w_rho2[sidx];
+        C.plain = true; C.px = w_px[sidx]; C.rho2 = w_rho2[sidx]; C.col = cc;
         code = tsdf_voxel<MERGE>(cc * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y, vol_dim_z,
                                  ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up, fov_down, sin_up_hi,
                                  sin_down_lo, color_im, depth_im, rem_im, wd_px, col_epoch, epoch, false, C, z, dct);
@@ -1560,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_quirk(
   if (i >= (long long)n_q * vol_dim_z) return;
   const int col = (int)qcols[i / vol_dim_z], z = (int)(i % vol_dim_z);
   col_plain C;
-  C.plain = false; C.px = -2; C.rho2 = 0.f;
+  C.plain = false; C.px = -2; C.rho2 = 0.f; C.col = 0;
   const int code = tsdf_voxel<MERGE>(col * vol_dim_z + z, tsdf_vol, weight_vol, color_vol, rem_vol, vol_dim_x, vol_dim_y,
                                      vol_dim_z, ox, oy, oz, voxel_size, im_h, im_w, trunc_margin, obs_weight, fov_up,
                                      fov_down, sin_up_hi, sin_down_lo, color_im, depth_im, rem_im, wd_px, col_epoch, epoch,

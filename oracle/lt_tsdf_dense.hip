@@ -3,10 +3,13 @@
 // One thread per voxel: the reference's pycuda kernel `integrate` (/root/reference auxiliary/fusion_lidar.py:66-229,
 // CUDA source inside a Python string) restated statement by statement for the GPU, as the A/B baseline of the shipped
 // column-aware kernel (lidar_transfer_amd/csrc/lt_tsdf.hip: k_tsdf_integrate_cols).  The arithmetic order is the
-// reference's -- that is what the bit-parity tests of tests/test_tsdf_gpu.py compare the product against; the FMA
-// contraction pattern (__fmaf_rn where nvcc's default -fmad=true fuses a product into the following add) is the same
-// assumption the product makes and is NOT pinned against a CUDA run (parity unpinned for the
-// class-aware branch; tests/golden/make_golden_tsdf_cuda.py is the generator that would pin it).
+// reference's -- that is what the bit-parity tests of tests/test_tsdf_gpu.py compare the product against.
+//
+// PINNED to the reference's source: tests/test_tsdf_ref_kernel_gpu.py runs the reference's kernel text, compiled unmodified
+// by hipcc for gfx950 (oracle/build_ref_tsdf.py -> oracle/_ref/libref_tsdf_integrate.so), next to this file's kernel on the
+// same observations -- all four volumes bit-identical, up to 72 M voxels.  The explicit __fmaf_rn below are therefore the
+// contractions hipcc applies to the reference's text under nvcc's default (-fmad=true == -ffp-contract=fast); this file is
+// built with -ffp-contract=off so that nothing else fuses.  NOT pinned: a CUDA run (CUDA's own norm3df / atan2 / asinf).
 //
 // Built by oracle/Makefile (target `dense`) into oracle/liblt_tsdf_dense.so; loaded by oracle.binding.dense_lib();
 // operates on raw device pointers.
@@ -77,7 +80,10 @@ __global__ __launch_bounds__(256) void k_dense_integrate(float* __restrict__ tsd
   const float pt_z = __fmaf_rn(voxel_z, voxel_size, oz);
   // spherical projection (:120-146); cam_pose is not used by the reference kernel (:112-114)
   const float fov = fabsf(fov_up) + fabsf(fov_down);
-  const float depth = sqrtf(__fmaf_rn(pt_z, pt_z, __fmaf_rn(pt_y, pt_y, pt_x * pt_x)));  // norm3df
+  // norm3df: the device library's, as the reference's own source gets it when hipcc compiles it (oracle/_ref/
+  // libref_tsdf_integrate.so -- bit-identical volumes, tests/test_tsdf_ref_kernel_gpu.py).  (ocml: the magnitudes sorted
+  // a >= b >= c, scaled by a's exponent, sqrt(fma(a, a, fma(b, b, c * c))) with the hardware's v_sqrt_f32.)
+  const float depth = norm3df(pt_x, pt_y, pt_z);
   const float yaw = -atan2f(pt_y, pt_x);
   const float pitch = asinf(pt_z / depth);
   if (pitch > fov_up || pitch < fov_down) return;

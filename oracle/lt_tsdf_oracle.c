@@ -1,11 +1,17 @@
 /*
  * lt_tsdf_oracle.c -- CPU restatement of the reference's TSDF `integrate` kernel (TEST INFRASTRUCTURE).
  *
- * PARITY UNPINNED for the class-aware branch: the reference implements it only as a CUDA kernel embedded
- * in Python (auxiliary/fusion_lidar.py:66-229, run through pycuda), which cannot be executed here; this
- * file restates that source line by line in C.  The `merge == false` branch (:178-205) is additionally
- * cross-checked against the reference's own numpy CPU mode (fusion_lidar.py:289-392) by the goldens F8
- * (float64 pixel maths there, float32 here -> tolerance, see tests/test_tsdf_gpu.py).
+ * PARITY: the reference implements `integrate` only as a CUDA kernel embedded in Python (auxiliary/
+ * fusion_lidar.py:66-229, run through pycuda); this file restates that source line by line in C.  What pins it:
+ *   - its GPU twin oracle/lt_tsdf_dense.hip is bit-identical, on all four volumes, to the reference's kernel source
+ *     compiled unmodified by hipcc for gfx950 (oracle/_ref/libref_tsdf_integrate.so, tests/test_tsdf_ref_kernel_gpu.py);
+ *     this C file agrees with both up to what a CPU cannot restate: the device library's atan2f / asinf and its
+ *     norm3df (sorted magnitudes, sqrt(fma(a, a, fma(b, b, c * c))) with the hardware's 1-ulp v_sqrt_f32 -- the same
+ *     formula below with libm's correctly rounded sqrtf): class and weight volumes equal but for voxels on a pixel /
+ *     fov / truncation boundary, tsdf within a few ulp (tests/test_tsdf_gpu.py);
+ *   - the `merge == false` branch (:178-205) is additionally cross-checked against the reference's own numpy CPU mode
+ *     (fusion_lidar.py:289-392) by the goldens F8 (float64 pixel maths there, float32 here -> tolerance).
+ * NOT pinned: a CUDA run (no NVIDIA device here) -- CUDA's last-ulp behaviour of norm3df / atan2 / asinf.
  * `a + b * c` is written fmaf(b, c, a): nvcc contracts these by default.
  */
 #include <math.h>
@@ -29,7 +35,14 @@ void lto_tsdf_integrate(float* tsdf_vol, float* weight_vol, float* color_vol, fl
     const float pt_x = fmaf(voxel_x, voxel_size, origin[0]);
     const float pt_y = fmaf(voxel_y, voxel_size, origin[1]);
     const float pt_z = fmaf(voxel_z, voxel_size, origin[2]);
-    const float depth = sqrtf(fmaf(pt_z, pt_z, fmaf(pt_y, pt_y, pt_x * pt_x)));
+    float depth;
+    { /* norm3df as the device library computes it (ocml len3): magnitudes sorted a >= b >= c */
+      float a = fabsf(pt_x), b = fabsf(pt_y), c = fabsf(pt_z), t;
+      if (a < b) { t = a; a = b; b = t; }
+      if (a < c) { t = a; a = c; c = t; }
+      if (b < c) { t = b; b = c; c = t; }
+      depth = sqrtf(fmaf(a, a, fmaf(b, b, c * c)));
+    }
     const float yaw = -atan2f(pt_y, pt_x);
     const float pitch = asinf(pt_z / depth);
     if (pitch > fov_up || pitch < fov_down) continue;

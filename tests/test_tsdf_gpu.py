@@ -1,9 +1,10 @@
 """TSDF integration kernel on the GPU.
 
 Parity status: the reference's `integrate` exists only as a CUDA kernel inside a Python string
-(auxiliary/fusion_lidar.py:66-229) and cannot be executed here, so the class-aware branch is checked against
-our C restatement of that source (oracle/lt_tsdf_oracle.c, PARITY UNPINNED), and the plain-average branch
-additionally against golden volumes produced by the reference's own numpy CPU mode (F8)."""
+(auxiliary/fusion_lidar.py:66-229).  tests/test_tsdf_ref_kernel_gpu.py pins the product to that source compiled for
+gfx950, bit for bit; here the product is checked against our C restatement of it (oracle/lt_tsdf_oracle.c -- libm's
+atan2f / asinf / sqrtf instead of the device library's: boundary voxels and last ulps differ), against the dense HIP
+restatement (bit for bit), and the plain-average branch against golden volumes of the reference's own numpy CPU mode (F8)."""
 import os
 
 import numpy as np
@@ -27,6 +28,24 @@ def _images(seed, H, W, fu, fd):
     return label3, depth, remi
 
 
+def _vs_c_restatement(got, ref, n, what=""):
+    """Product volumes against the C restatement.  The C code has libm's atan2f / asinf and a correctly rounded sqrtf where
+    the device has its own atan2f / asinf and norm3df (1-ulp v_sqrt_f32): a voxel projecting onto a pixel / fov /
+    truncation boundary may read the neighbouring pixel (<= 2e-4 of the volume), and the distance of the others may differ
+    by the ulp of the depth.  Weight and class must be bit-identical outside the boundary voxels, tsdf / remission within
+    a few ulp of their running averages."""
+    flips = (got[1] != ref[1]) | (got[2] != ref[2])
+    assert flips.sum() <= 2e-4 * n, f"{what}{flips.sum()} of {n} voxels differ in weight / class"
+    ok = ~flips
+    for k in (0, 3):
+        d = np.abs(got[k][ok].astype(np.float64) - ref[k][ok])
+        d = d[np.isfinite(d)]
+        far = d > 4e-6
+        assert far.sum() <= 2e-4 * n, f"{what}field {k}: {far.sum()} voxels off by more than 4e-6 (max {d.max()})"
+    nan_mismatch = np.isnan(got[0][ok]) != np.isnan(ref[0][ok])
+    assert not nan_mismatch.any()
+
+
 @pytest.mark.parametrize("merge", [True, False])
 def test_integrate_vs_c_restatement(oracle, merge):
     from lidar_transfer_amd.fusion import TSDFVolume
@@ -45,12 +64,7 @@ def test_integrate_vs_c_restatement(oracle, merge):
     n = got[0].size
     touched = int((ref[1] > 0).sum() + (ref[0] != 1).sum())
     assert touched > 0.02 * n, "test volume barely touched"
-    # libm vs ocml asinf/atan2f differ in the last ulp: a voxel projecting onto a pixel / fov boundary may read the
-    # neighbouring pixel.  Everything else must be bit-identical.
-    bad = np.zeros(dims, bool)
-    for a, b in zip(got, ref):
-        bad |= a.view(np.int32) != b.view(np.int32)
-    assert bad.sum() <= 2e-4 * n, f"{bad.sum()} of {n} voxels differ"
+    _vs_c_restatement(got, ref, n)
     vol.close()
 
 
@@ -73,11 +87,8 @@ def test_wedge_table_follows_the_image_shape(oracle):
             folded = np.floor(label3[:, :, 0] * 256 * 256 + label3[:, :, 1] * 256 + label3[:, :, 2]).astype(np.float32)
             oracle.tsdf_integrate(ref, dims, vol._vol_origin, 0.25, fu, fd, folded, depth, remi, 1.0, merge=True)
         got = [t.cpu().numpy() for t in vol.get_volume_tensors()]
-        bad = np.zeros(dims, bool)
-        for a, b in zip(got, ref):
-            bad |= a.view(np.int32) != b.view(np.int32)
         assert (ref[0] != 1).sum() > 0.005 * n, "test volume barely touched"
-        assert bad.sum() <= 2e-4 * n, f"shape {H}x{W}: {bad.sum()} of {n} voxels differ"
+        _vs_c_restatement(got, ref, n, f"shape {H}x{W}: ")
     vol.close()
 
 

@@ -1,0 +1,107 @@
+"""SURVEY.md section 8 row f1 pinned to the reference's own kernel source.
+
+The class-aware TSDF ``integrate`` exists in the reference only as CUDA C inside a Python string handed to pycuda
+(auxiliary/fusion_lidar.py:66-229).  ``oracle/build_ref_tsdf.py`` reads that string where it lies and lets hipcc compile
+it, unmodified, for gfx950 behind a restatement of the pycuda launch (block / grid / ``gpu_loop_idx`` loop of
+fusion_lidar.py:232-250, :267-287) -> ``oracle/_ref/libref_tsdf_integrate.so``.  Here that REAL kernel runs on the MI355X
+next to
+
+* ``oracle/lt_tsdf_dense.hip`` -- our one-thread-per-voxel restatement (the A/B partner of the product in test_tsdf_gpu.py),
+* ``liblidarhip.so``           -- the product's work-saving kernels through ``TSDFVolume.integrate`` and the fused
+                                   ``integrate_multi``,
+
+on the same observations: ALL FOUR VOLUMES OF ALL FOUR IMPLEMENTATIONS BIT-IDENTICAL, NaN / infinite / zero / "no data"
+depth pixels and a volume beyond 2^24 voxels (where the reference's float voxel index misplaces voxels) included.
+
+What the reference build does NOT carry is CUDA's math library: its ``norm3df`` / ``atan2`` / ``asinf`` are the ROCm device
+library's, and so are the product's and the restatement's (lt_tsdf.hip header).  A CUDA run of the same source may differ
+in the last ulp of those three functions; no NVIDIA device exists here to bound that.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _observations(H, W, n, seed=5):
+    rng = np.random.default_rng(seed)
+    yaw = np.linspace(-np.pi, np.pi, W)
+    obs = []
+    for k in range(n):
+        depth = (6.0 + 3.0 * np.sin(3 * yaw + k)[None, :] + 0.2 * rng.random((H, W))).astype(np.float32)
+        depth[rng.random((H, W)) < 0.05] = 0.0
+        depth[:, 40 * W // 256:60 * W // 256] = 0.0
+        depth[:, 100 * W // 256:110 * W // 256] = -1.0        # the reference's "no data" value (laserscan.py:38)
+        depth[rng.random((H, W)) < 0.003] = np.nan             # broken pixels: every implementation must treat them alike
+        depth[rng.random((H, W)) < 0.003] = np.inf
+        lab = rng.choice(np.array([0.0, 40.0, 50.0]), (H, W)).astype(np.float32)
+        if k == n - 1 and n > 1:                              # the last repeats the first's classes: same-class branch
+            lab = obs[0][0][:, :, 0].copy()
+        label3 = np.stack([lab, np.zeros_like(lab), np.zeros_like(lab)], 2)
+        obs.append((label3, depth, rng.random((H, W)).astype(np.float32)))
+    return obs
+
+
+@pytest.mark.parametrize("fu,fd,voxel,half,hw,n_obs", [(10.0, -25.0, 0.25, 20.0, (32, 256), 3),
+                                                        (5.0, -30.0, 0.25, 20.0, (70, 97), 2),
+                                                        (3.0, -25.0, 0.1, 25.6, (64, 1024), 3),
+                                                        (10.0, -25.0, 0.05, 15.0, (32, 256), 2)])
+def test_reference_kernel_source_on_gfx950_vs_restatement_and_product(fu, fd, voxel, half, hw, n_obs):
+    import torch
+    from oracle import binding as ob
+    from lidar_transfer_amd.fusion import TSDFVolume
+    if not ob.ref_tsdf_available():
+        pytest.skip("oracle/_ref/libref_tsdf_integrate.so not built (needs /root/reference + hipcc at build time)")
+    ref, dense = ob.ref_tsdf_lib(), ob.dense_lib()
+    H, W = hw
+    bnds = np.array([[-half, half], [-half, half], [-5.0, 5.0]])
+    vol = TSDFVolume(bnds, voxel, fu, fd, merge=True)
+    fused = TSDFVolume(bnds, voxel, fu, fd, merge=True)
+    dims_t = tuple(int(x) for x in vol._vol_dim)
+    n = int(np.prod(dims_t))
+    dims = (C.c_int * 3)(*dims_t)
+    org = (C.c_float * 3)(*[float(x) for x in vol._vol_origin])
+    geo = (C.c_int * 5)()
+    assert ref.ref_tsdf_geometry(dims, geo) == 0
+    threads, gx, gy, gz, loops = list(geo)
+    assert threads * gx * gy * gz * loops >= n and threads == 1024          # fusion_lidar.py:234 on this device
+    dev = torch.device("cuda", 0)
+
+    def fresh():
+        return [torch.ones(dims_t, device=dev), torch.zeros(dims_t, device=dev), torch.zeros(dims_t, device=dev),
+                torch.zeros(dims_t, device=dev)]
+    vr, vd = fresh(), fresh()
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    obs = _observations(H, W, n_obs)
+    for label3, depth, rem in obs:
+        c = torch.from_numpy(label3).to(dev)
+        folded = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()   # fusion_lidar.py:261-264
+        d, r = torch.from_numpy(depth).to(dev), torch.from_numpy(rem).to(dev)
+        args = (dims, org, C.c_float(np.float32(voxel)), C.c_float(np.float32(voxel * 5)), C.c_float(fu), C.c_float(fd),
+                vp(folded.data_ptr()), vp(d.data_ptr()), vp(r.data_ptr()), H, W, C.c_float(1.0))
+        assert ref.ref_tsdf_integrate(*[vp(t.data_ptr()) for t in vr], *args, st) == 0
+        assert dense.lt_test_tsdf_integrate_dense(*[vp(t.data_ptr()) for t in vd], *args, 1, st) == 0
+        vol.integrate(label3, depth, rem, np.eye(4), obs_weight=1.)
+    fused.integrate_multi(obs, obs_weight=1.)
+    torch.cuda.synchronize()
+    R = [t.cpu().numpy() for t in vr]
+    D = [t.cpu().numpy() for t in vd]
+    P = [t.cpu().numpy() for t in vol.get_volume_tensors()]
+    F = [t.cpu().numpy() for t in fused.get_volume_tensors()]
+    touched = (R[0] != 1) | (R[1] != 0)
+    assert touched.sum() > 0.01 * n, "test volume barely touched"
+    assert (R[0] < 0).sum() > 0.001 * n and (R[1] >= 2).sum() > 0, "no surface crossing / no same-class update in the test"
+    names = ("tsdf", "weight", "color", "rem")
+    for k in range(4):
+        r = R[k].view(np.int32)
+        for who, V in (("restatement oracle/lt_tsdf_dense.hip", D), ("product TSDFVolume.integrate", P),
+                       ("product TSDFVolume.integrate_multi", F)):
+            bad = int((r != V[k].view(np.int32)).sum())
+            assert bad == 0, f"reference kernel source vs {who}: {bad} of {n} voxels differ in {names[k]}"
+    print(f"\nreference kernel (launch {threads} x ({gx},{gy},{gz}) x {loops}): {n} voxels, {int(touched.sum())} touched -- "
+          f"restatement, product and fused product bit-identical")
+    vol.close()
+    fused.close()
