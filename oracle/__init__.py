@@ -8,9 +8,10 @@ Only tests/, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` leg may imp
                              golden vectors F2-F5)
   projection.py              do_range_projection / do_range_projection_new / label projection in numpy
                              (pinned against the reference's own arrays, golden vectors F6 and F9)
-  lt_tsdf_oracle.c           TSDF `integrate` CUDA source restated in C (parity unpinned for the class-aware branch:
-                             the reference kernel cannot be executed here; the plain-average branch is pinned
-                             against the reference's numpy CPU mode, golden F8)
+  lt_tsdf_oracle.c           TSDF `integrate` CUDA source restated in C; lt_tsdf_dense.hip the same for the GPU, bit-identical
+                             to the reference's own kernel text compiled by hipcc for gfx950 (build_ref_tsdf.py +
+                             ref_tsdf_launch.inc -> _ref/libref_tsdf_integrate{,_plain}.so); the plain-average branch
+                             also against the reference's numpy CPU mode, golden F8
   gen_rsqrt_table.c          measures and exhaustively verifies the x86 RSQRTSS table the kernels replay
   Makefile                   builds liblt_oracle.so and oracle/_ref/ (needs /root/reference for the latter)
 """

@@ -53,31 +53,34 @@ def dense_lib():
     return _dense
 
 
-_ref_tsdf = None
+_ref_tsdf = {}
 
 
 def ref_tsdf_available() -> bool:
-    return os.path.exists(os.path.join(HERE, "_ref", "libref_tsdf_integrate.so"))
+    return all(os.path.exists(os.path.join(HERE, "_ref", f)) for f in ("libref_tsdf_integrate.so",
+                                                                       "libref_tsdf_integrate_plain.so"))
 
 
-def ref_tsdf_lib():
+def ref_tsdf_lib(merge: bool = True):
     """oracle/_ref/libref_tsdf_integrate.so: the reference's OWN ``integrate`` kernel -- the CUDA C text held in
     /root/reference/auxiliary/fusion_lidar.py:66-229, read in place and compiled by hipcc for gfx950
     (oracle/build_ref_tsdf.py) -- behind a restatement of the pycuda launch (oracle/ref_tsdf_launch.inc,
-    fusion_lidar.py:232-250, :267-287).  ``ref_tsdf_integrate(tsdf, weight, color, rem, dims, origin, voxel_size,
-    trunc_margin, fov_up_deg, fov_down_deg, color_im, depth_im, rem_im, im_h, im_w, obs_weight, stream)`` on DEVICE
-    pointers; ``ref_tsdf_geometry(dims, out[5])`` -> threads, grid x/y/z, loops."""
-    global _ref_tsdf
-    if _ref_tsdf is None:
-        lib = C.CDLL(os.path.join(HERE, "_ref", "libref_tsdf_integrate.so"))
+    fusion_lidar.py:232-250, :267-287).  ``merge=False``: ..._plain.so, the same text with its hard-wired
+    ``bool merge = true;`` flipped (the plain running average branch).  ``ref_tsdf_integrate(tsdf, weight, color, rem,
+    dims, origin, voxel_size, trunc_margin, fov_up_deg, fov_down_deg, color_im, depth_im, rem_im, im_h, im_w, obs_weight,
+    stream)`` on DEVICE pointers; ``ref_tsdf_geometry(dims, out[5])`` -> threads, grid x/y/z, loops."""
+    key = bool(merge)
+    if key not in _ref_tsdf:
+        name = "libref_tsdf_integrate.so" if key else "libref_tsdf_integrate_plain.so"
+        lib = C.CDLL(os.path.join(HERE, "_ref", name))
         vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
         lib.ref_tsdf_integrate.argtypes = [vp, vp, vp, vp, ip, fp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp,
                                            C.c_int, C.c_int, C.c_float, vp]
         lib.ref_tsdf_integrate.restype = C.c_int
         lib.ref_tsdf_geometry.argtypes = [ip, ip]
         lib.ref_tsdf_geometry.restype = C.c_int
-        _ref_tsdf = lib
-    return _ref_tsdf
+        _ref_tsdf[key] = lib
+    return _ref_tsdf[key]
 
 
 def _lib():

@@ -25,6 +25,10 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_PY = os.environ.get("LT_REF_FUSION", "/root/reference/auxiliary/fusion_lidar.py")
 OUT = os.path.join(HERE, "_ref", "libref_tsdf_integrate.so")
+# the same text with the reference's own hard-wired switch (`bool merge = true;`, fusion_lidar.py:157) flipped -- the one
+# token that selects the plain running average (:158-...) instead of the class-aware update; nothing else is touched
+OUT_PLAIN = os.path.join(HERE, "_ref", "libref_tsdf_integrate_plain.so")
+SWITCH = "bool merge = true;"
 
 
 def kernel_text(path=REF_PY):
@@ -44,19 +48,22 @@ def main():
         print("oracle: no hipcc, keeping prebuilt", OUT)
         return 0
     text, a, b = kernel_text()
+    if text.count(SWITCH) != 1:
+        raise SystemExit(f"{REF_PY}: expected exactly one `{SWITCH}` in the kernel text")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    with tempfile.TemporaryDirectory(prefix="lt_ref_tsdf_") as tmp:
-        src = os.path.join(tmp, "ref_integrate.hip")
-        with open(src, "w") as f:
-            f.write("#include <hip/hip_runtime.h>\n")
-            f.write(f"// {REF_PY}:{a}-{b}, wrapped as pycuda's SourceModule does (no_extern_c=False)\n")
-            f.write('extern "C" {\n' + text + "\n}\n")
-            f.write(f'#include "{os.path.join(HERE, "ref_tsdf_launch.inc")}"\n')
-        cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=fast", "-fPIC", "-shared", "-w", "--offload-arch=gfx950",
-               "-o", OUT + ".tmp", src]
-        subprocess.run(cmd, check=True)
-        os.replace(OUT + ".tmp", OUT)
-    print("oracle: built", OUT, f"from {REF_PY}:{a}-{b}")
+    for out, body, note in ((OUT, text, ""), (OUT_PLAIN, text.replace(SWITCH, "bool merge = false;"), " (merge switch flipped)")):
+        with tempfile.TemporaryDirectory(prefix="lt_ref_tsdf_") as tmp:
+            src = os.path.join(tmp, "ref_integrate.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n")
+                f.write(f"// {REF_PY}:{a}-{b}{note}, wrapped as pycuda's SourceModule does (no_extern_c=False)\n")
+                f.write('extern "C" {\n' + body + "\n}\n")
+                f.write(f'#include "{os.path.join(HERE, "ref_tsdf_launch.inc")}"\n')
+            cmd = [hipcc, "-O3", "-std=c++17", "-ffp-contract=fast", "-fPIC", "-shared", "-w", "--offload-arch=gfx950",
+                   "-o", out + ".tmp", src]
+            subprocess.run(cmd, check=True)
+            os.replace(out + ".tmp", out)
+        print("oracle: built", out, f"from {REF_PY}:{a}-{b}{note}")
     return 0
 
 

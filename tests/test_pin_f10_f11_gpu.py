@@ -1,6 +1,8 @@
-"""The two rows of the scope table whose parity is UNPINNED in this image -- marching cubes (SURVEY.md section 8f-2;
-scikit-image's Lewiner implementation is the reference's dependency, not importable here) and the class-aware TSDF update
-(8f-1; CUDA inside a Python string, needs pycuda + an NVIDIA GPU) -- against golden fixtures made by the REAL reference:
+"""The two rows of the scope table that need the reference's own ENVIRONMENT -- marching cubes (SURVEY.md section 8f-2;
+scikit-image's Lewiner implementation is the reference's dependency, not importable here: parity unpinned) and the
+class-aware TSDF update as a CUDA run (8f-1; pinned in this image to the kernel's source compiled for gfx950,
+tests/test_tsdf_ref_kernel_gpu.py -- pycuda + an NVIDIA GPU would add CUDA's own last ulps) -- against golden fixtures
+made by the REAL reference:
 
     tests/golden/make_golden_mc.py         -> tests/golden/f10_mc_<case>.npz
     tests/golden/make_golden_tsdf_cuda.py  -> tests/golden/f11_tsdf_cuda.npz

@@ -44,21 +44,24 @@ def _observations(H, W, n, seed=5):
     return obs
 
 
+@pytest.mark.parametrize("merge", [True, False])
 @pytest.mark.parametrize("fu,fd,voxel,half,hw,n_obs", [(10.0, -25.0, 0.25, 20.0, (32, 256), 3),
                                                         (5.0, -30.0, 0.25, 20.0, (70, 97), 2),
                                                         (3.0, -25.0, 0.1, 25.6, (64, 1024), 3),
                                                         (10.0, -25.0, 0.05, 15.0, (32, 256), 2)])
-def test_reference_kernel_source_on_gfx950_vs_restatement_and_product(fu, fd, voxel, half, hw, n_obs):
+def test_reference_kernel_source_on_gfx950_vs_restatement_and_product(fu, fd, voxel, half, hw, n_obs, merge):
+    """``merge``: True is what the reference runs (its hard-wired ``bool merge = true;``, fusion_lidar.py:157); False is the
+    same text with that one switch flipped at build time -- the plain running average with per-channel colour average."""
     import torch
     from oracle import binding as ob
     from lidar_transfer_amd.fusion import TSDFVolume
     if not ob.ref_tsdf_available():
         pytest.skip("oracle/_ref/libref_tsdf_integrate.so not built (needs /root/reference + hipcc at build time)")
-    ref, dense = ob.ref_tsdf_lib(), ob.dense_lib()
+    ref, dense = ob.ref_tsdf_lib(merge), ob.dense_lib()
     H, W = hw
     bnds = np.array([[-half, half], [-half, half], [-5.0, 5.0]])
-    vol = TSDFVolume(bnds, voxel, fu, fd, merge=True)
-    fused = TSDFVolume(bnds, voxel, fu, fd, merge=True)
+    vol = TSDFVolume(bnds, voxel, fu, fd, merge=merge)
+    fused = TSDFVolume(bnds, voxel, fu, fd, merge=merge)
     dims_t = tuple(int(x) for x in vol._vol_dim)
     n = int(np.prod(dims_t))
     dims = (C.c_int * 3)(*dims_t)
@@ -83,7 +86,7 @@ def test_reference_kernel_source_on_gfx950_vs_restatement_and_product(fu, fd, vo
         args = (dims, org, C.c_float(np.float32(voxel)), C.c_float(np.float32(voxel * 5)), C.c_float(fu), C.c_float(fd),
                 vp(folded.data_ptr()), vp(d.data_ptr()), vp(r.data_ptr()), H, W, C.c_float(1.0))
         assert ref.ref_tsdf_integrate(*[vp(t.data_ptr()) for t in vr], *args, st) == 0
-        assert dense.lt_test_tsdf_integrate_dense(*[vp(t.data_ptr()) for t in vd], *args, 1, st) == 0
+        assert dense.lt_test_tsdf_integrate_dense(*[vp(t.data_ptr()) for t in vd], *args, 1 if merge else 0, st) == 0
         vol.integrate(label3, depth, rem, np.eye(4), obs_weight=1.)
     fused.integrate_multi(obs, obs_weight=1.)
     torch.cuda.synchronize()
