@@ -108,3 +108,61 @@ def test_reference_kernel_source_on_gfx950_vs_restatement_and_product(fu, fd, vo
           f"restatement, product and fused product bit-identical")
     vol.close()
     fused.close()
+
+
+def test_reference_kernel_at_the_default_volume(capsys):
+    """Full size (the reference's default grid, lidar_deform.py: 100 m x 100 m x 10 m at 0.05 m = 2000 x 2000 x 200 = 800 M
+    voxels, 64 x 2048 observations): the reference's kernel -- 781 250 workgroups of 1024 threads, every voxel through
+    atan2 / asinf -- and the product's pixel-driven integrate leave bit-identical volumes (compared on the device: 4 x 3.2 GB
+    each).  Prints both durations (HIP events): what the reference's own kernel costs on this GPU next to the product."""
+    import torch
+    from oracle import binding as ob
+    from lidar_transfer_amd.fusion import TSDFVolume
+    if not ob.ref_tsdf_available():
+        pytest.skip("oracle/_ref/libref_tsdf_integrate.so not built (needs /root/reference + hipcc at build time)")
+    ref = ob.ref_tsdf_lib(True)
+    fu, fd, voxel, (H, W) = 3.0, -25.0, 0.05, (64, 2048)
+    bnds = np.array([[-50.0, 50.0], [-50.0, 50.0], [-5.0, 5.0]])
+    vol = TSDFVolume(bnds, voxel, fu, fd, merge=True)
+    dims_t = tuple(int(x) for x in vol._vol_dim)
+    assert dims_t == (2000, 2000, 200)
+    dims = (C.c_int * 3)(*dims_t)
+    org = (C.c_float * 3)(*[float(x) for x in vol._vol_origin])
+    dev = torch.device("cuda", 0)
+    vr = [torch.ones(dims_t, device=dev), torch.zeros(dims_t, device=dev), torch.zeros(dims_t, device=dev),
+          torch.zeros(dims_t, device=dev)]
+    vp = C.c_void_p
+    stream = torch.cuda.current_stream()
+    st = vp(stream.cuda_stream)
+    t_ref, t_prod = [], []
+    for label3, depth, rem in _observations(H, W, 3, seed=11):
+        depth = depth * 2.5                     # surfaces 7 .. 23 m away: a street scene's scale inside the 100 m volume
+        c = torch.from_numpy(label3).to(dev)
+        folded = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()
+        d, r = torch.from_numpy(depth).to(dev), torch.from_numpy(rem).to(dev)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record(stream)
+        assert ref.ref_tsdf_integrate(*[vp(t.data_ptr()) for t in vr], dims, org, C.c_float(np.float32(voxel)),
+                                      C.c_float(np.float32(voxel * 5)), C.c_float(fu), C.c_float(fd), vp(folded.data_ptr()),
+                                      vp(d.data_ptr()), vp(r.data_ptr()), H, W, C.c_float(1.0), st) == 0
+        e[1].record(stream)
+        e[2].record(stream)
+        # (TSDFVolume.integrate's native call on the same device tensors: no host copies, no folding inside the clock)
+        vol._libmod.check(vol._lib.lt_tsdf_integrate_dev(vol._h, folded.data_ptr(), d.data_ptr(), r.data_ptr(), H, W, 1.0,
+                                                         vol._libmod.LT_TSDF_MERGE, st), "lt_tsdf_integrate_dev")
+        e[3].record(stream)
+        torch.cuda.synchronize()
+        t_ref.append(e[0].elapsed_time(e[1]))
+        t_prod.append(e[2].elapsed_time(e[3]))
+    P = vol.get_volume_tensors()
+    touched = int(((vr[0] != 1) | (vr[1] != 0)).sum())
+    assert touched > 1_000_000
+    for k, name in enumerate(("tsdf", "weight", "color", "rem")):
+        a, b = vr[k].view(torch.int32), P[k].view(torch.int32)
+        bad = int((a != b).sum())
+        assert bad == 0, f"default volume: {bad} voxels differ in {name}"
+    with capsys.disabled():
+        print(f"\ndefault volume 2000x2000x200, 64x2048 observations: reference kernel {['%.2f' % t for t in t_ref]} ms, "
+              f"product integrate {['%.3f' % t for t in t_prod]} ms per observation; {touched} voxels touched, "
+              f"all four volumes bit-identical")
+    vol.close()

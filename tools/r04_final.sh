@@ -4,6 +4,8 @@ mkdir -p gpurun_out/r04
 { timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -4
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
   timeout 1500 python tools/stress_scatter.py --cases 1000 --oracle --batch 8 2>&1 | tail -2; } > gpurun_out/r04/gpu_suite.txt 2>&1
+# row f1's pin: the reference's own kernel source (compiled for gfx950, oracle/_ref) next to the product -- what ran, what it cost
+timeout 900 python -m pytest tests/test_tsdf_ref_kernel_gpu.py -m gpu -q -s 2>&1 | grep -E "reference kernel|default volume|passed|failed" > gpurun_out/r04/tsdf_ref_kernel.txt
 bash tools/r04_profile.sh > gpurun_out/r04/profile.log 2>&1
 { LIDARHIP_DEBUG_TSDF=1 python tools/prof_chain.py 3 --ranges 2>&1 | grep -v amdgpu.ids | tail -6
   python tools/prof_chain.py 2 5 --ranges 2>&1 | grep -v amdgpu.ids | tail -2; } > gpurun_out/r04/pix_counts.txt 2>&1
