@@ -6,6 +6,8 @@ mkdir -p gpurun_out/r04
   timeout 1500 python tools/stress_scatter.py --cases 1000 --oracle --batch 8 2>&1 | tail -2; } > gpurun_out/r04/gpu_suite.txt 2>&1
 # row f1's pin: the reference's own kernel source (compiled for gfx950, oracle/_ref) next to the product -- what ran, what it cost
 timeout 900 python -m pytest tests/test_tsdf_ref_kernel_gpu.py -m gpu -q -s 2>&1 | grep -E "reference kernel|default volume|passed|failed" > gpurun_out/r04/tsdf_ref_kernel.txt
+# yardstick for the LBVH build's sort (ms_sort in the bench line): the ROCm library's device radix sort on the same job
+(/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/sort_probe tools/sort_probe.hip 2>/dev/null && /tmp/sort_probe && /tmp/sort_probe 2500000) > gpurun_out/r04/sort_probe.txt 2>&1
 bash tools/r04_profile.sh > gpurun_out/r04/profile.log 2>&1
 { LIDARHIP_DEBUG_TSDF=1 python tools/prof_chain.py 3 --ranges 2>&1 | grep -v amdgpu.ids | tail -6
   python tools/prof_chain.py 2 5 --ranges 2>&1 | grep -v amdgpu.ids | tail -2; } > gpurun_out/r04/pix_counts.txt 2>&1
