@@ -43,6 +43,10 @@ def import_reference(stub_skimage=True):
     ob.build(quiet=True)
     np.float = float  # removed alias used at laserscan.py:568, :714
     sys.modules["imageio"] = types.ModuleType("imageio")
+    try:  # laserscan.py:6 imports torch at module level; the functions the fixtures call (create_rays, projections) are numpy.
+        import torch  # noqa: F401   An interpreter that has scikit-image but no torch (make_golden_mc.py) gets an empty module.
+    except ImportError:
+        sys.modules["torch"] = types.ModuleType("torch")
     if stub_skimage:
         sk = types.ModuleType("skimage")
         sk.measure = types.ModuleType("skimage.measure")

@@ -3,11 +3,11 @@
 scikit-image's Lewiner marching cubes (:407) + the attribute look-ups (:409-423), and the image the reference's own
 raytracer renders from that mesh -- for the seeded volumes of tests/pin_cases.py.
 
-CANNOT RUN IN THE BUILD IMAGE (scikit-image is not installed there, and there is no network): this is the recipe a
-maintainer with the reference's environment runs once; tests/test_pin_f10_f11_gpu.py skips until the files exist.
+Needs an interpreter with scikit-image 0.18.x (the last series that has `measure.marching_cubes_lewiner`, the name the
+reference calls).  The build image has one beside the system Python: /opt/conda/bin/python3.9 (scikit-image 0.18.3, numpy
+1.26, no torch -- make_golden.import_reference gives laserscan.py's unused `import torch` an empty module):
 
-    pip install scikit-image            # the reference's own dependency (README.md:18, no version pinned)
-    LT_REFERENCE=/path/to/lidar_transfer python tests/golden/make_golden_mc.py
+    /opt/conda/bin/python3.9 tests/golden/make_golden_mc.py
     git add tests/golden/f10_mc_*.npz
 
 What runs is the reference itself: `auxiliary.fusion_lidar.TSDFVolume.get_mesh` on a volume object whose CPU arrays are
@@ -17,6 +17,7 @@ by oracle/Makefile (strict IEEE flags), with rays from its own `create_rays`.  s
 alias below bridges that and is recorded in the fixture.  Only data is written.
 
 Per case `f10_mc_<name>.npz`:
+    verts [V,3] f32, faces [F,3] i32, colors [V,3] u8, vrem [V] f32  `get_mesh`'s return values AS THEY ARE (values and order)
     verts_sorted [V,3] f32   world vertices, rows sorted lexicographically (x, y, z) -- the vertex SET; skimage's order is
                              not part of the contract (the order of lt_mc.hip is its own)
     colors_sorted [V,3] u8, rem_sorted [V] f32     attributes in the same order
@@ -43,7 +44,7 @@ def main():
         import skimage
         from skimage import measure
     except ImportError:
-        raise SystemExit("make_golden_mc.py needs scikit-image (the reference's dependency); not installable in the build image")
+        raise SystemExit("make_golden_mc.py needs scikit-image 0.18.x (the reference's dependency): /opt/conda/bin/python3.9 has it")
     used_alias = False
     if not hasattr(measure, "marching_cubes_lewiner"):
         used_alias = True
@@ -61,7 +62,8 @@ def main():
         order = np.lexsort((verts[:, 2], verts[:, 1], verts[:, 0]))
         tri = verts[np.asarray(faces)]
         area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
-        out = dict(verts_sorted=verts[order], colors_sorted=np.asarray(colors)[order], rem_sorted=np.asarray(vrem, np.float32)[order],
+        out = dict(verts=verts, faces=np.asarray(faces, np.int32), colors=np.asarray(colors, np.uint8), vrem=np.asarray(vrem, np.float32),
+                   verts_sorted=verts[order], colors_sorted=np.asarray(colors)[order], rem_sorted=np.asarray(vrem, np.float32)[order],
                    n_faces=len(faces), face_area_sum=float(area.sum()), skimage_version=np.array(skimage.__version__),
                    used_alias=used_alias, voxel_size=float(vs), vol_origin=org)
         if sensor is not None:

@@ -118,3 +118,29 @@ def test_degenerate_volumes(oracle):
     thin[0, 2, 3] = 1.0
     v, f, c, r = oracle.marching_cubes(thin, thin, thin, 0.1, np.zeros(3, np.float32))
     assert f.shape[0] == 0
+
+
+# ---- row f2 pinned: the reference's own get_mesh (scikit-image 0.18.3's Lewiner marching cubes) -----------------------------
+@pytest.mark.parametrize("case", ["blob", "noise", "street"])
+def test_lewiner_oracle_returns_the_arrays_of_the_reference_get_mesh(case):
+    """Golden F10 (tests/golden/make_golden_mc.py, run with /opt/conda/bin/python3.9: the reference's `TSDFVolume.get_mesh`
+    with the REAL scikit-image 0.18.3) holds `get_mesh`'s return values as they are.  The C restatement of Lewiner's
+    algorithm as scikit-image runs it (oracle/lt_mc_oracle.c) must return the SAME ARRAYS: vertices bit for bit and in the
+    same order, faces with the same indices in the same order, colours, remissions -- smooth surfaces (blob), a street
+    scene with label boundaries (street) and dense noise with exact zeros, where every ambiguous sub-case and the centre
+    vertex occur (noise)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pin_cases
+    from oracle import binding as ob
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"f10_mc_{case}.npz"))
+    assert str(g["skimage_version"]).startswith("0.18") and not bool(g["used_alias"])
+    tsdf, color, rem, vs, org = pin_cases.mc_case(case)
+    v, f, c, r = ob.marching_cubes_lewiner(tsdf, color, rem, vs, org)[:4]
+    assert v.shape == g["verts"].shape and f.shape == g["faces"].shape
+    assert np.array_equal(v.view(np.int32), g["verts"].view(np.int32))
+    assert np.array_equal(f, g["faces"])
+    assert np.array_equal(np.asarray(c).astype(np.uint8), g["colors"])
+    assert np.array_equal(np.asarray(r, np.float32).view(np.int32), g["vrem"].view(np.int32))
+    assert f.shape[0] > 10000
