@@ -363,10 +363,11 @@ int lt_mesh_destroy(lt_mesh* mesh);
  * (auxiliary/fusion_lidar.py:403-424): the three device-to-host volume copies of get_volume (:395-400),
  * skimage.measure.marching_cubes_lewiner on the CPU (:407), the vertex attribute look-ups (:409-423: nearest-voxel
  * colour / remission, voxel -> world coordinates, colour unfolding incl. the uint8 wrap of labels 256..259) and
- * the later upload of the mesh for the ray cast (:433-451).  The mesh is indexed like scikit-image's (one vertex
- * per sign-changing lattice edge, shared by the cells around it; vertex positions by its centre-of-mass rule);
- * triangulation and element order are this library's (generated watertight case table; owner voxel / cell order) --
- * scikit-image is not part of the reference and cannot be run here: parity unpinned, see DESIGN.md section 7c.
+ * the later upload of the mesh for the ray cast (:433-451).  The mesh is scikit-image 0.18's: Lewiner's cases with their
+ * face / interior tests and centre vertices, one vertex per sign-changing lattice edge shared by the cells around it,
+ * positions by its centre-of-mass rule, every face's vertices in its order -- the same SET of vertices (bit for bit) and of
+ * faces as the reference's get_mesh returns (golden F10 of the real scikit-image, tests/test_pin_f10_f11_gpu.py); only the
+ * ORDER of the elements in the arrays is this library's (owner voxel / cell order: no serial face stream on a GPU).
  * The call synchronises `stream` once (the sizes of the mesh are needed on the host).  ms: NULL, or two floats that
  * receive the duration of the sign pass (the one stream over the float field) and of everything else. */
 int lt_tsdf_extract_mesh_dev(lt_tsdf* vol, lt_mesh* mesh, void* stream, float* ms);
@@ -379,14 +380,6 @@ int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float
  * (r, g, b; the label in channel 2, as get_mesh + throw_rays_at_mesh hand it to ctrace), rem [V] f32.  The
  * pointers stay valid until the next extraction into this mesh or lt_mesh_destroy.  Any argument may be NULL. */
 int lt_mesh_get(lt_mesh* mesh, int* n_verts, int* n_faces, float** verts, int** faces, int** colors, float** rem);
-
-/* The 256-case triangulation table of the extraction, in the layout of LT_MC_PACKED (csrc/lt_mc_table.h: two 64-bit words
- * per case -- bits 0..2 the number of triangles, bits 8 + 5 i .. 12 + 5 i the lattice-edge code of corner i of the triangle
- * list).  `packed` = HOST [512] words, copied; NULL restores the built-in table.  A replacement may only RE-TRIANGULATE the
- * polygons of a case (same triangle count, same set of crossing edges: checked).  This is how the divergence from the
- * reference's scikit-image table is bounded while that table cannot be obtained: render the mesh of
- * the built-in table and of the table with every polygon's OTHER diagonals (tools/gen_mc_table.py --variant). */
-int lt_mesh_set_case_table(lt_mesh* mesh, const unsigned long long* packed);
 
 /* lt_scene_set_mesh_dev with the arrays of `mesh` (borrowed until the next extraction): the render reads the
  * mesh where marching cubes wrote it -- no PCIe traffic between fusion and range image. */

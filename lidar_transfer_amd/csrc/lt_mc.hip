@@ -10,10 +10,12 @@
 // The 800 M-voxel default volume (2000 x 2000 x 200, 3.2 GB per field) is 99.8 % empty space, so the float field is
 // read ONCE, as a stream, and everything else works on one SIGN BIT per voxel:
 //
-//   k_mc_signs    tsdf -> sign bit per voxel (wave ballot; rows of nz bits padded to 64-bit words): 3.2 GB in, 128 MB out
+//   k_mc_signs    tsdf -> one bit per voxel, set when the value is NOT above the level (wave ballot; rows of nz bits padded
+//                 to 64-bit words): 3.2 GB in, 128 MB out
 //   k_mc_words    one thread per 64-voxel word: crossing-edge masks ex / ey / ez of the edges its voxels own
 //                 (m ^ neighbour word, shifted for z), active-cell mask (the 8 corner words are not all equal), number
-//                 of vertices (popcounts) and triangles (case table, only on the set bits); per-workgroup totals
+//                 of vertices (popcounts + centre vertices) and triangles (case table, only on the set bits; the cell's
+//                 eight values for Lewiner's ambiguous cases); per-workgroup totals
 //   k_mc_scan1/2  exclusive scan of the workgroup totals in two levels -> V, F
 //   k_mc_compact  word -> compact index of the active words (the ~2 % that own a vertex or a triangle); per active
 //                 word a record {word, vertex base, triangle base, ex, ey, ez}
@@ -22,26 +24,152 @@
 //                 triangles; the index of a vertex owned by a neighbouring word comes from that word's record
 //                 (8 neighbour records staged in LDS per wave): base + popcount of the edge masks below the bit
 //
-// Vertex order = (owner voxel x, y, z ascending, edge axis); face order = (cell ascending, table order):
-// deterministic, no atomics anywhere.  Case table: lt_mc_table.h (generated, tools/gen_mc_table.py).
-// PARITY: unpinned against scikit-image (not importable here); bit-identical to the CPU oracle
-// (oracle/lt_mc_oracle.c) -- DESIGN.md section 7c.
+// WHICH mesh: scikit-image 0.18's `marching_cubes_lewiner` (what the reference calls, fusion_lidar.py:407) -- Lewiner's 33
+// cases with their face / interior tests and centre vertices, decided on the cell's eight VALUES where the signs do not
+// (1-2 % of a street scene's cells; the rest is table look-up on the sign bits as before), every face's vertices in
+// scikit-image's order (gradient_direction = "descent").  The SET of vertices (positions bit for bit, colours, remissions)
+// and the SET of faces equal the reference's get_mesh output (golden F10 made by the real scikit-image: tests/
+// test_pin_f10_f11_gpu.py; the CPU oracle oracle/lt_mc_oracle.c reproduces the reference's arrays including their order and
+// is bit-identical to this file up to that order).  Element ORDER is this library's: vertices by (word of 64 voxels; owner
+// voxel x, y, z ascending, edge axis; then the word's centre vertices), faces by (cell ascending, tiling order) --
+// deterministic, no atomics anywhere; scikit-image numbers vertices by first use in a serial face stream.
+// Tables: lt_mc_lewiner_table.h (Lewiner's LookUpTable.h as scikit-image ships it, tools/gen_mc_lewiner.py).
 #include "lt_internal.h"
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#define LT_TABLE_ATTR __device__
-#include "lt_mc_table.h"
-// ... and once more for the HOST (the emit kernels read the table through a pointer: every mesh object owns a 4 KB device
-// copy that lt_mesh_set_case_table can replace; the symbol API cannot resolve a static __device__ array)
-namespace lt_mc_host {
-#undef LT_MC_TABLE_H
-#undef LT_TABLE_ATTR
-#define LT_TABLE_ATTR
-#include "lt_mc_table.h"
-}  // namespace lt_mc_host
+#define LT_LW_ATTR __device__
+#define LT_LW_NO_RAW
+#include "lt_mc_lewiner_table.h"  // Lewiner's tables as the device reads them (tools/gen_mc_lewiner.py, derived())
+
+// ---- Lewiner's case selection, as scikit-image 0.18 runs it ---------------------------------------------------------------
+// (MarchingCubes.cpp process_cube / test_face / test_interior; skimage/measure/_marching_cubes_lewiner_cy.pyx the_big_switch /
+// test_face / test_internal.)  Everything in double on the float32 field values, level 0; `eps` = np.spacing(1.0) -- the
+// value scikit-image's `FLT_EPSILON` holds, despite its name.  Two properties of scikit-image's port are reproduced because
+// the reference runs IT (both measured against the real library, tools/mc_lewiner_fuzz.py): its divisions are guarded by
+// `+ eps` in the denominator, which decides exact ties, and `test_internal` falls off its end (returns 0) where Lewiner's
+// C++ returns `s < 0` -- case 4 with a negative TEST4 entry therefore takes tiling 4.1.2 for the 5 / 10 patterns.
+#define LT_MC_EPS 2.220446049250313e-16
+__device__ __forceinline__ double lw_pick(const double* v, int i) {  // v[i] without a private-memory array
+  double r = v[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) r = (i == k) ? v[k] : r;
+  return r;
+}
+__device__ __forceinline__ bool lw_test_face(const double* v, int face) {
+  const int f = face < 0 ? -face : face;
+  // faces 1..6: (A, B, C, D) = corners (0,4,5,1) (1,5,6,2) (2,6,7,3) (3,7,4,0) (0,3,2,1) (4,7,6,5)
+  const unsigned abcd = f == 1 ? 0x0451u : f == 2 ? 0x1562u : f == 3 ? 0x2673u : f == 4 ? 0x3740u : f == 5 ? 0x0321u : 0x4765u;
+  const double A = lw_pick(v, (abcd >> 12) & 7), B = lw_pick(v, (abcd >> 8) & 7), C = lw_pick(v, (abcd >> 4) & 7),
+               D = lw_pick(v, abcd & 7);
+  const double acbd = A * C - B * D;
+  if (acbd > -LT_MC_EPS && acbd < LT_MC_EPS) return face >= 0;
+  return (double)face * A * acbd >= 0;
+}
+// edge < 0: cases 4 and 10 (the interior's saddle along the 0-4 direction); else the reference edge of cases 6, 7, 12, 13
+__device__ __forceinline__ bool lw_test_interior(const double* v, int edge, int s) {
+  double t, At = 0, Bt, Ct, Dt;
+  if (edge < 0) {
+    const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+    const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+    t = -b / (2 * a + LT_MC_EPS);
+    if (t < 0 || t > 1) return s > 0;
+    At = v[0] + (v[4] - v[0]) * t;
+    Bt = v[3] + (v[7] - v[3]) * t;
+    Ct = v[2] + (v[6] - v[2]) * t;
+    Dt = v[1] + (v[5] - v[1]) * t;
+  } else {
+    // the reference edge (p, q) and the three edges parallel to it, round the cell: 8 corner numbers, 3 bits each
+    const unsigned E = edge == 0 ? 001327645u : edge == 1 ? 012034756u : edge == 2 ? 023105467u : edge == 3 ? 030216574u
+                     : edge == 4 ? 045763201u : edge == 5 ? 056470312u : edge == 6 ? 067541023u : edge == 7 ? 074652130u
+                     : edge == 8 ? 004372615u : edge == 9 ? 015043726u : edge == 10 ? 026150437u : 037261504u;
+    const double p = lw_pick(v, (E >> 21) & 7), q = lw_pick(v, (E >> 18) & 7);
+    const double b0 = lw_pick(v, (E >> 15) & 7), b1 = lw_pick(v, (E >> 12) & 7), c0 = lw_pick(v, (E >> 9) & 7),
+                 c1 = lw_pick(v, (E >> 6) & 7), d0 = lw_pick(v, (E >> 3) & 7), d1 = lw_pick(v, E & 7);
+    t = p / (p - q + LT_MC_EPS);
+    Bt = b0 + (b1 - b0) * t;
+    Ct = c0 + (c1 - c0) * t;
+    Dt = d0 + (d1 - d0) * t;
+  }
+  const int test = (At >= 0 ? 1 : 0) | (Bt >= 0 ? 2 : 0) | (Ct >= 0 ? 4 : 0) | (Dt >= 0 ? 8 : 0);
+  // 0 1 2 3 4 6 8 9 12 -> s > 0;  7 11 13 14 15 -> s < 0;  5 / 10: the saddle's sign, else scikit-image's fall-through (0)
+  if ((0x135Fu >> test) & 1u) return s > 0;
+  if (test == 5) return (At * Ct - Bt * Dt < LT_MC_EPS) ? s > 0 : false;
+  if (test == 10) return (At * Ct - Bt * Dt >= LT_MC_EPS) ? s > 0 : false;
+  return s < 0;
+}
+// a tiling = its rows's offset in LT_LWF | triangles << 16 | uses the centre vertex << 20
+#define LWT(T, row) ((unsigned)(LT_LWF_##T + (row) * LT_LWF_##T##_LEN) | ((unsigned)(LT_LWF_##T##_LEN / 3) << 16) | ((unsigned)LT_LWF_##T##_C << 20))
+// v[p]: the cell's values in Lewiner's corner order; cs: the device's case index (an AMBIGUOUS one: LT_LWC_FIXED[cs] == ~0)
+__device__ __noinline__ unsigned lw_select(const double* v, int cs) {
+  const int c = LT_LWC_CASE[cs], g = LT_LWC_CONFIG[cs];
+  int sub = 0;
+  switch (c) {
+    case 3: return lw_test_face(v, LT_LWD_TEST3[g]) ? LWT(TILING3_2, g) : LWT(TILING3_1, g);
+    case 4: return lw_test_interior(v, -1, LT_LWD_TEST4[g]) ? LWT(TILING4_1, g) : LWT(TILING4_2, g);
+    case 6:
+      if (lw_test_face(v, LT_LWD_TEST6[g][0])) return LWT(TILING6_2, g);
+      return lw_test_interior(v, LT_LWD_TEST6[g][2], LT_LWD_TEST6[g][1]) ? LWT(TILING6_1_1, g) : LWT(TILING6_1_2, g);
+    case 7:
+      if (lw_test_face(v, LT_LWD_TEST7[g][0])) sub += 1;
+      if (lw_test_face(v, LT_LWD_TEST7[g][1])) sub += 2;
+      if (lw_test_face(v, LT_LWD_TEST7[g][2])) sub += 4;
+      switch (sub) {
+        case 0: return LWT(TILING7_1, g);
+        case 1: return LWT(TILING7_2, g * 3 + 0);
+        case 2: return LWT(TILING7_2, g * 3 + 1);
+        case 3: return LWT(TILING7_3, g * 3 + 0);
+        case 4: return LWT(TILING7_2, g * 3 + 2);
+        case 5: return LWT(TILING7_3, g * 3 + 1);
+        case 6: return LWT(TILING7_3, g * 3 + 2);
+        default: return lw_test_interior(v, LT_LWD_TEST7[g][4], LT_LWD_TEST7[g][3]) ? LWT(TILING7_4_2, g) : LWT(TILING7_4_1, g);
+      }
+    case 10:
+      if (lw_test_face(v, LT_LWD_TEST10[g][0])) return lw_test_face(v, LT_LWD_TEST10[g][1]) ? LWT(TILING10_1_1_, g) : LWT(TILING10_2, g);
+      if (lw_test_face(v, LT_LWD_TEST10[g][1])) return LWT(TILING10_2_, g);
+      return lw_test_interior(v, -1, LT_LWD_TEST10[g][2]) ? LWT(TILING10_1_1, g) : LWT(TILING10_1_2, g);
+    case 12:
+      if (lw_test_face(v, LT_LWD_TEST12[g][0])) return lw_test_face(v, LT_LWD_TEST12[g][1]) ? LWT(TILING12_1_1_, g) : LWT(TILING12_2, g);
+      if (lw_test_face(v, LT_LWD_TEST12[g][1])) return LWT(TILING12_2_, g);
+      return lw_test_interior(v, LT_LWD_TEST12[g][3], LT_LWD_TEST12[g][2]) ? LWT(TILING12_1_1, g) : LWT(TILING12_1_2, g);
+    case 13: {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (lw_test_face(v, LT_LWD_TEST13[g][k])) sub += 1 << k;
+      const int sc = LT_LWD_SUBCONFIG13[sub];
+      if (sc < 0) return 0u;  // "Impossible case 13?": nothing is added
+      if (sc == 0) return LWT(TILING13_1, g);
+      if (sc <= 6) return LWT(TILING13_2, g * 6 + sc - 1);
+      if (sc <= 18) return LWT(TILING13_3, g * 12 + sc - 7);
+      if (sc <= 22) return LWT(TILING13_4, g * 4 + sc - 19);
+      if (sc <= 26)
+        return lw_test_interior(v, LT_LWD_EDGE13_5[g][sc - 23], LT_LWD_TEST13[g][6]) ? LWT(TILING13_5_1, g * 4 + sc - 23)
+                                                                                        : LWT(TILING13_5_2, g * 4 + sc - 23);
+      if (sc <= 38) return LWT(TILING13_3_, g * 12 + sc - 27);
+      if (sc <= 44) return LWT(TILING13_2_, g * 6 + sc - 39);
+      return LWT(TILING13_1_, g);
+    }
+    default: return 0u;
+  }
+}
+// the tiling of the cell at voxel (x, y, z) with case index cs: the table's for the cases without a test, else the tests
+// on the cell's eight values (Lewiner's corner p sits at (a0, a1, a2) = LW_CORNER[p] of the generator / the oracle:
+// 0 (0,0,0)  1 (0,0,1)  2 (0,1,1)  3 (0,1,0)  4 (1,0,0)  5 (1,0,1)  6 (1,1,1)  7 (1,1,0) -- scikit-image's x is the last axis)
+__device__ __forceinline__ unsigned lw_cell(const float* __restrict__ tsdf, int ny, int nz, int x, int y, int z, int cs) {
+  const unsigned fixed = LT_LWC_FIXED[cs];
+  if (fixed != 0xFFFFFFFFu) return fixed;
+  const size_t sy = (size_t)nz, sx = (size_t)ny * nz;
+  const float* c = tsdf + (size_t)x * sx + (size_t)y * sy + z;
+  double v[8];
+  v[0] = (double)c[0];       v[1] = (double)c[1];           v[2] = (double)c[sy + 1];      v[3] = (double)c[sy];
+  v[4] = (double)c[sx];      v[5] = (double)c[sx + 1];      v[6] = (double)c[sx + sy + 1]; v[7] = (double)c[sx + sy];
+  return lw_select(v, cs);
+}
+#define LW_NT(sel) (((sel) >> 16) & 15u)
+#define LW_C(sel) (((sel) >> 20) & 1u)
+#define LW_OFF(sel) ((sel) & 0xFFFFu)
 
 // debug (-DLT_MC_STAMP=1: k_mc_words, =2: k_mc_compact; tools/mc_wave_times.py): wall clock (100 MHz) at the start of a wave,
 // after its stamp ballot and at its end, and the number of blocks it walked
@@ -77,7 +205,7 @@ __device__ __forceinline__ int mc_row_of(const mc_dims& D, int w) {
 }
 
 struct mc_rec {  // one per active word
-  int w, vbase, tbase, pad;  // pad: the word's triangle count
+  int w, vbase, tbase, pad;  // pad: the word's triangle count | its number of centre vertices << 16
   u64 ex, ey, ez;
 };
 
@@ -96,8 +224,6 @@ struct lt_mesh {
   int* wave_na; size_t cap_wave_na;     // active words per wave of 64 rows (k_mc_words -> k_mc_compact)
   float ms_signs, ms_rest;              // last extraction (when timed)
   hipEvent_t ev[3];
-  const u64* case_table;                // [512] the 256-case triangulation the emit kernels read (LT_MC_PACKED's layout):
-  u64* case_table_own;                  //   the built-in table, or this mesh's own copy (lt_mesh_set_case_table)
 };
 
 // ---- k_mc_signs ----------------------------------------------------------------------------------------------------
@@ -132,7 +258,7 @@ __global__ __launch_bounds__(256) void k_mc_signs(const float* __restrict__ tsdf
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const u64 w = __ballot(v[k] < 0.0f);  // level 0; NaN is "not inside"
+          const u64 w = __ballot(!(v[k] > 0.0f));  // level 0: the bit says "NOT above the level" (Lewiner's index bit, inverted)
           if (lane == 0 && k0 + k < D.wz) bits[(size_t)r * D.wz + k0 + k] = w;
         }
       }
@@ -254,14 +380,17 @@ __device__ __forceinline__ bool mc_block_live(const unsigned* __restrict__ chunk
   return any;
 }
 
-__global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
+__global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf, const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
                                                   unsigned epoch, const unsigned* __restrict__ chunk_epoch,
                                                   int* __restrict__ wave_na, int n_blocks) {
   const int n_rows = D.nx * D.ny;
   const int n_chunks = (n_rows + 63) / 64;
   __shared__ unsigned char s_nt[256];  // triangles per case: the loops below look it up once per active cell, a chain of
-  s_nt[threadIdx.x] = LT_MC_NTRIS[threadIdx.x];  // dependent loads that is three times shorter through LDS
+  {                                    // dependent loads that is three times shorter through LDS.  0x80: an ambiguous case of
+    const unsigned fx = LT_LWC_FIXED[threadIdx.x];  // Lewiner's (3, 4, 6, 7, 10, 12, 13) -- the cell's eight VALUES decide
+    s_nt[threadIdx.x] = fx == 0xFFFFFFFFu ? 0x80 : (unsigned char)LW_NT(fx);  // (lw_cell; 1-2 % of a street scene's cells)
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -297,8 +426,13 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
 #ifndef LT_MC_HEAVY
 #define LT_MC_HEAVY 16  // (swept on the default volume: 2: 50 us, 4: 39, 6: 38, 10 .. 24: 32-33, 40: 35, never: 39)
 #endif
-  auto count_tris = [&](const mc_masks& M) -> unsigned {  // (called by all 64 lanes)
+  // -> triangles | centre vertices << 16 of the word k of this lane's row
+  auto count_tris = [&](const mc_masks& M, int k) -> unsigned {  // (called by all 64 lanes)
     unsigned t = 0;
+    auto ambiguous = [&](int b, unsigned cs) -> unsigned {  // triangles | centre vertex << 16 of the cell at bit b
+      const unsigned sel = lw_cell(tsdf, D.ny, D.nz, x, y, k * 64 + b, (int)cs);
+      return LW_NT(sel) | (LW_C(sel) << 16);
+    };
     const bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
     if (!heavy) {
       // the word's halves one after the other: with 32-bit masks a cell is 8 x (v_bfe_u32, v_lshl_or_b32) + a 32-bit
@@ -316,7 +450,8 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
           unsigned cs = 0;
 #pragma unroll
           for (int i = 0; i < 8; ++i) cs |= ((m[i] >> b) & 1u) << i;
-          t += s_nt[cs];
+          const unsigned n = s_nt[cs];
+          t += (n & 0x80u) ? ambiguous(32 * h + b, cs) : n;
         }
       }
     }
@@ -332,8 +467,14 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
       }
       const u64 ac = (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)M.ac, r) |
                      ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(M.ac >> 32), r) << 32);
-      const unsigned n = ((ac >> lane) & 1ull) ? s_nt[cs] : 0u;  // (<= 5)
-      const unsigned tot = __popcll(__ballot(n & 1u)) + 2u * __popcll(__ballot(n & 2u)) + 4u * __popcll(__ballot(n & 4u));
+      unsigned n = ((ac >> lane) & 1ull) ? s_nt[cs] : 0u;  // (<= 12, or the marker)
+      if (n & 0x80u) {  // (the OWNER's x, y, k: broadcast like its masks)
+        const int xr = __builtin_amdgcn_readlane(x, r), yr = __builtin_amdgcn_readlane(y, r);
+        const unsigned sel = lw_cell(tsdf, D.ny, D.nz, xr, yr, k * 64 + lane, cs);
+        n = LW_NT(sel) | (LW_C(sel) << 16);
+      }
+      const unsigned tot = __popcll(__ballot(n & 1u)) + 2u * __popcll(__ballot(n & 2u)) + 4u * __popcll(__ballot(n & 4u)) +
+                           8u * __popcll(__ballot(n & 8u)) + ((unsigned)__popcll(__ballot(n >> 16)) << 16);
       if (lane == r) t = tot;
     }
     return t;
@@ -359,8 +500,8 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) { w8[q] = w[q][k]; w8[q | 4] = w[q][k + 1]; }
       const mc_masks M = mc_build(w8, D, x, y, k);  // (a row that is not live holds zeros: no edge, no cell)
-      const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
-      const unsigned t = count_tris(M);
+      const unsigned tc = count_tris(M, k), t = tc & 0xFFFFu;
+      const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez) + (tc >> 16);
       if (rowlive) cnt[(size_t)row * D.wz + k] = v | (t << 16);
       na += (v | t) ? 1u : 0u; nv += v; nt += t;
     }
@@ -368,12 +509,12 @@ __global__ __launch_bounds__(256) void k_mc_words(const u64* __restrict__ bits, 
   for (int k = 0; k < D.wz; ++k) {
     mc_masks M = mc_load(bits, D, x, y, k);
     if (!rowlive) { M.ex = M.ey = M.ez = M.ac = 0ull; }
-    const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez);
-    const unsigned t = count_tris(M);
+    const unsigned tc = count_tris(M, k), t = tc & 0xFFFFu;
+    const unsigned v = __popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez) + (tc >> 16);
     if (rowlive) cnt[(size_t)row * D.wz + k] = v | (t << 16);
     na += (v | t) ? 1u : 0u; nv += v; nt += t;
   }
-  u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 320 triangles -- the host checks wz)
+  u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 768 triangles -- the host checks wz)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
   if (lane == 0) {
@@ -492,8 +633,9 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
         r.w = w;
         r.vbase = vb;
         r.tbase = tb;
-        r.pad = (int)(c >> 16);  // triangles of the word (k_mc_emit_batch: the extent of a batch)
         r.ex = M.ex; r.ey = M.ey; r.ez = M.ez;
+        // triangles of the word (k_mc_emit_batch: the extent of a batch) | its centre vertices << 16
+        r.pad = (int)((c >> 16) | (((c & 0xFFFFu) - (unsigned)(__popcll(M.ex) + __popcll(M.ey) + __popcll(M.ez))) << 16));
         rec[ci] = r;
         mine_ci = ci;
       }
@@ -511,139 +653,11 @@ struct mc_nb { u64 ex, ey, ez; int vbase; int have; };
 // float32 vertex coordinate along the edge from lattice coordinate c (value v1) to c + 1 (value v2): scikit-image's
 // centre-of-mass rule (Cell._add_face_from_edge_index), evaluated in double, stored as float32
 // (its `FLT_EPSILON` is, despite the name, `np.spacing(1.0)` = 2^-52 -- a double; C's FLT_EPSILON, 1.19e-7, would move
-// every vertex by ~1e-7 voxel and exact-zero samples visibly.  Still PARITY UNPINNED: no scikit-image output to check.)
-#define LT_MC_EPS 2.220446049250313e-16
+// every vertex by ~1e-7 voxel and exact-zero samples visibly.  Pinned: golden F10 of the real scikit-image, bit for bit.)
 __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
   const double w1 = 1.0 / (LT_MC_EPS + fabs((double)v1));
   const double w2 = 1.0 / (LT_MC_EPS + fabs((double)v2));
   return (float)((double)c + w2 / (w1 + w2));
-}
-
-__global__ __launch_bounds__(64) void k_mc_emit(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
-                                                const float* __restrict__ rem_vol, const u64* __restrict__ bits,
-                                                mc_dims D, const int* __restrict__ cmap,
-                                                const mc_rec* __restrict__ rec, int n_active, float voxel_size,
-                                                float ox, float oy, float oz, float* __restrict__ verts,
-                                                int* __restrict__ faces, int* __restrict__ colors,
-                                                float* __restrict__ rem, int cap_v, int cap_f,
-                                                const ulonglong2* __restrict__ case_table) {
-  // One wave per workgroup (the barrier below is a wave barrier); the kernel is a chain of dependent memory round
-  // trips per wave, so the loads that depend on the record only -- sign words, neighbour indices, field values -- are
-  // all issued before the first of them is needed: record -> {bits, cmap, tsdf} -> {neighbour records, attributes} ->
-  // stores (it was six levels deep: 335 us on the default volume).
-  __shared__ mc_nb nb[8];
-  const int b = threadIdx.x;
-  const int ci = blockIdx.x;
-  if (ci >= n_active) return;
-  const mc_rec R = rec[ci];
-  const int row = R.w / D.wz, wz = R.w - row * D.wz;
-  const int x = row / D.ny, y = row - x * D.ny;
-  const int z = wz * 64 + b;
-  const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
-  const size_t i = (size_t)x * sx + (size_t)y * sy + z;
-  // (a) sign words of the cell corners
-  const mc_masks M = mc_load(bits, D, x, y, wz);
-  // (b) compact index of the (up to) 8 words a triangle of this word's cells can reference: slot = dx | dy << 1 | dwz << 2
-  int c2 = -1;
-  if (b < 8) {
-    const int dx = b & 1, dy = (b >> 1) & 1, dw = b >> 2;
-    if (x + dx < D.nx && y + dy < D.ny && wz + dw < D.wz)
-      c2 = b == 0 ? ci : cmap[((x + dx) * D.ny + (y + dy)) * D.wz + wz + dw];
-  }
-  // (c) field values at the two ends of the edges this lane's voxel owns
-  const int fx = (int)((R.ex >> b) & 1ull), fy = (int)((R.ey >> b) & 1ull), fz = (int)((R.ez >> b) & 1ull);
-  float v0 = 0.f, v1[3] = {0.f, 0.f, 0.f};
-  if (fx | fy | fz) v0 = tsdf[i];
-  if (fx) v1[0] = tsdf[i + sx];
-  if (fy) v1[1] = tsdf[i + sy];
-  if (fz) v1[2] = tsdf[i + 1];
-  // (d) the neighbour records
-  if (b < 8) {
-    mc_nb e;
-    e.ex = e.ey = e.ez = 0; e.vbase = 0; e.have = 0;
-    if (c2 >= 0) {
-      const mc_rec r2 = rec[c2];
-      e.ex = r2.ex; e.ey = r2.ey; e.ez = r2.ez; e.vbase = r2.vbase; e.have = 1;
-    }
-    nb[b] = e;
-  }
-  const u64 lm = (1ull << b) - 1ull;
-  // ---- vertices of the edges this lane's voxel owns
-  if (fx | fy | fz) {
-    int vid = R.vbase + __popcll(R.ex & lm) + __popcll(R.ey & lm) + __popcll(R.ez & lm);
-    size_t jj[3] = {0, 0, 0};
-    float pp[3][3];
-    float rgbv[3] = {0.f, 0.f, 0.f}, remv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int f = a == 0 ? fx : (a == 1 ? fy : fz);
-      pp[a][0] = (float)x; pp[a][1] = (float)y; pp[a][2] = (float)z;
-      if (!f) continue;
-      pp[a][a] = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1[a]);
-      // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
-      // (clamped: a NaN field value must not become a wild address; numpy would raise there)
-      const int i0 = min(max((int)rintf(pp[a][0]), 0), D.nx - 1), i1 = min(max((int)rintf(pp[a][1]), 0), D.ny - 1),
-                i2 = min(max((int)rintf(pp[a][2]), 0), D.nz - 1);
-      jj[a] = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
-      rgbv[a] = color_vol[jj[a]];
-      remv[a] = rem_vol[jj[a]];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int f = a == 0 ? fx : (a == 1 ? fy : fz);
-      if (!f) continue;
-      if (vid < cap_v) {
-        // verts * voxel_size + vol_origin in float32 (:412)
-        verts[3 * (size_t)vid] = pp[a][0] * voxel_size + ox;
-        verts[3 * (size_t)vid + 1] = pp[a][1] * voxel_size + oy;
-        verts[3 * (size_t)vid + 2] = pp[a][2] * voxel_size + oz;
-        // colour unfolding (:419-423) in float32, .astype(np.uint8) = truncation to 8 bits
-        const float rgb = rgbv[a];
-        const float cb = floorf(rgb / (float)(256 * 256));
-        const float cg = floorf((rgb - cb * 256.0f * 256.0f) / 256.0f);
-        const float cr = rgb - cb * 256.0f * 256.0f - cg * 256.0f;
-        colors[3 * (size_t)vid] = (int)floorf(cr) & 255;
-        colors[3 * (size_t)vid + 1] = (int)floorf(cg) & 255;
-        colors[3 * (size_t)vid + 2] = (int)floorf(cb) & 255;
-        rem[vid] = remv[a];
-      }
-      ++vid;
-    }
-  }
-  __syncthreads();  // nb[] is complete (one wave: a wave barrier)
-  // ---- triangles of this lane's cell (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz: nb[3] / [4] are there)
-  // the lane's whole cell in one 128-bit load: triangle count + 15 five-bit edge codes (LT_MC_PACKED)
-  u64 pk0 = 0, pk1 = 0;
-  if ((M.ac >> b) & 1ull) {
-    const ulonglong2 pk = case_table[mc_case(M, b)];
-    pk0 = pk.x; pk1 = pk.y;
-  }
-  const int nt = (int)(pk0 & 7ull);
-  int inc = nt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int q = __shfl_up(inc, o, 64);
-    if (b >= o) inc += q;
-  }
-  const int tid0 = R.tbase + inc - nt;
-#pragma unroll
-  for (int t = 0; t < LT_MC_MAX_TRIS; ++t) {
-    if (t >= nt || tid0 + t >= cap_f) break;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int sh = 8 + 5 * (3 * t + k);  // compile-time constant after unrolling
-      const int code = (int)((sh < 64 ? (sh + 5 <= 64 ? (pk0 >> sh) : ((pk0 >> sh) | (pk1 << (64 - sh)))) : (pk1 >> (sh - 64))) & 31ull);
-      const int c0 = code & 7, a = code >> 3;
-      int b2 = b + ((c0 >> 2) & 1), slot = c0 & 3;
-      if (b2 == 64) { b2 = 0; slot |= 4; }
-      const mc_nb& e = nb[slot];
-      const u64 l2 = (1ull << b2) - 1ull;
-      int id = e.vbase + __popcll(e.ex & l2) + __popcll(e.ey & l2) + __popcll(e.ez & l2);
-      if (a > 0) id += (int)((e.ex >> b2) & 1ull);
-      if (a > 1) id += (int)((e.ey >> b2) & 1ull);
-      faces[3 * (size_t)(tid0 + t) + k] = id;
-    }
-  }
 }
 
 // ---- k_mc_emit_batch: one wave per K consecutive active words, one lane per VERTEX / per TRIANGLE ----------------------------
@@ -662,18 +676,18 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
                                                       const mc_rec* __restrict__ rec, int n_active, float voxel_size,
                                                       float ox, float oy, float oz, float* __restrict__ verts,
                                                       int* __restrict__ faces, int* __restrict__ colors,
-                                                      float* __restrict__ rem, int cap_v, int cap_f,
-                                                      const ulonglong2* __restrict__ case_table) {
+                                                      float* __restrict__ rem, int cap_v, int cap_f) {
   static_assert(K <= 16, "list entries hold the word in 4 bits");
   __shared__ mc_rec s_rec[K];
   __shared__ int s_xyz[K][3];       // x, y, wz of the words
   __shared__ u64 s_sg[K][8];        // sign words of the cell corners, [dx | dy << 1 | dw << 2]
   __shared__ mc_nb s_nb[K][8];      // records of the 8 words a cell's triangles can reference
   __shared__ u64 s_cm[K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
-  __shared__ unsigned short s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10 (12 bits)
-  __shared__ unsigned s_tl[LT_MC_TCAP];  // triangle j of the window: k | b << 4 | t << 10 | case << 13
-  __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | case << 13
-  __shared__ unsigned short s_ct[K * 64];  // ... and the (batch-relative) index of their first triangle (< 16 x 64 x 5)
+  __shared__ unsigned short s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10 (12 bits; axis 3 = the cell's centre vertex)
+  __shared__ unsigned short s_tl[LT_MC_TCAP];  // triangle j of the window: index into s_cl | t << 10
+  __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | triangles << 10 | centre << 14 | tiling offset << 15
+  __shared__ unsigned short s_ct[K * 64];  // ... and the (batch-relative) index of their first triangle (< 16 x 64 x 12)
+  __shared__ u64 s_ccm[K];               // the words' cells that own a centre vertex
   __shared__ int s_cpre[K + 1];          // active cells before word k
   const int lane = threadIdx.x;
   // (a wave takes batches until none is left; by default the grid has a wave per batch -- see the launch)
@@ -740,14 +754,75 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     }
     if (lane < nw) s_cpre[lane + 1] = c;
     if (lane == 0) s_cpre[0] = 0;
+    if (lane < K) s_ccm[lane] = 0ull;
     (void)mine;
   }
   __syncthreads();
   const mc_rec first = s_rec[0], last = s_rec[nw - 1];
   const int vbase0 = first.vbase, tbase0 = first.tbase;
-  const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) - vbase0;
-  const int ntt = last.tbase + last.pad - tbase0;
+  const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) + (last.pad >> 16) - vbase0;
+  const int ntt = last.tbase + (last.pad & 0xFFFF) - tbase0;
 #if defined(LT_MC_STOP) && LT_MC_STOP == 1  // instruction-count experiment (tools/mc_sections.sh): staging only
+  continue;
+#endif
+  // ---- the batch's active cells in order (word, z) with their TILING, and the (batch-relative) index of every cell's first
+  // triangle: a lane takes one (word, SEGMENT of 8 voxels) pair, lists the cells of its 8 voxels (the word's cell base + a
+  // popcount below the segment) -- case index from the corner masks, tiling from the table or, for Lewiner's ambiguous cases,
+  // from the tests on the cell's eight values (lw_cell) -- and adds up their triangle counts; ONE wave scan over the lanes
+  // turns the sums into offsets, and the lane hands them to its cells.  The cells whose tiling has a centre vertex are
+  // collected per word (s_ccm): their vertices follow the word's edge vertices in the output.
+  const int ncell = s_cpre[nw];  // (wave-uniform)
+  constexpr int NPV = (8 * K + 63) / 64;
+  {
+    int run = 0;  // triangles of the pairs before this round of 64
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int p = lane + 64 * i, k = p >> 3, seg = p & 7;
+      unsigned ac8 = 0, ntp = 0;  // ntp: the triangle counts of the segment's cells, 4 bits each, in cell order
+      int c0 = 0, tsum = 0;
+      if (k < nw) {
+        const u64 ac = s_cm[k][8];
+        ac8 = (unsigned)(ac >> (8 * seg)) & 255u;
+        if (ac8) {
+          c0 = s_cpre[k] + __popcll(ac & ((1ull << (8 * seg)) - 1ull));
+          unsigned m8[8];  // the corner masks' bits of this segment
+#pragma unroll
+          for (int q = 0; q < 8; ++q) m8[q] = (unsigned)(s_cm[k][q] >> (8 * seg)) & 255u;
+          int c = c0, sh = 0;
+          unsigned cm8 = 0;
+          for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, sh += 4) {
+            const int bb = __ffs((int)a8) - 1;
+            unsigned cs = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
+            const unsigned sel = lw_cell(tsdf, D.ny, D.nz, s_xyz[k][0], s_xyz[k][1], s_xyz[k][2] * 64 + 8 * seg + bb, (int)cs);
+            const unsigned nt = LW_NT(sel);
+            s_cl[c] = (unsigned)k | ((unsigned)(8 * seg + bb) << 4) | (nt << 10) | (LW_C(sel) << 14) | (LW_OFF(sel) << 15);
+            cm8 |= LW_C(sel) << bb;
+            ntp |= nt << sh;
+            tsum += (int)nt;
+          }
+          if (cm8) atomicOr((unsigned long long*)&s_ccm[k], (unsigned long long)cm8 << (8 * seg));
+        }
+      }
+      int inc = tsum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int q = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += q;
+      }
+      int t0 = run + inc - tsum;
+      int c = c0;
+      for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, ntp >>= 4) {
+        s_ct[c] = (unsigned short)t0;
+        t0 += (int)(ntp & 15u);
+      }
+      run += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  LT_MC_SECTION(5);  // cell masks, cell list, triangle offsets
+#if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
   continue;
 #endif
   // ---- vertices
@@ -757,7 +832,6 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   // is short where the batch is sparse and costs what a lane-per-voxel pass costs where it is dense (walls along z), so one
   // path serves both -- the lane-per-ITEM search it replaces (word by the bases, voxel by a 6-step binary search over
   // three 64-bit popcounts) was 277 vector instructions per batch.
-  constexpr int NPV = (8 * K + 63) / 64;
   for (int vb = 0; vb < nvt; vb += LT_MC_VCAP) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
@@ -779,6 +853,16 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
             if ((ez8 >> bb) & 1u) { if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)(e | (2u << 10)); ++j; }
           }
         }
+        // the centre vertices of the segment's cells: after all edge vertices of the word, in cell order
+        const u64 ccm = s_ccm[k];
+        unsigned cm8 = (unsigned)(ccm >> (8 * seg)) & 255u;
+        if (cm8) {
+          int j = R.vbase - vbase0 - vb + __popcll(R.ex) + __popcll(R.ey) + __popcll(R.ez) + __popcll(ccm & ((1ull << (8 * seg)) - 1ull));
+          for (; cm8; cm8 &= cm8 - 1u, ++j) {
+            const int bb = __ffs((int)cm8) - 1;
+            if ((unsigned)j < LT_MC_VCAP) s_vl[j] = (unsigned short)((unsigned)k | ((unsigned)(8 * seg + bb) << 4) | (3u << 10));
+          }
+        }
       }
     }
     __syncthreads();
@@ -792,11 +876,26 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       const int k = e & 15, b = (e >> 4) & 63, a = (e >> 10) & 3;
       const int x = s_xyz[k][0], y = s_xyz[k][1], z = s_xyz[k][2] * 64 + b;
       const size_t i = (size_t)x * sx + (size_t)y * sy + z;
-      const float v0 = tsdf[i];
-      const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : (size_t)1))];
       float p0 = (float)x, p1 = (float)y, p2 = (float)z;
-      const float pe = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
-      if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+      if (a == 3) {
+        // the cell's centre vertex (Cell.calculate_center_vertex): the centre of mass of the eight corners with weights
+        // 1 / (eps + |v|), summed in Lewiner's corner order (0 .. 7) in double, stored as float32
+        const float* c = tsdf + i;
+        const double w0 = 1.0 / (LT_MC_EPS + fabs((double)c[0])), w1 = 1.0 / (LT_MC_EPS + fabs((double)c[1])),
+                     w2 = 1.0 / (LT_MC_EPS + fabs((double)c[sy + 1])), w3 = 1.0 / (LT_MC_EPS + fabs((double)c[sy])),
+                     w4 = 1.0 / (LT_MC_EPS + fabs((double)c[sx])), w5 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + 1])),
+                     w6 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + sy + 1])), w7 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + sy]));
+        const double ff = ((((((w0 + w1) + w2) + w3) + w4) + w5) + w6) + w7;
+        const double f2 = ((w1 + w2) + w5) + w6;  // corners with a2 + 1 (scikit-image's x)
+        const double f1 = ((w2 + w3) + w6) + w7;  // ... a1 + 1 (y)
+        const double f0 = ((w4 + w5) + w6) + w7;  // ... a0 + 1 (z)
+        p0 = (float)((double)x + f0 / ff); p1 = (float)((double)y + f1 / ff); p2 = (float)((double)z + f2 / ff);
+      } else {
+        const float v0 = tsdf[i];
+        const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : (size_t)1))];
+        const float pe = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
+        if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+      }
       // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
       // (clamped: a NaN field value must not become a wild address; numpy would raise there)
       const int i0 = min(max((int)rintf(p0), 0), D.nx - 1), i1 = min(max((int)rintf(p1), 0), D.ny - 1),
@@ -825,82 +924,31 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
 #if defined(LT_MC_STOP) && LT_MC_STOP == 3  // ... + vertex pass
   continue;
 #endif
-  // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz)
-  // the batch's active cells in order (word, z) with their case, and the (batch-relative) index of every cell's first
-  // triangle: the same (word, segment) dealing -- a lane lists the cells of its 8 voxels (the word's cell base + a popcount
-  // below the segment) and adds up their triangle counts, ONE wave scan over the lanes turns the sums into offsets, and
-  // the lane hands them to its cells.  (Before: a lane per cell with two searches, then a scan per 64 cells -- 386 vector
-  // instructions per batch, more than any other section of the kernel.)
-  const int ncell = s_cpre[nw];  // (wave-uniform)
-  {
-    int run = 0;  // triangles of the pairs before this round of 64
-#pragma unroll
-    for (int i = 0; i < NPV; ++i) {
-      const int p = lane + 64 * i, k = p >> 3, seg = p & 7;
-      unsigned ac8 = 0, ntp = 0;  // ntp: the triangle counts of the segment's cells, 3 bits each, in cell order
-      int c0 = 0, tsum = 0;
-      if (k < nw) {
-        const u64 ac = s_cm[k][8];
-        ac8 = (unsigned)(ac >> (8 * seg)) & 255u;
-        if (ac8) {
-          c0 = s_cpre[k] + __popcll(ac & ((1ull << (8 * seg)) - 1ull));
-          unsigned m8[8];  // the corner masks' bits of this segment
-#pragma unroll
-          for (int q = 0; q < 8; ++q) m8[q] = (unsigned)(s_cm[k][q] >> (8 * seg)) & 255u;
-          int c = c0, sh = 0;
-          for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, sh += 3) {
-            const int bb = __ffs((int)a8) - 1;
-            unsigned cs = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
-            s_cl[c] = (unsigned)k | ((unsigned)(8 * seg + bb) << 4) | (cs << 13);
-            const unsigned nt = LT_MC_NTRIS[cs];
-            ntp |= nt << sh;
-            tsum += (int)nt;
-          }
-        }
-      }
-      int inc = tsum;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int q = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += q;
-      }
-      int t0 = run + inc - tsum;
-      int c = c0;
-      for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, ntp >>= 3) {
-        s_ct[c] = (unsigned short)t0;
-        t0 += (int)(ntp & 7u);
-      }
-      run += __shfl(inc, 63, 64);
-    }
-  }
-  __syncthreads();
-  LT_MC_SECTION(5);  // cell masks, cell list, triangle offsets
-#if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
-  continue;
-#endif
+  // ---- triangles (cells exist where x + 1 < nx, y + 1 < ny, z + 1 < nz): their cells were listed above
   for (int tb = 0; tb < ntt; tb += LT_MC_TCAP) {
-    for (int c = lane; c < ncell; c += 64) {  // a cell's (up to five) triangles into the window's list
-      const unsigned e = s_cl[c];
-      const int nt = LT_MC_NTRIS[(e >> 13) & 255];
+    for (int c = lane; c < ncell; c += 64) {  // a cell's (up to twelve) triangles into the window's list
+      const int nt = (int)((s_cl[c] >> 10) & 15u);
       const int j0 = (int)s_ct[c] - tb;
       for (int t = 0; t < nt; ++t)
-        if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = e | ((unsigned)t << 10);
+        if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = (unsigned short)((unsigned)c | ((unsigned)t << 10));
     }
     __syncthreads();
     const int nwin = min(LT_MC_TCAP, ntt - tb);
     for (int j = lane; j < nwin; j += 64) {
-      const unsigned e = s_tl[j];
-      const int k = e & 15, b = (e >> 4) & 63, t = (e >> 10) & 7, cs = (e >> 13) & 255;
-      const ulonglong2 pk = case_table[cs];
+      const unsigned tl = s_tl[j];
+      const unsigned e = s_cl[tl & 1023u];
+      const int k = e & 15, b = (e >> 4) & 63, t = (int)(tl >> 10);
+      const unsigned char* codes = LT_LWF + (e >> 15) + 3 * t;  // (already in the reference's order: np.fliplr(faces))
       const int tid = tbase0 + tb + j;
       int id[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const int sh = 8 + 5 * (3 * t + q);
-        const u64 raw = sh < 64 ? ((pk.x >> sh) | (sh > 59 ? (pk.y << (64 - sh)) : 0ull)) : (pk.y >> (sh - 64));
-        const int code = (int)(raw & 31ull);
+        const int code = codes[q];
+        if (code == 31) {  // the cell's centre vertex: behind the word's edge vertices, ranked among the word's centre cells
+          const mc_rec& Rk = s_rec[k];
+          id[q] = Rk.vbase + __popcll(Rk.ex) + __popcll(Rk.ey) + __popcll(Rk.ez) + __popcll(s_ccm[k] & ((1ull << b) - 1ull));
+          continue;
+        }
         const int c0 = code & 7, ax = code >> 3;
         int b2 = b + ((c0 >> 2) & 1), slot = c0 & 3;
         if (b2 == 64) { b2 = 0; slot |= 4; }
@@ -942,54 +990,7 @@ extern "C" int lt_mesh_create(lt_mesh** out, int device) {
     return LT_ERR_NO_MEMORY;
   }
   for (int k = 0; k < 3; ++k) (void)hipEventCreate(&m->ev[k]);
-  if (hipMalloc((void**)&m->case_table_own, sizeof(lt_mc_host::LT_MC_PACKED)) != hipSuccess ||
-      hipMemcpy(m->case_table_own, lt_mc_host::LT_MC_PACKED, sizeof(lt_mc_host::LT_MC_PACKED), hipMemcpyHostToDevice) != hipSuccess) {
-    lt_set_error("lt_mesh_create: cannot upload the case table");
-    if (m->case_table_own) (void)hipFree(m->case_table_own);
-    (void)hipHostFree(m->totals_host);
-    (void)hipGetLastError();
-    free(m);
-    return LT_ERR_NO_MEMORY;
-  }
-  m->case_table = m->case_table_own;
   *out = m;
-  return LT_OK;
-}
-
-// see include/lidarhip.h
-extern "C" int lt_mesh_set_case_table(lt_mesh* m, const unsigned long long* packed) {
-  if (!m) {
-    lt_set_error("lt_mesh_set_case_table: NULL mesh");
-    return LT_ERR_INVALID_ARG;
-  }
-  LT_HIP(hipSetDevice(m->device));
-  const u64* own = (const u64*)lt_mc_host::LT_MC_PACKED;
-  if (!packed) packed = own;
-  // a replacement may re-triangulate the polygons of a case, nothing else: the same number of triangles (the counting
-  // kernels keep using the built-in counts) over the same crossing edges (the vertices exist per crossing edge)
-  for (int c = 0; c < 256; ++c) {
-    const int nt = (int)(own[2 * c] & 7ull);
-    if ((int)(packed[2 * c] & 7ull) != nt) {
-      lt_set_error("lt_mesh_set_case_table: case %d has %d triangles, the table given says %d", c, nt, (int)(packed[2 * c] & 7ull));
-      return LT_ERR_INVALID_ARG;
-    }
-    unsigned have = 0, want = 0;
-    for (int i = 0; i < 3 * nt; ++i) {
-      const int sh = 8 + 5 * i;
-      auto code = [&](const u64* t) {
-        const u64 raw = sh < 64 ? ((t[2 * c] >> sh) | (sh > 59 ? (t[2 * c + 1] << (64 - sh)) : 0ull)) : (t[2 * c + 1] >> (sh - 64));
-        return (unsigned)(raw & 31ull);
-      };
-      want |= 1u << code(own);
-      have |= 1u << code(packed);
-    }
-    if (have != want) {
-      lt_set_error("lt_mesh_set_case_table: case %d references lattice edges that do not cross the surface", c);
-      return LT_ERR_INVALID_ARG;
-    }
-  }
-  LT_HIP(hipDeviceSynchronize());  // (an extraction in flight may still read the previous contents)
-  LT_HIP(hipMemcpy(m->case_table_own, packed, 512 * sizeof(u64), hipMemcpyHostToDevice));
   return LT_OK;
 }
 
@@ -997,7 +998,7 @@ extern "C" int lt_mesh_destroy(lt_mesh* m) {
   if (!m) return LT_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na, m->case_table_own};
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   if (m->totals_host) (void)hipHostFree(m->totals_host);
@@ -1050,6 +1051,12 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   }
   hipStream_t stream = (hipStream_t)stream_;
   LT_HIP(hipSetDevice(m->device));
+  if (nx < 2 || ny < 2 || nz < 2) {  // no cell (scikit-image: "Input array must be at least 2x2x2"): the empty mesh
+    m->n_verts = 0;
+    m->n_faces = 0;
+    if (ms) ms[0] = ms[1] = 0.f;
+    return LT_OK;
+  }
   mc_dims D;
   D.nx = nx; D.ny = ny; D.nz = nz;
   D.wz = (nz + 63) / 64;
@@ -1067,8 +1074,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   D.n_words = (int)n_words;
   const int n_rows = nx * ny;
   const int n_blocks = ((n_rows + 255) / 256) * 4;  // one block of the scan per wave of 64 rows
-  if (D.wz > 48) {  // (the packed per-block totals hold 20 bits a field: 64 rows x wz words x 320 triangles)
-    lt_set_error("lt_marching_cubes_dev: nz = %d exceeds 3072", nz);
+  if (D.wz > 21) {  // (the packed per-block totals hold 20 bits a field: 64 rows x wz words x 768 triangles)
+    lt_set_error("lt_marching_cubes_dev: nz = %d exceeds 1344", nz);
     return LT_ERR_TOO_LARGE;
   }
   if (n_words > m->cap_words || !m->bits) {
@@ -1111,7 +1118,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
   // (a wave takes LT_MC_BLOCKS_PER_WAVE blocks, see k_mc_words)
   const int sweep_wgs = lt_deal_count(n_blocks, LT_MC_BLOCKS_PER_WAVE, ny, 4) / 4;
-  hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
+  hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, tsdf, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
                      epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na, n_blocks);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
   hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
@@ -1160,16 +1167,9 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   }
   hipLaunchKernelGGL(k_mc_compact, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647), m->wave_na, n_blocks);
-  static const bool emit_waves = []() {  // A/B: LIDARHIP_MC_EMIT=waves -> one wave per active word (k_mc_emit)
-    const char* e = getenv("LIDARHIP_MC_EMIT");
-    return e && strcmp(e, "waves") == 0;
-  }();
 #define LT_MC_EMIT_ARGS tsdf, color_vol, rem_vol, bits, D, m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], \
-                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, (const ulonglong2*)m->case_table
-  if (n_active > 0 && emit_waves)
-    hipLaunchKernelGGL(k_mc_emit, dim3(n_active), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-  else if (n_active > 0)
-  {
+                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f
+  if (n_active > 0) {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
     // The grid: persistent waves taking batches in turn (bi += gridDim), twice the resident capacity (18 waves of 8.2 KB
     // LDS per CU, tools/occ_probe.hip).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
 }
 
 // the update of one voxel (fusion_lidar.py:178-228); returns what
-// happened to the voxel's tsdf: 0 untouched, 1 written (not negative), 2 written negative (the sign bit marching cubes
+// happened to the voxel's tsdf: 0 untouched, 1 written (above the level 0), 2 written NOT above it -- <= 0 or NaN -- (the sign bit marching cubes
 // needs, lt_mc.hip)
 // `fresh`: the voxel's column has not been written since the last reset, so the old values are the initial ones
 // (tsdf 1, weight 0, colour 0, remission 0) and need not be loaded
@@ -86,7 +86,7 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
     new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
     color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
     rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
-    return tv < 0.0f ? 2 : 1;
+    return !(tv > 0.0f) ? 2 : 1;
   } else {
     const float dist_old = fresh ? 0.0f : weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
     const float old_color = fresh ? 0.0f : color_vol[voxel_idx];
@@ -97,7 +97,7 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
       const float tv = __fmaf_rn(fresh ? 1.0f : tsdf_vol[voxel_idx], w_old, dist) / w_new;
       tsdf_vol[voxel_idx] = tv;
       rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
-      return tv < 0.0f ? 2 : 1;
+      return !(tv > 0.0f) ? 2 : 1;
     } else if (dist < dist_old) {  // other class: the closer observation wins
       tsdf_vol[voxel_idx] = dist;
       const float new_b = floorf(new_color / (256 * 256));
@@ -105,7 +105,7 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
       const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
       color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
       rem_vol[voxel_idx] = new_rem;
-      return dist < 0.0f ? 2 : 1;
+      return !(dist > 0.0f) ? 2 : 1;
     }
     return 0;
   }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_tsdf_columns(int vol_dim_x, int vol_dim
 // y = dim_y - 1 are always walked, whole: they are where the reference's float voxel index can misplace a voxel into
 // the (x + 1, -1) column, which the table does not describe -- tsdf_voxel() handles every voxel by the reference's own
 // decomposition.  The signs of the values written update the column's sign bits (bit b of word k = voxel z = 64 k + b
-// is negative), which marching cubes reads instead of the float field; a 16-aligned chunk of z lies inside one word and
+// is NOT above the level 0), which marching cubes reads instead of the float field; a 16-aligned chunk of z lies inside one word and
 // only this quarter wave works on this column, so the read-modify-write needs no atomic.
 template <bool MERGE>
 __global__ __launch_bounds__(256) LT_TSDF_WAVES_ATTR void k_tsdf_integrate_cols(
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_tsdf_dct4(tsdf_obs_ptrs O, int n_obs, i
 }
 
 // the n class-aware updates of one voxel of a FRESH volume (fusion_lidar.py:177, :191-228; tsdf_update<true> above, on
-// registers): returns 0 untouched, 1 written (not negative), 2 written negative
+// registers): returns 0 untouched, 1 written (> 0), 2 written not > 0 (the sign bit, as tsdf_update)
 __device__ __forceinline__ int tsdf_updates_fresh(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
                                                    float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
                                                    float depth, float trunc_margin, float obs_weight,
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ int tsdf_updates_fresh(float* __restrict__ tsdf_vol, 
   weight_vol[voxel_idx] = wv;
   color_vol[voxel_idx] = cv;
   rem_vol[voxel_idx] = rv;
-  return tv < 0.0f ? 2 : 1;
+  return !(tv > 0.0f) ? 2 : 1;
 }
 
 // tsdf_voxel's geometry (the reference's expressions, :95-146), then the n updates; want_py as there

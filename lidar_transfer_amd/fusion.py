@@ -288,20 +288,6 @@ class DeviceMesh:
         self._h = h
         self.last_ms = None
 
-    def set_case_table(self, packed=None):
-        """Replace the 256-case triangulation table of the extraction (``lt_mesh_set_case_table``): ``packed`` = 512
-        64-bit words in ``LT_MC_PACKED``'s layout (``None`` restores the built-in table).  Only re-triangulations of a
-        case's polygons are accepted.  Used to bound the divergence from the reference's scikit-image table
-        (DESIGN.md section 7c)."""
-        C = self._C
-        arr = None
-        if packed is not None:
-            packed = [int(x) for x in packed]
-            if len(packed) != 512:
-                raise ValueError("set_case_table: 512 words (two per case)")
-            arr = (C.c_ulonglong * 512)(*packed)
-        self._libmod.check(self._lib.lt_mesh_set_case_table(self._h, arr), "lt_mesh_set_case_table")
-
     def close(self):
         if getattr(self, "_h", None):
             self._lib.lt_mesh_destroy(self._h)

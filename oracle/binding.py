@@ -212,22 +212,13 @@ def tsdf_integrate(vols, dims, origin, voxel_size, fov_up, fov_down, color_im, d
                            *[x.ctypes.data_as(fp) for x in ims], int(bool(merge)))
 
 
-def marching_cubes_lewiner(tsdf, color_vol, rem_vol, voxel_size, origin):
+def marching_cubes(tsdf, color_vol, rem_vol, voxel_size, origin):
     """``get_mesh`` (fusion_lidar.py:403-424) = scikit-image 0.18's ``marching_cubes_lewiner`` + the attribute look-ups,
-    restated in oracle/lt_mc_oracle.c (``lto_mc_lewiner``): the SAME ARRAYS as the reference returns -- vertices and faces,
-    values and order (golden F10 of the real scikit-image; tools/mc_lewiner_fuzz.py)."""
-    return marching_cubes(tsdf, color_vol, rem_vol, voxel_size, origin, _entry="lto_mc_lewiner")
-
-
-def marching_cubes(tsdf, color_vol, rem_vol, voxel_size, origin, _entry="lto_marching_cubes"):
-    """``get_mesh`` restatement (oracle/lt_mc_oracle.c; fusion_lidar.py:403-424): returns
+    restated in oracle/lt_mc_oracle.c: the SAME ARRAYS as the reference returns -- vertices and faces, values and order
+    (golden F10 of the real scikit-image; tools/mc_lewiner_fuzz.py).  Returns
     ``(verts [V,3] f32 world, faces [F,3] i32, colors [V,3] i32 (r, g, b after the uint8 wrap), rem [V] f32)``."""
     lib = _lib()
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-    if _entry != "lto_marching_cubes":
-        class _Alias:  # (same signature; the classic entry stays until the device path is switched)
-            lto_marching_cubes = getattr(lib, _entry)
-        lib = _Alias
     lib.lto_marching_cubes.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int,
                                        C.c_int, ip, ip]
     lib.lto_marching_cubes.restype = C.c_int

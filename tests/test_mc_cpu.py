@@ -137,7 +137,7 @@ def test_lewiner_oracle_returns_the_arrays_of_the_reference_get_mesh(case):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"f10_mc_{case}.npz"))
     assert str(g["skimage_version"]).startswith("0.18") and not bool(g["used_alias"])
     tsdf, color, rem, vs, org = pin_cases.mc_case(case)
-    v, f, c, r = ob.marching_cubes_lewiner(tsdf, color, rem, vs, org)[:4]
+    v, f, c, r = ob.marching_cubes(tsdf, color, rem, vs, org)[:4]
     assert v.shape == g["verts"].shape and f.shape == g["faces"].shape
     assert np.array_equal(v.view(np.int32), g["verts"].view(np.int32))
     assert np.array_equal(f, g["faces"])

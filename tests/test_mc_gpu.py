@@ -1,9 +1,10 @@
 """Marching cubes on the device (replaces TSDFVolume.get_mesh, fusion_lidar.py:403-424).
 
-PARITY UNPINNED against scikit-image (the reference's dependency is not importable here).  Checked: the HIP path is
-bit-identical -- vertex order, positions, faces, colours, remissions -- to the CPU oracle (oracle/lt_mc_oracle.c,
-itself property-tested in tests/test_mc_cpu.py), on every word-layout corner case of the sign bitmask; and the whole
-fusion -> mesh -> range image chain runs without the mesh leaving HBM and equals the host-mesh drop-in call."""
+PINNED to scikit-image 0.18.3 (the reference's dependency): the CPU oracle (oracle/lt_mc_oracle.c) returns the arrays of
+the reference's own get_mesh (golden F10, tests/test_mc_cpu.py), and the HIP path is checked against it here -- the same
+vertices (positions bit for bit, colours, remissions) and the same faces (each face's vertices in the same order), on
+every word-layout corner case of the sign bitmask; element ORDER is the device's own.  And the whole fusion -> mesh ->
+range image chain runs without the mesh leaving HBM and equals the host-mesh drop-in call."""
 import numpy as np
 import pytest
 
@@ -22,13 +23,13 @@ def _gpu_mesh(t, col, rem, vs, org):
 
 
 def _assert_same_mesh(got, want):
-    v, f, c, r = got
-    ov, of, oc, orr = want
-    assert v.shape == ov.shape and f.shape == of.shape, (v.shape, ov.shape, f.shape, of.shape)
-    assert np.array_equal(f, of), "faces"
-    assert np.array_equal(v.view(np.int32), ov.view(np.int32)), "verts"
-    assert np.array_equal(c, oc), "colors"
-    assert np.array_equal(r.view(np.int32), orr.view(np.int32)), "rem"
+    """Device mesh vs the oracle's (= the reference's arrays, golden F10): the same vertices and the same faces, each face's
+    vertices in the same order; the order of the ELEMENTS is the device's own (tests/mesh_canon.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mesh_canon import assert_same_mesh
+    assert_same_mesh(got, want)
 
 
 @pytest.mark.parametrize("shape", [(9, 8, 7), (5, 6, 64), (4, 5, 65), (6, 3, 130), (3, 4, 200), (1, 9, 70), (7, 1, 70),
@@ -327,82 +328,3 @@ def test_bare_lt_fusion_scan_dev_symbol_edge_cases():
     assert mesh.n_faces == 0 and int((out["range"] != 0).sum()) == 0
     del none
     mesh.close(); sc.close(); vol.close(); rs.close()
-
-
-def test_other_diagonals_bound_what_a_different_case_table_can_change(oracle):
-    """Parity of the triangulation is UNPINNED (scikit-image's Lewiner table cannot be read here).  What CAN be bounded: on
-    every case whose polygons are the same -- everything but the ambiguous cases, counted below -- another table can only
-    choose other diagonals inside the same polygons.  Extract the fused street scene twice, with the built-in table and with
-    the table of every polygon's OTHER diagonals (tools/gen_mc_table.py, `triangulate_other`), render both with the target
-    sensor: same vertices, same face count; the hit / miss pattern, the label image and the range all but identical -- a
-    polygon of a cell is within a voxel of flat, so its diagonals move the surface by less than half a voxel; what remains
-    are the rays that graze a silhouette and slip past the surface with one diagonal but not the other (they then hit
-    whatever lies behind: up to metres), a fraction of a per cent that the assertions below bound."""
-    import torch
-    from tools import gen_mc_table as g
-    from lidar_transfer_amd.laserscan import create_rays
-    from lidar_transfer_amd.raytracer import RaySet, Scene
-    vol, (H, W, fu, fd) = _fused_volume()
-    voxel = 0.1
-    dev = torch.device("cuda", 0)
-    HT, WT = 64, 2048
-    rays = torch.from_numpy(create_rays(3.0, -25.0, HT, WT)).to(dev)
-    rs = RaySet(rays, HT)
-    sc = Scene(0)
-    res = {}
-    mesh = None
-    for name, table in (("built_in", None), ("other", g.packed_words("other")), ("built_in_again", None)):
-        mesh = vol.extract_mesh(mesh)
-        if name == "built_in":
-            with pytest.raises(RuntimeError, match="triangles"):     # a table with another triangle count is refused
-                bad = g.packed_words()
-                bad[2 * 1] = (bad[2 * 1] & ~7) | 2
-                mesh.set_case_table(bad)
-        mesh.set_case_table(table)
-        mesh = vol.extract_mesh(mesh)
-        sc.set_device_mesh(mesh)
-        o = sc.render(rs, (0.0, 0.0, 0.0))
-        torch.cuda.synchronize()
-        v, f, c, r = [t.cpu().numpy().copy() for t in mesh.tensors()]
-        res[name] = dict(v=v, f=f, c=c, rng=o["range"].cpu().numpy(), lab=o["endcolors"].cpu().numpy()[:, 2],
-                         tri=o["tri"].cpu().numpy())
-    a, b = res["built_in"], res["other"]
-    assert np.array_equal(a["v"].view(np.int32), b["v"].view(np.int32)) and np.array_equal(a["c"], b["c"])
-    assert a["f"].shape == b["f"].shape and not np.array_equal(a["f"], b["f"])
-    assert np.array_equal(a["f"], res["built_in_again"]["f"])                 # NULL restores the built-in table
-    hit_a, hit_b = a["tri"] >= 0, b["tri"] >= 0
-    both = hit_a & hit_b
-    flips = int((hit_a != hit_b).sum())
-    dr = np.abs(a["rng"][both] - b["rng"][both])
-    lab_diff = int((a["lab"][both] != b["lab"][both]).sum())
-    n = int(both.sum())
-    assert n > 50000
-    # measured on this scene (MI355X): see the assertion messages when they fail; the bounds carry a margin
-    far = int((dr > voxel / 2).sum())
-    print(f"other-diagonal table: {n} rays hit both meshes, {flips} hit/miss flips, {lab_diff} labels differ, "
-          f"{int((dr > 0).sum())} rays with another range: |d range| median {float(np.median(dr)):.6f} m, p99 "
-          f"{float(np.quantile(dr, 0.99)):.5f} m, p99.9 {float(np.quantile(dr, 0.999)):.5f} m, max {float(dr.max()):.4f} m, "
-          f"{far} rays beyond half a voxel")
-    # measured on MI355X (profiles/r04/mc_other_diagonals.txt): 126 263 rays hit both meshes; 187 hit / miss flips (0.15 %),
-    # 887 labels differ (0.70 %: class borders, where the hit face's first vertex is another one), |d range| median 12 um,
-    # p99 9.3 cm, p99.9 25 cm, max 0.99 m (a silhouette ray that slips past the surface); 1 958 rays (1.55 %) beyond half a
-    # voxel.  The bounds below carry a margin of about two.
-    assert flips <= 0.004 * n, f"{flips} hit/miss flips of {n}"
-    assert far <= 0.03 * n, f"{far} of {n} rays differ by more than half a voxel"
-    assert float(np.median(dr)) <= 1e-3 and float(np.quantile(dr, 0.99)) <= 1.5 * voxel
-    assert lab_diff <= 0.015 * n, f"{lab_diff} labels differ of {n}"
-    # and how much of the mesh could differ in TOPOLOGY: the ambiguous cases among the active cells
-    tsdf = vol.get_volume_tensors()[0]
-    ins = (tsdf < 0)
-    idx = torch.zeros(tuple(s - 1 for s in ins.shape), dtype=torch.int32, device=ins.device)
-    for i in range(8):
-        dx, dy, dz = i & 1, (i >> 1) & 1, (i >> 2) & 1
-        idx += ins[dx:ins.shape[0] - 1 + dx, dy:ins.shape[1] - 1 + dy, dz:ins.shape[2] - 1 + dz].to(torch.int32) << i
-    hist = torch.bincount(idx.reshape(-1), minlength=256).cpu().numpy()
-    cls = g.case_classes()
-    active = int(hist[1:255].sum())
-    amb = int(sum(hist[c] for c in range(1, 255) if cls[c]["face_ambiguous"] or cls[c]["interior_ambiguous_only"]))
-    assert active > 10000 and sum(int(hist[c]) * cls[c]["n_triangles"] for c in range(256)) == a["f"].shape[0]
-    assert amb <= 0.06 * active, f"{amb} ambiguous cells of {active}"   # (3.2 % on this 10 cm scene, 1.6 % on the default volume: bench.py)
-    print(f"active cells {active}, ambiguous (face or interior) {amb} = {100.0 * amb / active:.2f} %")
-    rs.close(); sc.close(); vol.close()

@@ -18,8 +18,8 @@ from skimage import measure
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "oracle", "liblt_oracle.so"))
 fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-lib.lto_mc_lewiner.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int, C.c_int, ip, ip]
-lib.lto_mc_lewiner.restype = C.c_int
+lib.lto_marching_cubes.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int, C.c_int, ip, ip]
+lib.lto_marching_cubes.restype = C.c_int
 
 
 def ours(vol):
@@ -28,12 +28,12 @@ def ours(vol):
     org = np.zeros(3, np.float32)
     nv, nf = C.c_int(0), C.c_int(0)
     f = lambda a: a.ctypes.data_as(fp)  # noqa: E731
-    lib.lto_mc_lewiner(f(vol), f(zeros), f(zeros), *vol.shape, 1.0, f(org), None, None, None, None, 0, 0, C.byref(nv), C.byref(nf))
+    lib.lto_marching_cubes(f(vol), f(zeros), f(zeros), *vol.shape, 1.0, f(org), None, None, None, None, 0, 0, C.byref(nv), C.byref(nf))
     v = np.zeros((max(nv.value, 1), 3), np.float32)
     fa = np.zeros((max(nf.value, 1), 3), np.int32)
     col = np.zeros((max(nv.value, 1), 3), np.int32)
     rem = np.zeros(max(nv.value, 1), np.float32)
-    lib.lto_mc_lewiner(f(vol), f(zeros), f(zeros), *vol.shape, 1.0, f(org), f(v), fa.ctypes.data_as(ip), col.ctypes.data_as(ip),
+    lib.lto_marching_cubes(f(vol), f(zeros), f(zeros), *vol.shape, 1.0, f(org), f(v), fa.ctypes.data_as(ip), col.ctypes.data_as(ip),
                            f(rem), nv.value, nf.value, C.byref(nv), C.byref(nf))
     return v[:nv.value], fa[:nf.value]
 
