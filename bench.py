@@ -983,17 +983,19 @@ def main():
         n_written = 0
         for x0 in range(0, tv.shape[0], 250):   # (in slabs: the masks of the whole volume would be 1.6 GB)
             n_written += int(((tv[x0:x0 + 250] != 1) | (wv[x0:x0 + 250] != 0)).sum().item())
-        # where the reference's scikit-image (Lewiner) table COULD give another surface: the share of ambiguous cases among
-        # the active cells of this very volume, and of cells whose polygons leave a choice of diagonals (outside the clock;
-        # tools/gen_mc_table.py classifies the 256 cases -- checker infrastructure, used here as such)
+        # how many of this very volume's active cells are one of Lewiner's AMBIGUOUS cases (3, 4, 6, 7, 10, 12, 13: the cell's
+        # eight values, not its signs, pick the tiling -- lt_mc.hip, lw_select); outside the clock.  The device's case index
+        # -> Lewiner's case: LT_LWC_CASE of the generated table header.
         mc_cases = None
         try:
-            from tools import gen_mc_table as gmt
-            cls = gmt.case_classes()
+            import re
+            hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lidar_transfer_amd", "csrc",
+                                    "lt_mc_lewiner_table.h")).read()
+            lw_case = np.array([int(x) for x in re.search(r"LT_LWC_CASE\[256\] = \{([^}]*)\}", hdr).group(1).split(",")])
             hist = np.zeros(256, np.int64)
             X = tv.shape[0]
             for x0 in range(0, X - 1, 100):
-                ins = tv[x0:min(x0 + 101, X)] < 0
+                ins = ~(tv[x0:min(x0 + 101, X)] > 0)     # the sign bit: NOT above the level
                 if not bool(ins.any()):
                     continue
                 sx, sy, sz = ins.shape
@@ -1004,16 +1006,11 @@ def main():
                 hist += torch.bincount(idx.reshape(-1), minlength=256).cpu().numpy()
                 del ins, idx
             act = int(hist[1:255].sum())
-            fa = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["face_ambiguous"]))
-            ia = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["interior_ambiguous_only"]))
-            sp = int(sum(hist[c_] for c_ in range(1, 255) if cls[c_]["splits_a_polygon"]))
-            mc_cases = {"active_cells": act, "face_ambiguous": fa, "interior_ambiguous_only": ia,
-                        "ambiguous_share": round((fa + ia) / max(act, 1), 5), "cells_with_a_choice_of_diagonals": sp,
-                        "diagonal_choice_share": round(sp / max(act, 1), 4),
-                        "triangles_by_table": int(sum(int(hist[c_]) * cls[c_]["n_triangles"] for c_ in range(256))),
-                        "note": "parity of the triangulation is unpinned (scikit-image absent); ambiguous cases are where "
-                                "a Lewiner table can differ in topology, the others only in diagonals -- bounded by "
-                                "tests/test_mc_gpu.py::test_other_diagonals_bound_what_a_different_case_table_can_change"}
+            amb = int(sum(int(hist[c_]) for c_ in range(1, 255) if lw_case[c_] in (3, 4, 6, 7, 10, 12, 13)))
+            mc_cases = {"active_cells": act, "ambiguous_cells": amb, "ambiguous_share": round(amb / max(act, 1), 5),
+                        "by_lewiner_case": {str(k): int(hist[lw_case == k].sum()) for k in range(1, 15)},
+                        "note": "the mesh is scikit-image 0.18.3's (Lewiner): vertex and face sets equal to the reference's "
+                                "get_mesh on golden F10, render bit-identical (tests/test_pin_f10_f11_gpu.py)"}
         except Exception as e:  # noqa: BLE001
             mc_cases = {"error": repr(e)[:200]}
         del tv, wv
