@@ -154,18 +154,34 @@ __device__ __noinline__ unsigned lw_select(const double* v, int cs) {
     default: return 0u;
   }
 }
-// the tiling of the cell at voxel (x, y, z) with case index cs: the table's for the cases without a test, else the tests
-// on the cell's eight values (Lewiner's corner p sits at (a0, a1, a2) = LW_CORNER[p] of the generator / the oracle:
-// 0 (0,0,0)  1 (0,0,1)  2 (0,1,1)  3 (0,1,0)  4 (1,0,0)  5 (1,0,1)  6 (1,1,1)  7 (1,1,0) -- scikit-image's x is the last axis)
-__device__ __forceinline__ unsigned lw_cell(const float* __restrict__ tsdf, int ny, int nz, int x, int y, int z, int cs) {
-  const unsigned fixed = LT_LWC_FIXED[cs];
-  if (fixed != 0xFFFFFFFFu) return fixed;
-  const size_t sy = (size_t)nz, sx = (size_t)ny * nz;
-  const float* c = tsdf + (size_t)x * sx + (size_t)y * sy + z;
+// the tiling of an AMBIGUOUS cell at voxel (x, y, z) with case index cs: the tests on the cell's eight values (Lewiner's
+// corner p sits at (a0, a1, a2) = LW_CORNER[p] of the generator / the oracle: 0 (0,0,0)  1 (0,0,1)  2 (0,1,1)  3 (0,1,0)
+// 4 (1,0,0)  5 (1,0,1)  6 (1,1,1)  7 (1,1,0) -- scikit-image's x is the last axis).  Only k_mc_amb calls this: the double
+// precision tests cost 100 vector registers, which the sweep and the emission kernels must not pay for 1-2 % of the cells.
+__device__ __forceinline__ unsigned lw_cell_eval(const float* __restrict__ c, size_t sx, size_t sy, int cs) {
   double v[8];
   v[0] = (double)c[0];       v[1] = (double)c[1];           v[2] = (double)c[sy + 1];      v[3] = (double)c[sy];
   v[4] = (double)c[sx];      v[5] = (double)c[sx + 1];      v[6] = (double)c[sx + sy + 1]; v[7] = (double)c[sx + sy];
   return lw_select(v, cs);
+}
+// ---- the ambiguous cells' side channel -------------------------------------------------------------------------------
+// k_mc_words queues every ambiguous cell it meets (voxel index, case index, its block of the scan) and counts it with 0
+// triangles; k_mc_amb evaluates the queue -- one lane per cell --, adds the cell's triangles / centre vertex to the counts
+// of its word and of its block (atomics: the one place of the extraction that has them; the RESULT does not depend on their
+// order), and files the tiling under the voxel index in an open-addressing table that k_mc_emit_batch reads.
+struct mc_amb {
+  uint2* queue;      // [cap]: (voxel index, case | block << 8)
+  int* counter;      // [0]: cells queued (may exceed cap: the host then grows the buffers and starts over)
+  uint2* table;      // [tcap], tcap a power of two >= 4 cap: (voxel index + 1, tiling); 0 = empty
+  unsigned cap, tmask;
+};
+__device__ __forceinline__ unsigned amb_slot(unsigned i, unsigned tmask) { return (i * 2654435761u) & tmask; }
+__device__ __forceinline__ unsigned amb_lookup(const mc_amb& A, unsigned i) {
+  for (unsigned h = amb_slot(i, A.tmask);; h = (h + 1) & A.tmask) {
+    const uint2 e = A.table[h];
+    if (e.x == i + 1u) return e.y;
+    if (e.x == 0u) return 0u;  // (not filed: cannot happen after k_mc_amb; no triangles rather than a wild read)
+  }
 }
 #define LW_NT(sel) (((sel) >> 16) & 15u)
 #define LW_C(sel) (((sel) >> 20) & 1u)
@@ -222,6 +238,8 @@ struct lt_mesh {
   // extraction (their records are still in `rec`); state_dirty: an extraction did not finish -- sweep everything once
   int n_prev, state_dirty;
   int* wave_na; size_t cap_wave_na;     // active words per wave of 64 rows (k_mc_words -> k_mc_compact)
+  mc_amb amb; size_t amb_cap;           // the ambiguous cells' queue and tiling table (k_mc_amb); counter = amb.counter
+  int n_amb_prev;                       // cells of the last extraction: their table slots are emptied by k_mc_clear
   float ms_signs, ms_rest;              // last extraction (when timed)
   hipEvent_t ev[3];
 };
@@ -380,7 +398,7 @@ __device__ __forceinline__ bool mc_block_live(const unsigned* __restrict__ chunk
   return any;
 }
 
-__global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf, const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
+__global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restrict__ bits, mc_dims D, unsigned* __restrict__ cnt,
                                                   int* __restrict__ blk, const unsigned* __restrict__ col_epoch,
                                                   unsigned epoch, const unsigned* __restrict__ chunk_epoch,
                                                   int* __restrict__ wave_na, int n_blocks) {
@@ -389,8 +407,14 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
   __shared__ unsigned char s_nt[256];  // triangles per case: the loops below look it up once per active cell, a chain of
   {                                    // dependent loads that is three times shorter through LDS.  0x80: an ambiguous case of
     const unsigned fx = LT_LWC_FIXED[threadIdx.x];  // Lewiner's (3, 4, 6, 7, 10, 12, 13) -- the cell's eight VALUES decide
-    s_nt[threadIdx.x] = fx == 0xFFFFFFFFu ? 0x80 : (unsigned char)LW_NT(fx);  // (lw_cell; 1-2 % of a street scene's cells)
+    s_nt[threadIdx.x] = fx == 0xFFFFFFFFu ? 0x80 : (unsigned char)LW_NT(fx);  // (k_mc_amb; 1-2 % of a street scene's cells)
   }
+  // the ambiguous cells a wave meets in one block of 64 rows, collected in LDS and appended to the queue with ONE global
+  // atomic (a returning atomic per cell on the one counter -- 14 500 of them on a street scene -- doubled the kernel's time)
+#define LT_MC_QW 96
+  __shared__ uint2 s_q[4][LT_MC_QW];
+  __shared__ int s_qn[4];
+  const int wv = threadIdx.x >> 6;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -413,6 +437,8 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
   live &= live - 1;
   const int row = blkid * 64 + lane;
   unsigned na = 0, nv = 0, nt = 0;
+  if (lane == 0) s_qn[wv] = 0;
+  __builtin_amdgcn_wave_barrier();
   // (a clean row writes nothing: its words hold 0 -- no active word of the last extraction is left, k_mc_clear)
   const bool rowlive = row < n_rows && mc_rows_dirty(col_epoch, epoch, D, row);
   const int rowc = min(row, n_rows - 1);
@@ -429,9 +455,15 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
   // -> triangles | centre vertices << 16 of the word k of this lane's row
   auto count_tris = [&](const mc_masks& M, int k) -> unsigned {  // (called by all 64 lanes)
     unsigned t = 0;
-    auto ambiguous = [&](int b, unsigned cs) -> unsigned {  // triangles | centre vertex << 16 of the cell at bit b
-      const unsigned sel = lw_cell(tsdf, D.ny, D.nz, x, y, k * 64 + b, (int)cs);
-      return LW_NT(sel) | (LW_C(sel) << 16);
+    auto ambiguous = [&](int xx, int yy, int b, unsigned cs) -> unsigned {  // queued for k_mc_amb; counts 0 here
+      const uint2 e = make_uint2((unsigned)((xx * D.ny + yy) * D.nz + k * 64 + b), cs | ((unsigned)blkid << 8));
+      const int slot = atomicAdd(&s_qn[wv], 1);  // (LDS)
+      if (slot < LT_MC_QW) s_q[wv][slot] = e;
+      else {  // (more than the buffer holds in one block of rows: straight to the queue)
+        const unsigned pos = (unsigned)atomicAdd(A.counter, 1);
+        if (pos < A.cap) A.queue[pos] = e;
+      }
+      return 0u;
     };
     const bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
     if (!heavy) {
@@ -451,7 +483,7 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
 #pragma unroll
           for (int i = 0; i < 8; ++i) cs |= ((m[i] >> b) & 1u) << i;
           const unsigned n = s_nt[cs];
-          t += (n & 0x80u) ? ambiguous(32 * h + b, cs) : n;
+          t += (n & 0x80u) ? ambiguous(x, y, 32 * h + b, cs) : n;
         }
       }
     }
@@ -468,11 +500,8 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
       const u64 ac = (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)M.ac, r) |
                      ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(M.ac >> 32), r) << 32);
       unsigned n = ((ac >> lane) & 1ull) ? s_nt[cs] : 0u;  // (<= 12, or the marker)
-      if (n & 0x80u) {  // (the OWNER's x, y, k: broadcast like its masks)
-        const int xr = __builtin_amdgcn_readlane(x, r), yr = __builtin_amdgcn_readlane(y, r);
-        const unsigned sel = lw_cell(tsdf, D.ny, D.nz, xr, yr, k * 64 + lane, cs);
-        n = LW_NT(sel) | (LW_C(sel) << 16);
-      }
+      if (n & 0x80u)  // (the OWNER's x, y: broadcast like its masks)
+        n = ambiguous(__builtin_amdgcn_readlane(x, r), __builtin_amdgcn_readlane(y, r), lane, (unsigned)cs);
       const unsigned tot = __popcll(__ballot(n & 1u)) + 2u * __popcll(__ballot(n & 2u)) + 4u * __popcll(__ballot(n & 4u)) +
                            8u * __popcll(__ballot(n & 8u)) + ((unsigned)__popcll(__ballot(n >> 16)) << 16);
       if (lane == r) t = tot;
@@ -514,6 +543,17 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
     if (rowlive) cnt[(size_t)row * D.wz + k] = v | (t << 16);
     na += (v | t) ? 1u : 0u; nv += v; nt += t;
   }
+  {  // the block's ambiguous cells -> the queue
+    __builtin_amdgcn_wave_barrier();
+    const int nq = min(s_qn[wv], LT_MC_QW);  // (wave-uniform)
+    if (nq > 0) {
+      unsigned base = 0;
+      if (lane == 0) base = (unsigned)atomicAdd(A.counter, nq);
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      for (int j = lane; j < nq; j += 64)
+        if (base + (unsigned)j < A.cap) A.queue[base + j] = s_q[wv][j];
+    }
+  }
   u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 768 triangles -- the host checks wz)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
@@ -527,10 +567,40 @@ __global__ __launch_bounds__(256) void k_mc_words(const float* __restrict__ tsdf
   LT_MC_STAMP_AT(1, wave, 2, wall_clock64());
 }
 
+// ---- k_mc_amb: the queued ambiguous cells, one lane each ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, mc_dims D, mc_amb A, unsigned* __restrict__ cnt,
+                                                int* __restrict__ blk, int* __restrict__ wave_na) {
+  const unsigned n = min((unsigned)A.counter[0], A.cap);
+  const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
+  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+    const uint2 e = A.queue[q];
+    const unsigned i = e.x;
+    const int cs = (int)(e.y & 255u), b = (int)(e.y >> 8);
+    const unsigned sel = lw_cell_eval(tsdf + i, sx, sy, cs);
+    for (unsigned h = amb_slot(i, A.tmask);; h = (h + 1) & A.tmask)  // (every cell is queued once: the slot is free or foreign)
+      if (atomicCAS(&A.table[h].x, 0u, i + 1u) == 0u) { A.table[h].y = sel; break; }
+    const unsigned nt = LW_NT(sel), c = LW_C(sel);
+    if (nt) {
+      const unsigned row = i / (unsigned)D.nz, z = i - row * (unsigned)D.nz;
+      const unsigned old = atomicAdd(&cnt[(size_t)row * D.wz + (z >> 6)], c | (nt << 16));
+      if (c) atomicAdd(&blk[3 * b + 1], (int)c);
+      atomicAdd(&blk[3 * b + 2], (int)nt);
+      if (old == 0u) { atomicAdd(&blk[3 * b], 1); atomicAdd(&wave_na[b], 1); }  // the word becomes an active word
+    }
+  }
+}
+
 // undo the last extraction's entries of cnt / cmap (its records are still there): both arrays are back to 0 / -1
+// ... and of the ambiguous cells' tiling table (its queue is still there too): every queued cell empties its own slot
 __global__ __launch_bounds__(256) void k_mc_clear(const mc_rec* __restrict__ rec, int n, unsigned* __restrict__ cnt,
-                                                  int* __restrict__ cmap) {
+                                                  int* __restrict__ cmap, mc_amb A, int n_amb) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_amb) {
+    const unsigned key = A.queue[i].x + 1u;
+    unsigned h = amb_slot(key - 1u, A.tmask);
+    for (unsigned tries = 0; tries <= A.tmask; ++tries, h = (h + 1) & A.tmask)  // (not stopped by slots others emptied)
+      if (A.table[h].x == key) { A.table[h].x = 0u; break; }
+  }
   if (i >= n) return;
   const int w = rec[i].w;
   cnt[w] = 0u;
@@ -565,7 +635,8 @@ __global__ __launch_bounds__(256) void k_mc_scan1(int* __restrict__ blk, int n_b
     for (int k = 0; k < 3; ++k) seg[3 * blockIdx.x + k] = (int)min(tot[k], (u64)2147483647);
 }
 
-__global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_seg, int* __restrict__ totals) {
+__global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_seg, int* __restrict__ totals,
+                                                   int* __restrict__ amb_counter) {
   __shared__ long long part[3][1024];
   const int t = threadIdx.x;
   long long s[3] = {0, 0, 0};
@@ -582,8 +653,11 @@ __global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_
   }
   if (t < n_seg)
     for (int k = 0; k < 3; ++k) seg[3 * t + k] = (int)min(part[k][t] - s[k], 2147483647ll);
-  if (t == 1023)
+  if (t == 1023) {
     for (int k = 0; k < 3; ++k) totals[k] = (int)min(part[k][1023], 2147483647ll);
+    totals[3] = amb_counter[0];  // the ambiguous cells queued (k_mc_amb is done); re-armed for the next extraction
+    amb_counter[0] = 0;
+  }
 }
 
 // ---- k_mc_compact ----------------------------------------------------------------------------------------------------
@@ -676,7 +750,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
                                                       const mc_rec* __restrict__ rec, int n_active, float voxel_size,
                                                       float ox, float oy, float oz, float* __restrict__ verts,
                                                       int* __restrict__ faces, int* __restrict__ colors,
-                                                      float* __restrict__ rem, int cap_v, int cap_f) {
+                                                      float* __restrict__ rem, int cap_v, int cap_f, mc_amb A) {
   static_assert(K <= 16, "list entries hold the word in 4 bits");
   __shared__ mc_rec s_rec[K];
   __shared__ int s_xyz[K][3];       // x, y, wz of the words
@@ -768,7 +842,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   // ---- the batch's active cells in order (word, z) with their TILING, and the (batch-relative) index of every cell's first
   // triangle: a lane takes one (word, SEGMENT of 8 voxels) pair, lists the cells of its 8 voxels (the word's cell base + a
   // popcount below the segment) -- case index from the corner masks, tiling from the table or, for Lewiner's ambiguous cases,
-  // from the tests on the cell's eight values (lw_cell) -- and adds up their triangle counts; ONE wave scan over the lanes
+  // from k_mc_amb's side table (the tests on the cell's eight values ran there) -- and adds up their triangle counts; ONE wave scan over the lanes
   // turns the sums into offsets, and the lane hands them to its cells.  The cells whose tiling has a centre vertex are
   // collected per word (s_ccm): their vertices follow the word's edge vertices in the output.
   const int ncell = s_cpre[nw];  // (wave-uniform)
@@ -795,7 +869,9 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
             unsigned cs = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
-            const unsigned sel = lw_cell(tsdf, D.ny, D.nz, s_xyz[k][0], s_xyz[k][1], s_xyz[k][2] * 64 + 8 * seg + bb, (int)cs);
+            unsigned sel = LT_LWC_FIXED[cs];
+            if (sel == 0xFFFFFFFFu)  // an ambiguous case: the tiling k_mc_amb filed under the cell's voxel index
+              sel = amb_lookup(A, (unsigned)((s_xyz[k][0] * D.ny + s_xyz[k][1]) * D.nz + s_xyz[k][2] * 64 + 8 * seg + bb));
             const unsigned nt = LW_NT(sel);
             s_cl[c] = (unsigned)k | ((unsigned)(8 * seg + bb) << 4) | (nt << 10) | (LW_C(sel) << 14) | (LW_OFF(sel) << 15);
             cm8 |= LW_C(sel) << bb;
@@ -881,14 +957,16 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
         // the cell's centre vertex (Cell.calculate_center_vertex): the centre of mass of the eight corners with weights
         // 1 / (eps + |v|), summed in Lewiner's corner order (0 .. 7) in double, stored as float32
         const float* c = tsdf + i;
-        const double w0 = 1.0 / (LT_MC_EPS + fabs((double)c[0])), w1 = 1.0 / (LT_MC_EPS + fabs((double)c[1])),
-                     w2 = 1.0 / (LT_MC_EPS + fabs((double)c[sy + 1])), w3 = 1.0 / (LT_MC_EPS + fabs((double)c[sy])),
-                     w4 = 1.0 / (LT_MC_EPS + fabs((double)c[sx])), w5 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + 1])),
-                     w6 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + sy + 1])), w7 = 1.0 / (LT_MC_EPS + fabs((double)c[sx + sy]));
-        const double ff = ((((((w0 + w1) + w2) + w3) + w4) + w5) + w6) + w7;
-        const double f2 = ((w1 + w2) + w5) + w6;  // corners with a2 + 1 (scikit-image's x)
-        const double f1 = ((w2 + w3) + w6) + w7;  // ... a1 + 1 (y)
-        const double f0 = ((w4 + w5) + w6) + w7;  // ... a0 + 1 (z)
+        double ff = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0;
+#pragma unroll 1  // (rare: a rolled loop keeps the kernel's registers where they were without the centre vertex)
+        for (int q = 0; q < 8; ++q) {  // Lewiner's corner q sits at (a0, a1, a2) = (q >> 2, q >> 1 & 1, (q ^ q >> 1) & 1)
+          const int a0 = q >> 2, a1 = (q >> 1) & 1, a2 = (q ^ (q >> 1)) & 1;
+          const double w = 1.0 / (LT_MC_EPS + fabs((double)c[(size_t)a0 * sx + (size_t)a1 * sy + (size_t)a2]));
+          ff += w;
+          if (a2) f2 += w;
+          if (a1) f1 += w;
+          if (a0) f0 += w;
+        }
         p0 = (float)((double)x + f0 / ff); p1 = (float)((double)y + f1 / ff); p2 = (float)((double)z + f2 / ff);
       } else {
         const float v0 = tsdf[i];
@@ -998,7 +1076,7 @@ extern "C" int lt_mesh_destroy(lt_mesh* m) {
   if (!m) return LT_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na};
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na, m->amb.queue, m->amb.table, m->amb.counter};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   if (m->totals_host) (void)hipHostFree(m->totals_host);
@@ -1091,15 +1169,40 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     m->cap_words = n_words;
     m->state_dirty = 1;  // (fresh buffers: swept below)
   }
+  // the ambiguous cells' queue and tiling table: grown when an extraction queued more cells than fit (below)
+  if (!m->amb.queue) {
+    const size_t cap = m->amb_cap ? m->amb_cap : (size_t)1 << 16;
+    size_t tcap = 1;
+    while (tcap < 4 * cap) tcap <<= 1;
+    if (hipMalloc((void**)&m->amb.queue, cap * sizeof(uint2)) != hipSuccess || hipMalloc((void**)&m->amb.table, tcap * sizeof(uint2)) != hipSuccess ||
+        (!m->amb.counter && hipMalloc((void**)&m->amb.counter, 4 * sizeof(int)) != hipSuccess)) {
+      (void)hipGetLastError();
+      (void)hipFree(m->amb.queue); (void)hipFree(m->amb.table);
+      m->amb.queue = nullptr; m->amb.table = nullptr;
+      lt_set_error("lt_marching_cubes_dev: hipMalloc of the ambiguous cells' buffers (%zu cells) failed", cap);
+      return LT_ERR_NO_MEMORY;
+    }
+    m->amb_cap = cap;
+    m->amb.cap = (unsigned)cap;
+    m->amb.tmask = (unsigned)(tcap - 1);
+    LT_HIP(hipMemsetAsync(m->amb.counter, 0, 4 * sizeof(int), stream));
+    LT_HIP(hipMemsetAsync(m->amb.table, 0, tcap * sizeof(uint2), stream));
+    m->n_amb_prev = 0;
+  }
   if (m->state_dirty) {  // new buffers, or an extraction that did not finish: cnt = 0, cmap = -1 everywhere, once
     LT_HIP(hipMemsetAsync(m->cnt, 0, m->cap_words * sizeof(unsigned), stream));
     LT_HIP(hipMemsetAsync(m->cmap, 0xFF, m->cap_words * sizeof(int), stream));
+    LT_HIP(hipMemsetAsync(m->amb.counter, 0, 4 * sizeof(int), stream));
+    LT_HIP(hipMemsetAsync(m->amb.table, 0, ((size_t)m->amb.tmask + 1) * sizeof(uint2), stream));
     m->n_prev = 0;
+    m->n_amb_prev = 0;
   } else if (m->n_prev > 0) {
-    hipLaunchKernelGGL(k_mc_clear, dim3((m->n_prev + 255) / 256), dim3(256), 0, stream, m->rec, m->n_prev, m->cnt, m->cmap);
+    hipLaunchKernelGGL(k_mc_clear, dim3((max(m->n_prev, m->n_amb_prev) + 255) / 256), dim3(256), 0, stream, m->rec, m->n_prev,
+                       m->cnt, m->cmap, m->amb, m->n_amb_prev);
   }
   m->state_dirty = 1;  // until this extraction has finished
   m->n_prev = 0;
+  m->n_amb_prev = 0;
   LT_CHECK(mc_grow(&m->wave_na, &m->cap_wave_na, (size_t)n_blocks));
   const int n_seg = (n_blocks + 255) / 256;
   if (n_seg > 1024) {
@@ -1118,12 +1221,23 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   if (ms) LT_HIP(hipEventRecord(m->ev[1], stream));
   // (a wave takes LT_MC_BLOCKS_PER_WAVE blocks, see k_mc_words)
   const int sweep_wgs = lt_deal_count(n_blocks, LT_MC_BLOCKS_PER_WAVE, ny, 4) / 4;
-  hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, tsdf, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
+  hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, m->amb, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
                      epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na, n_blocks);
+  // Lewiner's ambiguous cells (1-2 % of a street scene's): tests on their eight values, counts added, tilings filed
+  hipLaunchKernelGGL(k_mc_amb, dim3(128), dim3(256), 0, stream, tsdf, D, m->amb, m->cnt, m->blk, m->wave_na);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
-  hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev);
-  LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev, m->amb.counter);
+  LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
   LT_HIP(hipStreamSynchronize(stream));  // the one synchronisation: the sizes of the mesh
+  if ((size_t)(unsigned)m->totals_host[3] > m->amb_cap) {
+    // more ambiguous cells than the queue holds (white noise: a third of all cells): the counts above are incomplete --
+    // larger buffers, and the extraction once more from the start (cnt / cmap are swept: state_dirty is still set)
+    const size_t need = (size_t)(unsigned)m->totals_host[3];
+    (void)hipFree(m->amb.queue); (void)hipFree(m->amb.table);
+    m->amb.queue = nullptr; m->amb.table = nullptr;
+    m->amb_cap = need + need / 4 + 1024;
+    return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, col_epoch, epoch, ext_bits, chunk_epoch);
+  }
   const int n_active = m->totals_host[0], nv = m->totals_host[1], nf = m->totals_host[2];
   static const bool dbg_mc = getenv("LIDARHIP_DEBUG_MC") != nullptr;
   if (dbg_mc) fprintf(stderr, "marching cubes: %d active words, %d vertices, %d triangles\n", n_active, nv, nf);
@@ -1168,7 +1282,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   hipLaunchKernelGGL(k_mc_compact, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647), m->wave_na, n_blocks);
 #define LT_MC_EMIT_ARGS tsdf, color_vol, rem_vol, bits, D, m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], \
-                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f
+                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, m->amb
   if (n_active > 0) {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
     // The grid: persistent waves taking batches in turn (bi += gridDim), twice the resident capacity (18 waves of 8.2 KB
@@ -1192,6 +1306,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   m->n_verts = nv;
   m->n_faces = nf;
   m->n_prev = n_active;  // (the records k_mc_clear will undo before the next extraction)
+  m->n_amb_prev = m->totals_host[3];
   m->state_dirty = 0;
   if (ms) {
     LT_HIP(hipEventRecord(m->ev[2], stream));
