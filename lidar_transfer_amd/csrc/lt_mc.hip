@@ -572,8 +572,32 @@ __global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, 
                                                 int* __restrict__ blk, int* __restrict__ wave_na) {
   const unsigned n = min((unsigned)A.counter[0], A.cap);
   const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
-  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
-    const uint2 e = A.queue[q];
+  // a workgroup takes 256 queued cells and deals them to its lanes SORTED by Lewiner's case (counting sort in LDS): the seven
+  // ambiguous cases run different tests, and a wave pays for every case its lanes hold
+  __shared__ uint2 s_e[256];
+  __shared__ int s_n[16], s_o[16];
+  const int tid = threadIdx.x;
+  for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {  // (workgroup-uniform)
+    if (tid < 16) s_n[tid] = 0;
+    __syncthreads();
+    const bool valid = base + tid < n;
+    uint2 e0 = make_uint2(0u, 0u);
+    int bucket = 0, rank = 0;
+    if (valid) {
+      e0 = A.queue[base + tid];
+      bucket = LT_LWC_CASE[e0.y & 255u];  // 3, 4, 6, 7, 10, 12, 13
+      rank = atomicAdd(&s_n[bucket], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int k = 0; k < 16; ++k) { s_o[k] = o; o += s_n[k]; }
+    }
+    __syncthreads();
+    if (valid) s_e[s_o[bucket] + rank] = e0;
+    __syncthreads();
+    if (!valid) continue;  // (no barrier below)
+    const uint2 e = s_e[tid];
     const unsigned i = e.x;
     const int cs = (int)(e.y & 255u), b = (int)(e.y >> 8);
     const unsigned sel = lw_cell_eval(tsdf + i, sx, sy, cs);

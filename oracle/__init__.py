@@ -12,6 +12,9 @@ Only tests/, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` leg may imp
                              to the reference's own kernel text compiled by hipcc for gfx950 (build_ref_tsdf.py +
                              ref_tsdf_launch.inc -> _ref/libref_tsdf_integrate{,_plain}.so); the plain-average branch
                              also against the reference's numpy CPU mode, golden F8
+  lt_mc_oracle.c             get_mesh = scikit-image 0.18's Lewiner marching cubes + the attribute look-ups, restated in C:
+                             returns the reference's ARRAYS (values and order) -- pinned by goldens F10 / F10b made with the
+                             real scikit-image (tests/golden/make_golden_mc*.py, /opt/conda/bin/python3.9)
   gen_rsqrt_table.c          measures and exhaustively verifies the x86 RSQRTSS table the kernels replay
   Makefile                   builds liblt_oracle.so and oracle/_ref/ (needs /root/reference for the latter)
 """

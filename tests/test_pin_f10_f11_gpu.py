@@ -1,5 +1,6 @@
 """The two rows of the scope table that need the reference's own ENVIRONMENT -- marching cubes (SURVEY.md section 8f-2;
-scikit-image's Lewiner implementation is the reference's dependency, not importable here: parity unpinned) and the
+scikit-image's Lewiner implementation is the reference's dependency: golden F10 was made with the real scikit-image 0.18.3 of
+the build image's /opt/conda interpreter, so these tests RUN) and the
 class-aware TSDF update as a CUDA run (8f-1; pinned in this image to the kernel's source compiled for gfx950,
 tests/test_tsdf_ref_kernel_gpu.py -- pycuda + an NVIDIA GPU would add CUDA's own last ulps) -- against golden fixtures
 made by the REAL reference:
@@ -7,8 +8,8 @@ made by the REAL reference:
     tests/golden/make_golden_mc.py         -> tests/golden/f10_mc_<case>.npz
     tests/golden/make_golden_tsdf_cuda.py  -> tests/golden/f11_tsdf_cuda.npz
 
-Neither generator can run in the build image; every test here SKIPS until a maintainer with the reference's environment
-has run them once and committed the files (recipe: INTEGRATION.md, "Pinning marching cubes and the CUDA fusion kernel").
+F10 is committed; the F11 test SKIPS until a maintainer with pycuda + an NVIDIA GPU has run its generator once and committed
+the file (recipe: INTEGRATION.md, "How marching cubes and the fusion kernel are pinned").
 Inputs come from tests/pin_cases.py (seeded, numpy only), shared with the generators."""
 import os
 
