@@ -1037,7 +1037,7 @@ def main():
                                                 "k_tsdf_dct"], comp_int,
                                                float(m[1]), "written voxels x 16 B out (+ in again after the first "
                                                "observation) + 3 images per observation"),
-                   "marching_cubes": chain_roofline(["k_mc_emit_batch", "k_mc_words", "k_mc_compact", "k_mc_clear",
+                   "marching_cubes": chain_roofline(["k_mc_emit_batch", "k_mc_words", "k_mc_amb", "k_mc_compact", "k_mc_clear",
                                                      "k_mc_scan1", "k_mc_scan2"], comp_mc, float(m[2]),
                                                     "mesh out (28 B per vertex, 12 B per face) + 16 B of field samples "
                                                     "in per vertex")}}

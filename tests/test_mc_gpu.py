@@ -51,6 +51,29 @@ def test_white_noise_equals_oracle_on_every_word_layout(oracle, shape):
         assert want[1].shape[0] > 10
 
 
+def test_more_ambiguous_cells_than_the_queue_holds_grow_the_buffers_and_start_over(oracle):
+    """White noise makes a third of all cells one of Lewiner's ambiguous cases: 546 000 cells queue ~180 000 of them, more
+    than the 65 536 the side buffers start with -- the extraction sees the overflow at its one host synchronisation, grows
+    queue and table and runs again; a second extraction into the same mesh object (buffers now large enough, table slots
+    emptied by k_mc_clear) and a small volume afterwards give the oracle's meshes too."""
+    import torch
+    from lidar_transfer_amd.fusion import DeviceMesh
+    dev = torch.device("cuda", 0)
+    m = DeviceMesh(0)
+    org = np.zeros(3, np.float32)
+    for k, shape in enumerate([(70, 60, 130), (70, 60, 130), (9, 8, 7)]):
+        rng = np.random.default_rng(100 + k)
+        t = rng.normal(size=shape).astype(np.float32)
+        t[rng.random(shape) < 0.02] = 0.0
+        col = (rng.integers(0, 260, shape) * 65536).astype(np.float32)
+        rem = rng.random(shape).astype(np.float32)
+        want = oracle.marching_cubes(t, col, rem, 0.1, org)
+        m.extract(*[torch.from_numpy(a).to(dev) for a in (t, col, rem)], 0.1, (0.0, 0.0, 0.0))
+        _assert_same_mesh([a.cpu().numpy() for a in m.tensors()], want)
+        assert k == 2 or want[1].shape[0] > 1_000_000
+    m.close()
+
+
 @pytest.mark.parametrize("p_neg", [0.0005, 0.004, 0.02, 0.08, 0.3])
 def test_speckled_fields_cross_the_sparse_and_dense_emission_paths(oracle, p_neg):
     """The emission kernel lists a batch of 8 active words with a lane per vertex / cell when the batch holds <= 128 of them

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("k_tsdf_integrate_pix", "k_tsdf_integrate_pix_multi", "k_tsdf_integrate_quirk_multi", "k_tsdf_dct4", "k_tsdf_integrate_written", "k_tsdf_integrate_quirk", "k_tsdf_dct",
-           "k_tsdf_integrate_cols", "k_tsdf_columns", "k_tsdf_colmax", "k_tsdf_reset_cols", "k_mc_words", "k_mc_compact",
+           "k_tsdf_integrate_cols", "k_tsdf_columns", "k_tsdf_colmax", "k_tsdf_reset_cols", "k_mc_words", "k_mc_amb", "k_mc_compact",
            "k_mc_emit_batch", "k_mc_clear", "k_mc_scan1", "k_mc_scan2")
 
 
