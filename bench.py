@@ -1009,7 +1009,7 @@ def main():
             amb = int(sum(int(hist[c_]) for c_ in range(1, 255) if lw_case[c_] in (3, 4, 6, 7, 10, 12, 13)))
             mc_cases = {"active_cells": act, "ambiguous_cells": amb, "ambiguous_share": round(amb / max(act, 1), 5),
                         "by_lewiner_case": {str(k): int(hist[lw_case == k].sum()) for k in range(1, 15)},
-                        "note": "the mesh is scikit-image 0.18.3's (Lewiner): vertex and face sets equal to the reference's "
+                        "note": "the mesh is scikit-image 0.18.3's (Lewiner): vertices and face stream equal to the reference's "
                                 "get_mesh on golden F10, render bit-identical (tests/test_pin_f10_f11_gpu.py)"}
         except Exception as e:  # noqa: BLE001
             mc_cases = {"error": repr(e)[:200]}

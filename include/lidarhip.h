@@ -365,9 +365,10 @@ int lt_mesh_destroy(lt_mesh* mesh);
  * colour / remission, voxel -> world coordinates, colour unfolding incl. the uint8 wrap of labels 256..259) and
  * the later upload of the mesh for the ray cast (:433-451).  The mesh is scikit-image 0.18's: Lewiner's cases with their
  * face / interior tests and centre vertices, one vertex per sign-changing lattice edge shared by the cells around it,
- * positions by its centre-of-mass rule, every face's vertices in its order -- the same SET of vertices (bit for bit) and of
- * faces as the reference's get_mesh returns (golden F10 of the real scikit-image, tests/test_pin_f10_f11_gpu.py); only the
- * ORDER of the elements in the arrays is this library's (owner voxel / cell order: no serial face stream on a GPU).
+ * positions by its centre-of-mass rule -- the same vertices (bit for bit) and the same FACE STREAM as the reference's
+ * get_mesh returns: face k has the same three vertices in the same order (golden F10 of the real scikit-image,
+ * tests/test_pin_f10_f11_gpu.py).  Only the NUMBERING of the vertices is this library's (by word of 64 voxels, owner voxel,
+ * edge axis; scikit-image numbers them by first use in its serial face stream).
  * The call synchronises `stream` once (the sizes of the mesh are needed on the host).  ms: NULL, or two floats that
  * receive the duration of the sign pass (the one stream over the float field) and of everything else. */
 int lt_tsdf_extract_mesh_dev(lt_tsdf* vol, lt_mesh* mesh, void* stream, float* ms);

@@ -14,25 +14,29 @@
 //                 to 64-bit words): 3.2 GB in, 128 MB out
 //   k_mc_words    one thread per 64-voxel word: crossing-edge masks ex / ey / ez of the edges its voxels own
 //                 (m ^ neighbour word, shifted for z), active-cell mask (the 8 corner words are not all equal), number
-//                 of vertices (popcounts + centre vertices) and triangles (case table, only on the set bits; the cell's
-//                 eight values for Lewiner's ambiguous cases); per-workgroup totals
+//                 of vertices (popcounts) and triangles (case table, only on the set bits); the cells of Lewiner's
+//                 ambiguous cases are queued; per-workgroup totals
+//   k_mc_amb      one lane per queued cell: the face / interior tests on its eight values pick the tiling; its triangles
+//                 and centre vertex are added to the counts, the tiling is filed for k_mc_emit_batch
 //   k_mc_scan1/2  exclusive scan of the workgroup totals in two levels -> V, F
 //   k_mc_compact  word -> compact index of the active words (the ~2 % that own a vertex or a triangle); per active
 //                 word a record {word, vertex base, triangle base, ex, ey, ez}
-//   k_mc_emit     one WAVE per active word, one lane per voxel: the lane's up to three vertices (position by
-//                 scikit-image's centre-of-mass rule in double, attributes from the nearest voxel) and its cell's
-//                 triangles; the index of a vertex owned by a neighbouring word comes from that word's record
-//                 (8 neighbour records staged in LDS per wave): base + popcount of the edge masks below the bit
+//   k_mc_emit_batch  one WAVE per 8 active words, one lane per VERTEX / per TRIANGLE of the batch (positions by
+//                 scikit-image's centre-of-mass rule in double, attributes from the nearest voxel); the index of a vertex
+//                 owned by a neighbouring word comes from that word's record (neighbour records staged in LDS): base +
+//                 popcount of the edge masks below the bit; a cell's centre vertex follows its word's edge vertices
 //
 // WHICH mesh: scikit-image 0.18's `marching_cubes_lewiner` (what the reference calls, fusion_lidar.py:407) -- Lewiner's 33
 // cases with their face / interior tests and centre vertices, decided on the cell's eight VALUES where the signs do not
 // (1-2 % of a street scene's cells; the rest is table look-up on the sign bits as before), every face's vertices in
-// scikit-image's order (gradient_direction = "descent").  The SET of vertices (positions bit for bit, colours, remissions)
-// and the SET of faces equal the reference's get_mesh output (golden F10 made by the real scikit-image: tests/
-// test_pin_f10_f11_gpu.py; the CPU oracle oracle/lt_mc_oracle.c reproduces the reference's arrays including their order and
-// is bit-identical to this file up to that order).  Element ORDER is this library's: vertices by (word of 64 voxels; owner
-// voxel x, y, z ascending, edge axis; then the word's centre vertices), faces by (cell ascending, tiling order) --
-// deterministic, no atomics anywhere; scikit-image numbers vertices by first use in a serial face stream.
+// scikit-image's order (gradient_direction = "descent").  The vertices (positions bit for bit, colours, remissions) and the
+// FACE STREAM -- face k: the same three vertices in the same order -- equal the reference's get_mesh output (golden F10
+// made by the real scikit-image: tests/test_pin_f10_f11_gpu.py; the CPU oracle oracle/lt_mc_oracle.c reproduces the
+// reference's arrays and is identical to this file up to the numbering of the vertices).  Faces come by (cell ascending in
+// (a0, a1, a2), tiling order), which IS scikit-image's order; vertices are numbered by (word of 64 voxels; owner voxel x, y, z
+// ascending, edge axis; then the word's centre vertices) where scikit-image numbers them by first use --
+// deterministic (the only atomics, k_mc_amb's, are commutative adds and slot claims whose outcome does not reach the
+// output's order); scikit-image numbers vertices by first use in a serial face stream.
 // Tables: lt_mc_lewiner_table.h (Lewiner's LookUpTable.h as scikit-image ships it, tools/gen_mc_lewiner.py).
 #include "lt_internal.h"
 #include <float.h>
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
   LT_MC_STAMP_AT(2, wave, 2, wall_clock64());
 }
 
-// ---- k_mc_emit --------------------------------------------------------------------------------------------------------
+// ---- emission ----------------------------------------------------------------------------------------------------------
 struct mc_nb { u64 ex, ey, ez; int vbase; int have; };
 
 // float32 vertex coordinate along the edge from lattice coordinate c (value v1) to c + 1 (value v2): scikit-image's
@@ -759,7 +763,7 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 }
 
 // ---- k_mc_emit_batch: one wave per K consecutive active words, one lane per VERTEX / per TRIANGLE ----------------------------
-// k_mc_emit spends its time issuing instructions for idle lanes: on the default volume's street scene an active word owns
+// A wave per active word with a lane per voxel (rounds 1-2) spent its time issuing instructions for idle lanes: on the default volume's street scene an active word owns
 // 3.6 vertices and 7.3 triangles, so the double-precision vertex rule (three IEEE divisions), unrolled over the three edge
 // axes, and the 5 x 3 unrolled index computations run with 2-4 of 64 lanes live -- 252 000 waves x ~3 300 cycles = the
 // kernel's 265 us (more words per wave or a lane per word change nothing: 272 / 332 us measured).  Here a wave takes K
