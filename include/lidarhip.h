@@ -382,6 +382,13 @@ int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float
  * pointers stay valid until the next extraction into this mesh or lt_mesh_destroy.  Any argument may be NULL. */
 int lt_mesh_get(lt_mesh* mesh, int* n_verts, int* n_faces, float** verts, int** faces, int** colors, float** rem);
 
+/* Number the vertices of the last extraction as scikit-image numbers them -- by first use in the face stream -- and rewrite
+ * the face array accordingly: verts / colors / rem / faces then EQUAL the arrays the reference's get_mesh returns (golden
+ * F10), not only up to the vertices' numbers.  For host-facing consumers of the arrays (TSDFVolume.get_mesh); the ray cast
+ * does not care.  Call it BEFORE lt_scene_set_mesh / lt_mesh_get: the vertex arrays move to other buffers.  Synchronises
+ * `stream`. */
+int lt_mesh_renumber_dev(lt_mesh* mesh, void* stream);
+
 /* lt_scene_set_mesh_dev with the arrays of `mesh` (borrowed until the next extraction): the render reads the
  * mesh where marching cubes wrote it -- no PCIe traffic between fusion and range image. */
 int lt_scene_set_mesh(lt_scene* scene, lt_mesh* mesh);

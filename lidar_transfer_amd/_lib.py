@@ -30,7 +30,7 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_tsdf_volumes", "lt_tsdf_touch", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_fusion_scan_dev", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
            "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free", "lt_projector_create",
-           "lt_projector_destroy", "lt_range_projection_batch_dev",
+           "lt_projector_destroy", "lt_range_projection_batch_dev", "lt_mesh_renumber_dev",
            "lt_tsdf_integrate_multi_dev", "lt_deform_scan_dev"]
 
 
@@ -138,6 +138,8 @@ def load():
     lib.lt_mesh_destroy.argtypes = [vp]
     lib.lt_tsdf_extract_mesh_dev.argtypes = [vp, vp, vp, fp]
     lib.lt_marching_cubes_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, fp, vp, vp, fp]
+    lib.lt_mesh_renumber_dev.argtypes = [vp, vp]
+    lib.lt_mesh_renumber_dev.restype = C.c_int
     lib.lt_mesh_get.argtypes = [vp, ip, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.lt_scene_set_mesh.argtypes = [vp, vp]
     lib.lt_fusion_scan_dev.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,

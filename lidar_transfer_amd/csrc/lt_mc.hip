@@ -244,6 +244,9 @@ struct lt_mesh {
   int* wave_na; size_t cap_wave_na;     // active words per wave of 64 rows (k_mc_words -> k_mc_compact)
   mc_amb amb; size_t amb_cap;           // the ambiguous cells' queue and tiling table (k_mc_amb); counter = amb.counter
   int n_amb_prev;                       // cells of the last extraction: their table slots are emptied by k_mc_clear
+  // lt_mesh_renumber_dev: the second set of vertex arrays (swapped with the first), first use / new number per vertex, block sums
+  float* verts2; int* colors2; float* rem2; int cap_v2;
+  int* rn_first; int* rn_newid; size_t cap_rn; int* rn_bsum; size_t cap_bsum;
   float ms_signs, ms_rest;              // last extraction (when timed)
   hipEvent_t ev[3];
 };
@@ -1104,7 +1107,8 @@ extern "C" int lt_mesh_destroy(lt_mesh* m) {
   if (!m) return LT_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na, m->amb.queue, m->amb.table, m->amb.counter};
+  void* ps[] = {m->verts, m->faces, m->colors, m->rem, m->bits, m->cnt, m->cmap, m->blk, m->rec, m->wave_na, m->amb.queue, m->amb.table, m->amb.counter,
+                m->verts2, m->colors2, m->rem2, m->rn_first, m->rn_newid, m->rn_bsum};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   if (m->totals_host) (void)hipHostFree(m->totals_host);
@@ -1344,6 +1348,164 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     ms[0] = m->ms_signs;
     ms[1] = m->ms_rest;
   }
+  return LT_OK;
+}
+
+// ---- lt_mesh_renumber_dev: the vertices numbered as scikit-image numbers them ----------------------------------------
+// The extraction above emits scikit-image's FACE STREAM with its own vertex numbers (by word / owner voxel / edge axis).
+// scikit-image creates a vertex when a face first references it, so its number is the rank of its first use in ITS face
+// stream -- which lists a face's corners in the tiling's order; the reversal (np.fliplr, gradient_direction="descent")
+// happens afterwards, so position q = 3 face + k of that stream is corner 2 - k of the face array here (rn_at).
+// first[v] = min q (atomicMin), flag(q) = "q is a first use", new number = exclusive prefix sum of the flags at first[v]
+// (two-level scan, 1024 positions per block), vertex arrays permuted, faces rewritten.
+// For the host-facing get_mesh (the arrays then EQUAL the reference's, golden F10); the in-HBM chain has no use for it.
+__device__ __forceinline__ int rn_at(int q) { return q + 2 - 2 * (q % 3); }  // index in the face array of stream position q
+__global__ __launch_bounds__(256) void k_rn_first(const int* __restrict__ faces, int n3, int* __restrict__ first) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < n3) atomicMin(&first[faces[rn_at(q)]], q);
+}
+__device__ __forceinline__ int rn_block_excl_scan(int v, int* total) {  // 256 threads; returns the exclusive prefix of v
+  __shared__ int ws[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int q = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += q;
+  }
+  __syncthreads();  // (ws may still be read by a previous call)
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wv; ++w) off += ws[w];
+  *total = ws[0] + ws[1] + ws[2] + ws[3];
+  return off + inc - v;
+}
+// stream positions [1024 b, 1024 b + 1024): thread t holds the four consecutive positions 1024 b + 4 t ..
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_rn_rank(const int* __restrict__ faces, int n3, const int* __restrict__ first,
+                                                 int* __restrict__ bsum, int* __restrict__ newid) {
+  const int p0 = blockIdx.x * 1024 + threadIdx.x * 4;
+  int v[4], f[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = p0 + j < n3 ? faces[rn_at(p0 + j)] : -1;
+    f[j] = (v[j] >= 0 && first[v[j]] == p0 + j) ? 1 : 0;
+    s += f[j];
+  }
+  int total;
+  int ex = rn_block_excl_scan(s, &total);
+  if (!WRITE) {
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+    return;
+  }
+  ex += bsum[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (f[j]) newid[v[j]] = ex;
+    ex += f[j];
+  }
+}
+__global__ __launch_bounds__(1024) void k_rn_scan_blocks(int* __restrict__ bsum, int nb) {  // exclusive, in place; total -> bsum[nb]
+  __shared__ int carry, ws[16];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int q = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += q;
+    }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wv; ++w) off += ws[w];
+    if (i < nb) bsum[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[nb] = carry;
+}
+__global__ __launch_bounds__(256) void k_rn_move(const int* __restrict__ newid, int nv, const float* __restrict__ verts,
+                                                 const int* __restrict__ colors, const float* __restrict__ rem,
+                                                 float* __restrict__ verts2, int* __restrict__ colors2, float* __restrict__ rem2) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= nv) return;
+  const int j = newid[v];
+  if (j < 0) return;  // (an unreferenced vertex: reported by the host)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { verts2[3 * (size_t)j + k] = verts[3 * (size_t)v + k]; colors2[3 * (size_t)j + k] = colors[3 * (size_t)v + k]; }
+  rem2[j] = rem[v];
+}
+__global__ __launch_bounds__(256) void k_rn_faces(int* __restrict__ faces, int n3, const int* __restrict__ newid) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n3) faces[p] = newid[faces[p]];
+}
+
+// see include/lidarhip.h
+extern "C" int lt_mesh_renumber_dev(lt_mesh* m, void* stream_) {
+  if (!m) {
+    lt_set_error("lt_mesh_renumber_dev: NULL mesh");
+    return LT_ERR_INVALID_ARG;
+  }
+  const int nv = m->n_verts, n3 = 3 * m->n_faces;
+  if (nv == 0 || n3 == 0) return LT_OK;
+  if ((long long)m->n_faces * 3 > 2147483647ll) {
+    lt_set_error("lt_mesh_renumber_dev: more than 2^31 face corners");
+    return LT_ERR_TOO_LARGE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  LT_HIP(hipSetDevice(m->device));
+  const int nb = (n3 + 1023) / 1024;
+  if ((size_t)nv > m->cap_rn || !m->rn_first) {
+    (void)hipFree(m->rn_first); (void)hipFree(m->rn_newid);
+    m->rn_first = nullptr; m->rn_newid = nullptr; m->cap_rn = 0;
+    const size_t cap = (size_t)nv + nv / 4 + 1024;
+    LT_HIP(hipMalloc((void**)&m->rn_first, cap * sizeof(int)));
+    LT_HIP(hipMalloc((void**)&m->rn_newid, cap * sizeof(int)));
+    m->cap_rn = cap;
+  }
+  if ((size_t)nb + 1 > m->cap_bsum || !m->rn_bsum) {
+    (void)hipFree(m->rn_bsum);
+    m->rn_bsum = nullptr; m->cap_bsum = 0;
+    const size_t cap = (size_t)nb + nb / 4 + 1024;
+    LT_HIP(hipMalloc((void**)&m->rn_bsum, cap * sizeof(int)));
+    m->cap_bsum = cap;
+  }
+  if (m->cap_v2 < m->cap_v || !m->verts2) {
+    (void)hipFree(m->verts2); (void)hipFree(m->colors2); (void)hipFree(m->rem2);
+    m->verts2 = nullptr; m->colors2 = nullptr; m->rem2 = nullptr; m->cap_v2 = 0;
+    LT_HIP(hipMalloc((void**)&m->verts2, (size_t)m->cap_v * 12));
+    LT_HIP(hipMalloc((void**)&m->colors2, (size_t)m->cap_v * 12));
+    LT_HIP(hipMalloc((void**)&m->rem2, (size_t)m->cap_v * 4));
+    m->cap_v2 = m->cap_v;
+  }
+  LT_HIP(hipMemsetAsync(m->rn_first, 0x7F, (size_t)nv * sizeof(int), stream));   // 0x7F7F7F7F: beyond any position
+  LT_HIP(hipMemsetAsync(m->rn_newid, 0xFF, (size_t)nv * sizeof(int), stream));   // -1
+  hipLaunchKernelGGL(k_rn_first, dim3((n3 + 255) / 256), dim3(256), 0, stream, m->faces, n3, m->rn_first);
+  hipLaunchKernelGGL(k_rn_rank<false>, dim3(nb), dim3(256), 0, stream, m->faces, n3, m->rn_first, m->rn_bsum, m->rn_newid);
+  hipLaunchKernelGGL(k_rn_scan_blocks, dim3(1), dim3(1024), 0, stream, m->rn_bsum, nb);
+  hipLaunchKernelGGL(k_rn_rank<true>, dim3(nb), dim3(256), 0, stream, m->faces, n3, m->rn_first, m->rn_bsum, m->rn_newid);
+  hipLaunchKernelGGL(k_rn_move, dim3((nv + 255) / 256), dim3(256), 0, stream, m->rn_newid, nv, m->verts, m->colors, m->rem,
+                     m->verts2, m->colors2, m->rem2);
+  hipLaunchKernelGGL(k_rn_faces, dim3((n3 + 255) / 256), dim3(256), 0, stream, m->faces, n3, m->rn_newid);
+  int referenced = 0;
+  LT_HIP(hipMemcpyAsync(&referenced, m->rn_bsum + nb, sizeof(int), hipMemcpyDeviceToHost, stream));
+  LT_HIP(hipStreamSynchronize(stream));
+  LT_HIP(hipGetLastError());
+  if (referenced != nv) {  // (cannot happen for a mesh of lt_marching_cubes_dev: every vertex lies on an edge some tiling uses)
+    lt_set_error("lt_mesh_renumber_dev: %d of %d vertices are referenced by no face", nv - referenced, nv);
+    return LT_ERR_BAD_INDEX;
+  }
+  float* tv = m->verts; m->verts = m->verts2; m->verts2 = tv;
+  int* tc = m->colors; m->colors = m->colors2; m->colors2 = tc;
+  float* tr = m->rem; m->rem = m->rem2; m->rem2 = tr;
+  const int tcap = m->cap_v; m->cap_v = m->cap_v2; m->cap_v2 = tcap;
   return LT_OK;
 }
 

@@ -212,18 +212,22 @@ class TSDFVolume:
 
     def get_mesh(self, color_lut=None):
         """``(verts, faces, norms, colors, rem)`` as numpy arrays like fusion_lidar.py:403-424: verts ``[V,3]`` f32 in
-        world coordinates, faces ``[F,3]`` i32, colors ``[V,3]`` uint8 (r, g, b), rem ``[V]`` f32.  ``norms`` is
+        world coordinates, faces ``[F,3]`` i32, colors ``[V,3]`` uint8 (r, g, b), rem ``[V]`` f32 -- the arrays scikit-image
+        0.18 + fusion_lidar.py:409-423 return, element for element (golden F10).  ``norms`` is
         ``None``: scikit-image's vertex normals are returned by the reference but read by nothing on the path
         (only by the PLY writer that is commented out, fusion_lidar.py:430-431)."""
-        v, f, c, r = self.extract_mesh().tensors()
+        v, f, c, r = self.extract_mesh().renumber().tensors()   # scikit-image's vertex numbers: the reference's arrays
         return v.cpu().numpy(), f.cpu().numpy(), None, c.cpu().numpy().astype(np.uint8), r.cpu().numpy()
 
-    def throw_rays_at_mesh_device(self, rayset, origin, out=None, scene=None, label_image=False):
+    def throw_rays_at_mesh_device(self, rayset, origin, out=None, scene=None, label_image=False, renumber=False):
         """Fusion -> range image without leaving HBM: marching cubes on the device, then the single-origin render of
         ``rayset`` (a :class:`~lidar_transfer_amd.raytracer.RaySet`).  Returns the dict of device tensors of
-        ``Scene.render`` plus ``mesh`` (the :class:`DeviceMesh`)."""
+        ``Scene.render`` plus ``mesh`` (the :class:`DeviceMesh`).  ``renumber``: number the vertices as scikit-image does
+        before the render (the images do not depend on it; the mesh arrays then equal the reference's)."""
         from .raytracer import Scene
         mesh = self.extract_mesh()
+        if renumber:
+            mesh.renumber()
         if scene is None:
             scene = getattr(self, "_scene", None) or Scene(self.device.index)
             self._scene = scene
@@ -247,7 +251,7 @@ class TSDFVolume:
                 cached[2].close()
             cached = (key, rays_t, RaySet(rays_t, int(H)))
             self._rs = cached
-        o = self.throw_rays_at_mesh_device(cached[2], [float(x) for x in np.asarray(origin).reshape(-1)[:3]])
+        o = self.throw_rays_at_mesh_device(cached[2], [float(x) for x in np.asarray(origin).reshape(-1)[:3]], renumber=True)
         torch.cuda.synchronize(self.device)
         v, f, c, r = o["mesh"].tensors()
         return (o["endpoints"].cpu().numpy().reshape(-1, 3), o["endcolors"].cpu().numpy().reshape(-1, 3),
@@ -332,6 +336,15 @@ class DeviceMesh:
     @property
     def n_faces(self):
         return self._get()[1]
+
+    def renumber(self):
+        """Number the vertices as scikit-image does -- by first use in the face stream -- (``lt_mesh_renumber_dev``): the four
+        arrays then equal the reference's ``get_mesh`` arrays element for element.  Before any ``Scene.set_device_mesh`` of
+        this extraction: the vertex arrays move."""
+        C = self._C
+        st = self._torch.cuda.current_stream(self.device)
+        self._libmod.check(self._lib.lt_mesh_renumber_dev(self._h, C.c_void_p(st.cuda_stream)), "lt_mesh_renumber_dev")
+        return self
 
     def tensors(self):
         """``(verts, faces, colors, rem)`` as zero-copy device tensors."""

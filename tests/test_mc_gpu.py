@@ -156,6 +156,9 @@ def test_fused_volume_mesh_equals_oracle_and_renders_in_hbm(oracle):
     # get_mesh: the reference's 5-tuple (fusion_lidar.py:424)
     v, f, norms, colors, r = vol.get_mesh(None)
     assert v.dtype == np.float32 and f.dtype == np.int32 and colors.dtype == np.uint8 and colors.shape == v.shape
+    # ... with scikit-image's vertex numbers (lt_mesh_renumber_dev): the oracle's arrays (= the reference's, golden F10)
+    assert np.array_equal(v.view(np.int32), want[0].view(np.int32)) and np.array_equal(f, want[1])
+    assert np.array_equal(colors, np.asarray(want[2]).astype(np.uint8)) and np.array_equal(r.view(np.int32), want[3].view(np.int32))
     # the whole chain on the device == the drop-in host call on the downloaded mesh
     HT, WT = 32, 512
     rays = create_rays(10.0, -30.0, HT, WT)

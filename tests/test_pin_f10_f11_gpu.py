@@ -58,6 +58,13 @@ def test_f10_marching_cubes_vertex_set_equals_scikit_image(case):
     assert f.shape[0] == int(g["n_faces"])
     from mesh_canon import assert_same_mesh
     assert_same_mesh((v, f, c, r), (g["verts"], g["faces"], g["colors"].astype(np.int32), g["vrem"]), f"{case}: ")
+    # ... and with scikit-image's vertex numbers (lt_mesh_renumber_dev): the reference's arrays, element for element
+    m, _ = _device_mesh(case)
+    v, f, c, r = [t.cpu().numpy() for t in m.renumber().tensors()]
+    m.close()
+    assert np.array_equal(v.view(np.int32), g["verts"].view(np.int32)), "verts"
+    assert np.array_equal(f, g["faces"]), "faces"
+    assert np.array_equal(c.astype(np.uint8), g["colors"]) and np.array_equal(r.view(np.int32), g["vrem"].view(np.int32))
 
 
 @pytest.mark.parametrize("case", [k for k, s in sorted(pin_cases.MC_CASES.items()) if s is not None])
