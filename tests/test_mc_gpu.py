@@ -51,6 +51,29 @@ def test_white_noise_equals_oracle_on_every_word_layout(oracle, shape):
         assert want[1].shape[0] > 10
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_fuzz_volume_kinds_equal_oracle(oracle, kind):
+    """The volume kinds of tools/mc_lewiner_fuzz.py (on which the oracle equals the real scikit-image, 1 000 volumes) through
+    the device path: dense noise, smooth fields, exact zeros, values on a coarse grid (exact ties of the asymptotic decider
+    and of the interior test -- scikit-image's `+ eps` in the denominators decides them), clipped TSDF-like fields."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from mc_lewiner_fuzz import volume
+    rng = np.random.default_rng(900 + kind)
+    faces = 0
+    for rep in range(4):
+        shape = tuple(int(x) for x in rng.integers(3, 24, 2)) + (int(rng.integers(3, 140)),)
+        t = np.ascontiguousarray(volume(rng, kind, shape), np.float32)
+        col = (rng.integers(0, 260, shape) * 65536).astype(np.float32)
+        rem = rng.random(shape).astype(np.float32)
+        org = np.array([0.5, -1.0, 2.0], np.float32)
+        want = oracle.marching_cubes(t, col, rem, 0.05, org)
+        _assert_same_mesh(_gpu_mesh(t, col, rem, 0.05, org), want)
+        faces += want[1].shape[0]
+    assert faces > 1000
+
+
 def test_more_ambiguous_cells_than_the_queue_holds_grow_the_buffers_and_start_over(oracle):
     """White noise makes a third of all cells one of Lewiner's ambiguous cases: 546 000 cells queue ~180 000 of them, more
     than the 65 536 the side buffers start with -- the extraction sees the overflow at its one host synchronisation, grows

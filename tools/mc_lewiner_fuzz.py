@@ -13,16 +13,23 @@ import os
 import sys
 
 import numpy as np
-from skimage import measure
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "oracle", "liblt_oracle.so"))
 fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-lib.lto_marching_cubes.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int, C.c_int, ip, ip]
-lib.lto_marching_cubes.restype = C.c_int
+_lib = None
+
+
+def _oracle():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(os.path.join(ROOT, "oracle", "liblt_oracle.so"))
+        _lib.lto_marching_cubes.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, fp, fp, ip, ip, fp, C.c_int, C.c_int, ip, ip]
+        _lib.lto_marching_cubes.restype = C.c_int
+    return _lib
 
 
 def ours(vol):
+    lib = _oracle()
     vol = np.ascontiguousarray(vol, np.float32)
     zeros = np.zeros_like(vol)
     org = np.zeros(3, np.float32)
@@ -57,6 +64,7 @@ def volume(rng, kind, shape):
 
 
 def main():
+    from skimage import measure   # (only here: `volume` is imported by tests/test_mc_gpu.py under the system interpreter)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
