@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/stress_mc.py [n] [seed] -- marching cubes on the device against the CPU oracle (which returns scikit-image 0.18.3's
+"""tests/stress_mc.py [n] [seed] -- marching cubes on the device against the CPU oracle (which returns scikit-image 0.18.3's
 arrays: goldens F10 / F10b, tools/mc_lewiner_fuzz.py) on random volumes of the five fuzz kinds and random shapes (nz on both
 sides of the 64-bit word boundaries), through ONE mesh object (buffers grown, shrunk, the side table emptied in between):
 the same vertices and the same face stream, and after lt_mesh_renumber_dev the same arrays element for element."""
@@ -12,17 +12,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))  # (mc_lewiner_fuzz.volume)
 
 
-def main():
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
     import torch
     from mc_lewiner_fuzz import volume
     from mesh_canon import assert_same_mesh
     from lidar_transfer_amd.fusion import DeviceMesh
     from oracle import binding as ob
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n = int(argv[1]) if len(argv) > 1 else 200
+    rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 0)
     dev = torch.device("cuda", 0)
     m = DeviceMesh(0)
     faces = cells = bad = 0

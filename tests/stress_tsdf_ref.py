@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/stress_tsdf_ref.py [n] [seed] -- the reference's own TSDF `integrate` kernel (its source compiled for gfx950,
+"""tests/stress_tsdf_ref.py [n] [seed] -- the reference's own TSDF `integrate` kernel (its source compiled for gfx950,
 oracle/_ref/libref_tsdf_integrate{,_plain}.so) against TSDFVolume.integrate and integrate_multi on RANDOM configurations:
 field of view, voxel size, volume extent and offset (the sensor on / off a lattice point, inside / outside the volume), image
 shape, number and content of the observations (zero / -1 / NaN / infinite depth pixels, 1-4 classes), both branches.  All
@@ -15,12 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
     import torch
     from lidar_transfer_amd.fusion import TSDFVolume
     from oracle import binding as ob
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n = int(argv[1]) if len(argv) > 1 else 40
+    rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 0)
     dev = torch.device("cuda", 0)
     vp = C.c_void_p
     bad = 0
