@@ -29,7 +29,10 @@ def main():
     dev = torch.device("cuda", 0)
     sc = Scene(0)
     sc.set_mesh(*[torch.from_numpy(x).to(dev) for x in synth_scene(0, wl["tris"])])
-    rs = RaySet(torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev), H)
+    # the reference's `normalize` seeds 1/sqrt with RSQRTSS, whose bits are CPU-vendor specific: the LIVE
+    # reference below runs on this box's host, so the ray set replays this host's table
+    amd_host = "authenticamd" in open("/proc/cpuinfo").read(4096).lower()
+    rs = RaySet(torch.from_numpy(create_rays(wl["fov_up"], wl["fov_down"], H, W)).to(dev), H, exact_normalize="amd" if amd_host else False)
     o = sc.render(rs, (0, 0, 0))
     torch.cuda.synchronize()
     lab = o["endcolors"][:, 2].reshape(H, W).float()
@@ -46,9 +49,44 @@ def main():
     v, f, c, r = [t.cpu().numpy() for t in mesh.renumber().tensors()]
     same = (np.array_equal(v.view(np.int32), want[0].view(np.int32)) and np.array_equal(f, want[1]) and
             np.array_equal(c, np.asarray(want[2])) and np.array_equal(r.view(np.int32), want[3].view(np.int32)))
+    # ... and the reference's tail of deform('mesh') at full size: the REAL reference raytracer (oracle/_ref, the reference's C++
+    # compiled in place) on the oracle's mesh (= scikit-image's arrays) against the device chain (its own mesh, its own ray cast)
+    line2 = "reference raytracer build absent"
+    ok_img = True
+    if ob.ref_available("strict"):
+        rays = create_rays(wl["fov_up"], wl["fov_down"], H, W)
+        t2 = time.time()
+        refimg = ob.ref_trace(rays, np.zeros(3, np.float32), want[0], want[1], np.asarray(want[2], np.int32), want[3], H, kind="strict")
+        t3 = time.time()
+        chain = vol.throw_rays_at_mesh_device(rs, (0.0, 0.0, 0.0))
+        torch.cuda.synchronize()
+        rng_ = chain["range"].cpu().numpy().reshape(-1)
+        lab_ = chain["endcolors"].cpu().numpy().reshape(-1, 3)
+        rem_ = chain["endrem"].cpu().numpy().reshape(-1)
+        same_r = rng_.view(np.int32) == np.asarray(refimg["range"], np.float32).reshape(-1).view(np.int32)
+        same_l = (lab_ == np.asarray(refimg["endcolors"]).reshape(-1, 3)).all(1)
+        same_m = rem_.view(np.int32) == np.asarray(refimg["endrem"], np.float32).reshape(-1).view(np.int32)
+        line2 = (f"reference raytracer on scikit-image's mesh vs the device chain, {H} x {W} rays: range bit-identical on {same_r.mean():.6f} of the "
+                 f"pixels, labels on {same_l.mean():.6f}, remission on {same_m.mean():.6f}; {int((rng_ > 0).sum())} hits; reference {t3 - t2:.1f} s")
+        refr = np.asarray(refimg["range"], np.float32).reshape(-1)
+        dif = np.flatnonzero(~same_r)
+        flips = int(((rng_[dif] > 0) != (refr[dif] > 0)).sum())
+        line2 += (f"; the {len(dif)} differing pixels: {flips} hit / miss flips, max |d range| "
+                  f"{float(np.abs(rng_[dif] - refr[dif]).max()) if len(dif) else 0.0:.3g} m")
+        if os.environ.get("LT_STRESS_VERBOSE"):
+            for pidx in dif[:12]:
+                print("  pixel row", int(pidx) // W, "col", int(pidx) % W, "ray", rays[pidx].tolist(), "device", float(rng_[pidx]), "reference", float(refr[pidx]))
+            brute = ob.oracle_trace(rays, np.zeros(3, np.float32), want[0], want[1], np.asarray(want[2], np.int32), want[3], H,
+                                    mode=ob.MODE_BRUTE, norm=ob.NORM_AMD_TABLE if amd_host else ob.NORM_SSE_TABLE)
+            bvh = ob.oracle_trace(rays, np.zeros(3, np.float32), want[0], want[1], np.asarray(want[2], np.int32), want[3], H,
+                                  mode=ob.MODE_REF_BVH, norm=ob.NORM_AMD_TABLE if amd_host else ob.NORM_SSE_TABLE)
+            print("  device == brute-force oracle:", bool(np.array_equal(rng_.view(np.int32), brute["range"].view(np.int32))),
+                  "| reference == its restated BVH:", bool(np.array_equal(refr.view(np.int32), bvh["range"].view(np.int32))))
+        ok_img = bool(same_r.mean() >= 0.9999 and same_l.mean() >= 0.9999)
     print(f"default volume {tsdf.shape}: {want[0].shape[0]} vertices, {want[1].shape[0]} faces -- device mesh = oracle mesh (vertices, face "
           f"stream); after renumbering the arrays are {'EQUAL element for element' if same else 'DIFFERENT'}; oracle {t1 - t0:.0f} s on the host")
-    return 0 if same else 1
+    print("default volume: " + line2)
+    return 0 if (same and ok_img) else 1
 
 
 if __name__ == "__main__":

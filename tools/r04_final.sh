@@ -7,7 +7,7 @@ mkdir -p gpurun_out/r04
   timeout 900 python tests/stress_mc.py 300 1 2>&1 | tail -2          # marching cubes vs the oracle (= scikit-image's arrays)
   timeout 900 python tests/stress_tsdf_ref.py 300 7 2>&1 | tail -2; } > gpurun_out/r04/gpu_suite.txt 2>&1   # integrate vs the reference's kernel build
 # row f2 at BASELINE's full size: the device's marching cubes on the default 800 M-voxel volume vs the oracle (= scikit-image's arrays)
-(echo "# python tests/stress_mc_full.py"; timeout 1200 python tests/stress_mc_full.py 2>&1 | grep "default volume") > gpurun_out/r04/mc_full_size.txt
+(echo "# python tests/stress_mc_full.py"; timeout 1200 python tests/stress_mc_full.py 2>&1 | grep "default volume") > gpurun_out/r04/mc_full_size_rerun.txt  # (profiles/r04/mc_full_size.txt: the verbose run, kept by hand)
 # row f1's pin: the reference's own kernel source (compiled for gfx950, oracle/_ref) next to the product -- what ran, what it cost
 timeout 900 python -m pytest tests/test_tsdf_ref_kernel_gpu.py -m gpu -q -s 2>&1 | grep -E "reference kernel|default volume|passed|failed" > gpurun_out/r04/tsdf_ref_kernel.txt
 # yardstick for the LBVH build's sort (ms_sort in the bench line): the ROCm library's device radix sort on the same job
