@@ -165,3 +165,28 @@ def test_cloud_pipeline_with_scans_in_flight_equals_the_single_chain():
             assert got["n_faces"] == nf
             assert torch.equal(got["range"].view(torch.int32), r.reshape(-1).view(torch.int32))
             assert torch.equal(got["endcolors"], l.reshape(-1))
+
+
+@pytest.mark.parametrize("pf", [False, True])
+def test_cp_adaption_equals_the_references_own_deform_and_write(pf):
+    """Golden F12 (tests/golden/make_golden_deform.py): the reference's `MultiSemLaserScan.deform('cp', poses, idx)` + `write()`
+    run AS A WHOLE on three seeded source scans (identity poses) -- the bytes of velodyne/NNNNNN.bin and labels/NNNNNN.label and
+    the images `deform` leaves on the object.  `DeviceDeform.cp` of the same clouds must produce the same bytes."""
+    import os
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f12_deform_cp.npz"))
+    src = (int(g["source"][0]), int(g["source"][1]), float(g["source"][2]), float(g["source"][3]))
+    tgt = (int(g["target"][0]), int(g["target"][1]), float(g["target"][2]), float(g["target"][3]))
+    clouds = [(torch.from_numpy(g[f"points{k}"]).cuda(), torch.from_numpy(g[f"rem{k}"]).cuda(),
+               torch.from_numpy(g[f"label{k}"].astype(np.int32)).cuda()) for k in range(3)]
+    tag = "float" if pf else "int"
+    dd = DeviceDeform(src, tgt, preserve_float=pf)
+    got = dd.cp(clouds)
+    torch.cuda.synchronize()
+    assert np.array_equal(got["index"].cpu().numpy(), g[f"index_{tag}"])
+    assert np.array_equal(got["range"].cpu().numpy().view(np.int32), g[f"proj_range_{tag}"].view(np.int32))
+    assert got["bin"].cpu().numpy().tobytes() == g[f"bin_{tag}"].tobytes()
+    assert got["label_file"].cpu().numpy().tobytes() == g[f"label_{tag}"].tobytes()
+    assert g[f"bin_{tag}"].size // 16 > 3000
+    dd.close()
