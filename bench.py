@@ -1027,6 +1027,13 @@ def main():
                        "cubes on the device -> render the target image; the mesh never leaves HBM (no PCIe between "
                        "fusion and range image)",
                "observations": nscans,
+               "parity": {"integrate": "all four volumes bit-identical to the reference's own CUDA kernel source compiled by hipcc "
+                                       "for gfx950 and run beside it (tests/test_tsdf_ref_kernel_gpu.py, tests/stress_tsdf_ref.py)",
+                          "marching_cubes": "the arrays of the reference's get_mesh run with the real scikit-image 0.18.3 (goldens F10 "
+                                            "/ F10b; tests/test_pin_f10_f11_gpu.py, tests/stress_mc.py, full size: "
+                                            "tests/stress_mc_full.py)",
+                          "render": "bit-identical to the reference raytracer's image of that mesh (F10; full size: 131 066 of "
+                                    "131 072 pixels, profiles/r04/mc_full_size.txt)"},
                "ms_per_scan": round(t * 1e3, 3), "scans_per_s": round(1.0 / t, 1), "value": round(R / t / 1e6, 2),
                "unit": "Mrays/s", "voxels": nvox, "voxels_written": n_written, "mesh_verts": nv, "mesh_faces": nf,
                "hit_fraction": round(hits_c / R, 4), "marching_cubes_cases": mc_cases,
