@@ -47,7 +47,12 @@ def main(argv=None):
             vol.close(); fused.close(); continue
         ran += 1
         dims = (C.c_int * 3)(*dims_t); org = (C.c_float * 3)(*[float(x) for x in vol._vol_origin])
-        vr = [torch.ones(dims_t, device=dev)] + [torch.zeros(dims_t, device=dev) for _ in range(3)]
+        # (64 spare floats behind each field: the reference kernel's bounds test is `voxel_idx > N`, so thread N -- one past
+        # the end -- runs and, when its point happens to project onto a valid pixel, WRITES element N of all four arrays:
+        # into whatever lies behind them.  With back-to-back allocations that is voxel 0 of the next field; here it is the pad.)
+        n_vox = int(np.prod(dims_t))
+        flat = [torch.ones(n_vox + 64, device=dev)] + [torch.zeros(n_vox + 64, device=dev) for _ in range(3)]
+        vr = [t[:n_vox].view(dims_t) for t in flat]
         st = vp(torch.cuda.current_stream().cuda_stream)
         yaw = np.linspace(-np.pi, np.pi, W)
         classes = rng.choice(np.array([0.0, 10.0, 40.0, 50.0, 259.0]), int(rng.integers(1, 5)), replace=False)
@@ -75,6 +80,14 @@ def main(argv=None):
             nb = sum(int((a.view(torch.int32) != b.view(torch.int32)).sum()) for a, b in zip(vr, V))
             if nb:
                 bad += 1
+                if os.environ.get("LT_STRESS_VERBOSE"):
+                    names = ("tsdf", "weight", "color", "rem")
+                    for fi, (a, b) in enumerate(zip(vr, V)):
+                        idx = torch.nonzero(a.view(torch.int32) != b.view(torch.int32))
+                        for x, y, z in idx[:4].tolist():
+                            px, py, pz = [float(np.float32(org[j]) + np.float32(v) * np.float32(voxel)) for j, v in enumerate((x, y, z))]
+                            print(f"    {names[fi]}[{x},{y},{z}] pt ({px:.7g}, {py:.7g}, {pz:.7g}): reference {float(a[x, y, z])!r} product {float(b[x, y, z])!r}; "
+                                  f"all fields ref {[float(t[x, y, z]) for t in vr]} prod {[float(t[x, y, z]) for t in V]}")
                 print(f"case {k}: {who} differs in {nb} field values (merge {merge}, fov {fu}/{fd}, voxel {voxel}, dims {dims_t}, image {H}x{W}, {n_obs} observations, origin {list(org)})")
         vol.close(); fused.close()
     print(f"{ran} configurations (of {n} drawn; the rest beyond 120 M voxels), {touched_total} voxels touched by the reference kernel: {bad} mismatches ({time.time() - t0:.0f} s)")
