@@ -10,6 +10,7 @@ import glob
 import hashlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -365,3 +366,49 @@ def test_compare_restatement_negative_labels_vs_reference_python(case):
     assert np.array_equal(r["rem_diff"].view(np.int32), g[f"{case}_rem_diff"].view(np.int32))
     assert r["m_iou"] == float(g[f"{case}_m_iou"]) and r["m_acc"] == float(g[f"{case}_m_acc"])
     assert np.float32(r["MSE"]) == g[f"{case}_mse"]
+
+
+def test_projection_restatement_vs_the_live_reference_on_random_clouds():
+    """Where the reference checkout is present (the build container; never the GPU box): oracle/projection.py against the
+    reference's OWN `do_range_projection_new` + `do_label_projection_new` run right here, on 40 random float64 clouds --
+    random image shapes, fields of view, `remove`, beam tables, depth-0 points, exact duplicates (depth ties), points outside
+    the field of view.  Range, remission, index, proj_x / proj_y and label images must be the reference's arrays."""
+    ref = os.environ.get("LT_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "auxiliary")):
+        pytest.skip("reference checkout absent")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    from oracle import projection as op
+    from lidar_transfer_amd.synth import synth_cloud
+    ls, _ = make_golden.import_reference()
+    color_dict = {0: [0, 0, 0], 10: [245, 150, 100], 40: [255, 0, 255], 48: [75, 0, 75], 50: [0, 200, 255],
+                  70: [0, 175, 0], 80: [150, 240, 255]}
+    rng = np.random.default_rng(2025)
+    filled = 0
+    for k in range(40):
+        H, W = int(rng.choice([5, 16, 32, 64])), int(rng.choice([7, 64, 257, 512, 1024]))
+        fu, fd = float(rng.choice([2.0, 3.0, 10.0, 15.0])), -float(rng.choice([16.6, 25.0, 30.0]))
+        n = int(rng.integers(500, 20000))
+        pts, rem, lab = synth_cloud(300 + k, n, dtype=np.float64, fov_up=fu + 3.0, fov_down=fd - 3.0)
+        pts[rng.integers(0, n, 3)] = 0.0
+        dup = rng.integers(0, n, 40)
+        pts[dup[:20]] = pts[dup[20:]]
+        remove = bool(rng.random() < 0.7)
+        beams = sorted((np.linspace(fd, fu, H) / 180.0 * np.pi).tolist()) if rng.random() < 0.3 else None
+        lab = lab.astype(np.uint32)
+        s = ls.SemLaserScan(H, W, 300, color_dict, None, beams)
+        s.points, s.remissions, s.label = pts.copy(), rem.copy(), lab.copy()
+        s.colorize()
+        s.do_range_projection_new(fu, fd, remove=remove)
+        s.do_label_projection_new()
+        o = op.range_projection(pts, rem, H, W, fu, fd, beam_angles=beams, remove=remove, method="new")
+        assert _bits_equal(o["range"], np.asarray(s.range_image)), k
+        assert np.array_equal(o["index"], np.asarray(s.index)), k
+        assert np.array_equal(o["remission"], np.asarray(s.proj_remissions)), k
+        own = o["index"] >= 0
+        assert np.array_equal(o["px"][o["index"][own]], np.asarray(s.proj_x)[own]), k
+        assert np.array_equal(o["py"][o["index"][own]], np.asarray(s.proj_y)[own]), k
+        lab_img = op.label_projection(o["index"], lab[o["kept"]])
+        assert np.array_equal(lab_img[own], np.asarray(s.label_image)[..., 0][own].astype(np.int32)), k
+        filled += int(own.sum())
+    assert filled > 50000
