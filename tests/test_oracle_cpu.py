@@ -412,3 +412,22 @@ def test_projection_restatement_vs_the_live_reference_on_random_clouds():
         assert np.array_equal(lab_img[own], np.asarray(s.label_image)[..., 0][own].astype(np.int32)), k
         filled += int(own.sum())
     assert filled > 50000
+
+
+def test_create_rays_vs_the_live_reference_on_random_sensors():
+    """... and the host mirror of `create_rays` (laserscan.py:1092-1119) against the reference's own, for 30 random sensor
+    models, where the checkout is present."""
+    ref = os.environ.get("LT_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "auxiliary")):
+        pytest.skip("reference checkout absent")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    ls, _ = make_golden.import_reference()
+    rng = np.random.default_rng(7)
+    for _k in range(30):
+        fu, fd = float(rng.uniform(0.5, 45.0)), -float(rng.uniform(5.0, 50.0))
+        H, W = int(rng.integers(1, 130)), int(rng.integers(1, 2100))
+        want = ls.MultiSemLaserScan.create_rays(None, fu, fd, H, W)
+        got = create_rays(fu, fd, H, W)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert np.array_equal(got.view(np.int32), np.asarray(want).view(np.int32)), (fu, fd, H, W)
