@@ -1,10 +1,13 @@
-"""Seeded inputs shared by the generators of the still-missing golden fixtures (tests/golden/make_golden_mc.py,
-make_golden_tsdf_cuda.py -- they need scikit-image / pycuda, which this image does not have) and by the GPU tests that
-consume those fixtures when present (tests/test_pin_f10_f11_gpu.py).  numpy only, deterministic for a seed on any machine
-(integer lattices, float64 sin/cos rounded to float32 afterwards)."""
+"""Seeded inputs shared by the generators of golden fixtures that need the reference's own environment (tests/golden/
+make_golden_mc.py: scikit-image, run with the image's /opt/conda interpreter; make_golden_tsdf_cuda.py: pycuda + an NVIDIA GPU;
+make_golden_deform_fuzz.py) and by the GPU tests that consume those fixtures (tests/test_pin_f10_f11_gpu.py,
+tests/test_deform_gpu.py).  numpy only, deterministic for a seed on any machine (integer lattices, float64 sin/cos rounded to
+float32 afterwards)."""
 from __future__ import annotations
 
 import numpy as np
+
+from lidar_transfer_amd.synth import synth_cloud
 
 # ---- F10: marching cubes (fusion_lidar.py:403-424) ----------------------------------------------------------------------
 #: name -> (H, W, fov_up, fov_down) of the image rendered from the extracted mesh (None: no render, mesh only)
@@ -83,3 +86,32 @@ def tsdf_observations(n=3):
         rem = rng.random((H, W)).astype(np.float32)
         out.append((label3, depth, rem))
     return out
+
+
+# ---- golden F12b (tests/golden/make_golden_deform_fuzz.py): random configurations of the closest-point adaption -------------
+def deform_cp_case(k):
+    rng = np.random.default_rng(5000 + k)
+    H, W = int(rng.choice([8, 16, 32, 64])), int(rng.choice([64, 256, 500, 1024]))
+    fu, fd = float(rng.choice([2.0, 3.0, 10.0, 15.0])), -float(rng.choice([16.6, 25.0, 30.0]))
+    nscans = int(rng.integers(1, 4))
+    sizes = [int(rng.integers(800, 9000)) for _ in range(nscans)]
+    beams = bool(rng.random() < 0.33)
+    pf = bool(k % 2)
+    return H, W, fu, fd, sizes, beams, pf
+
+
+def deform_cp_clouds(k):
+    H, W, fu, fd, sizes, beams, pf = deform_cp_case(k)
+    rng = np.random.default_rng(9000 + k)
+    out = []
+    for j, n in enumerate(sizes):
+        pts, rem, lab = synth_cloud(7000 + 10 * k + j, n, dtype=np.float64, fov_up=fu + 2.0, fov_down=fd - 2.0)
+        pts[rng.integers(0, n, 2)] = 0.0
+        d = rng.integers(0, n, 20)
+        pts[d[:10]] = pts[d[10:]]
+        lab = np.where(lab == 0, 40, lab).astype(np.uint32)
+        lab[rng.integers(0, n, max(n // 80, 1))] = 0
+        out.append((pts, rem.astype(np.float32), lab))
+    return out
+
+

@@ -190,3 +190,38 @@ def test_cp_adaption_equals_the_references_own_deform_and_write(pf):
     assert got["label_file"].cpu().numpy().tobytes() == g[f"label_{tag}"].tobytes()
     assert g[f"bin_{tag}"].size // 16 > 3000
     dd.close()
+
+
+def test_cp_adaption_on_random_configurations_equals_the_references_own_deform_and_write():
+    """Golden F12b (tests/golden/make_golden_deform_fuzz.py): the reference's `deform('cp')` + `write()` on 24 random
+    configurations -- image shapes up to 64 x 1024 (W = 500 included), 1-3 source scans, beam tables, `preserve_float` on and
+    off, depth-0 points, duplicates, unlabeled points -- as SHA-256 of the written files' bytes, the `index` image and
+    `back_points` as float32.  The clouds are rebuilt from their seeds (tests/pin_cases.py); `DeviceDeform.cp` must hash the same."""
+    import hashlib
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pin_cases
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f12b_deform_cp_fuzz.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    written = 0
+    for k in range(int(g["n_cases"])):
+        H, W, fu, fd, sizes, beams, pf = pin_cases.deform_cp_case(k)
+        ba = sorted((np.linspace(fd, fu, H) / 180.0 * np.pi).tolist()) if beams else None
+        clouds = [(torch.from_numpy(p).cuda(), torch.from_numpy(r).cuda(), torch.from_numpy(l.astype(np.int32)).cuda())
+                  for p, r, l in pin_cases.deform_cp_clouds(k)]
+        dd = DeviceDeform((H, W, fu, fd), (H, W, fu, fd), beam_angles=ba, preserve_float=pf)
+        got = dd.cp(clouds)
+        torch.cuda.synchronize()
+        what = f"case {k}: {H}x{W} fov {fu}/{fd} scans {sizes} beams {beams} preserve_float {pf}"
+        assert sha(got["index"].cpu().numpy()) == str(g[f"sha_index_{k}"]), what + " (index image)"
+        # (float64 sin / cos of two math libraries: the last ulp of the double may differ; the float32 `write` packs must not)
+        assert sha(got["back_points"].cpu().numpy().astype(np.float32)) == str(g[f"sha_back32_{k}"]), what + " (back_points)"
+        assert got["bin"].shape[0] == int(g[f"n_written_{k}"]), what
+        assert sha(got["bin"].cpu().numpy()) == str(g[f"sha_bin_{k}"]), what + " (.bin bytes)"
+        assert sha(got["label_file"].cpu().numpy()) == str(g[f"sha_label_{k}"]), what + " (.label bytes)"
+        written += got["bin"].shape[0]
+        dd.close()
+    assert written > 50000
