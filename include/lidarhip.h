@@ -307,6 +307,8 @@ typedef struct lt_proj_images {
   void* proj_xf;
   void* proj_yf;
   int* n_kept;
+  double* bnds; /* [6] {xmin, xmax, ymin, ymax, zmin, zmax} of the KEPT points: SemLaserScan.get_bnds() after the projection's
+                 * remove_points (laserscan.py:678-681, read by deform('mergemesh') :957); (+inf, -inf) when none is kept */
 } lt_proj_images;
 int lt_projector_create(lt_projector** projector, int device);
 int lt_projector_destroy(lt_projector* projector);
@@ -320,6 +322,10 @@ int lt_range_projection_batch_dev(lt_projector* projector, int n_clouds, const l
 typedef struct lt_tsdf lt_tsdf; /* opaque: four float32 volumes [dim_x][dim_y][dim_z] (tsdf, weight, colour, rem) */
 
 #define LT_TSDF_MERGE 1u /* class-aware update, the branch the reference runs (fusion_lidar.py:177, :191-228) */
+/* the reference's numpy branch of `integrate` (FUSION_GPU_MODE == 0: what it runs without pycuda, fusion_lidar.py:290-388):
+ * float64 voxel projection, plain running average (float64 sum and quotient), per-channel colour average with
+ * round-half-even, remissions NOT integrated.  Excludes LT_TSDF_MERGE (the numpy branch has no class-aware update). */
+#define LT_TSDF_HOST_MODE 2u
 
 /* vol_bnds = {xmin, xmax, ymin, ymax, zmin, zmax} (metres), fov in degrees.  Replaces TSDFVolume.__init__
  * (auxiliary/fusion_lidar.py:23-63): dims = ceil(extent / voxel_size), truncation = 5 voxels,

@@ -20,6 +20,7 @@ LT_TRACE_NORM_AMD = 16
 LT_PROJ_REMOVE = 1
 LT_PROJ_NEW = 2
 LT_TSDF_MERGE = 1
+LT_TSDF_HOST_MODE = 2
 
 #: every symbol include/lidarhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_dev", "lt_scene_set_mesh_host",
@@ -54,7 +55,7 @@ class Cloud(C.Structure):
 class ProjImages(C.Structure):
     """Mirror of ``lt_proj_images``: the [H*W] DEVICE images of one cloud; NULL = not wanted."""
     _fields_ = [(k, C.c_void_p) for k in ("idx", "range", "xyz", "rem", "label", "color", "mask", "label_folded", "proj_x",
-                                           "proj_y", "proj_xf", "proj_yf", "n_kept")]
+                                           "proj_y", "proj_xf", "proj_yf", "n_kept", "bnds")]
 
 
 _lib = None

@@ -109,6 +109,7 @@ struct lt_tsdf {
   int dim[3];
   float origin[3];
   float voxel_size, trunc_margin;
+  double voxel_size_d;  // as given (the numpy branch of the reference computes with the Python float, fusion_lidar.py:300)
   double fov_up_deg, fov_down_deg;
   size_t n;
   float *tsdf, *weight, *color, *rem;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_resolve(const T* __restrict__ pts, cons
   const unsigned lab = (has && label) ? label[i] : 0u;
   if (label_img) label_img[c] = (int)lab;
   if (color_img) {
-    const bool ok = has && lut && (int)lab < lut_len;
+    const bool ok = has && lut && lab < (unsigned)lut_len;
     color_img[3 * (size_t)c] = ok ? lut[3 * (size_t)lab] : 0.f;
     color_img[3 * (size_t)c + 1] = ok ? lut[3 * (size_t)lab + 1] : 0.f;
     color_img[3 * (size_t)c + 2] = ok ? lut[3 * (size_t)lab + 2] : 0.f;
@@ -400,6 +400,8 @@ struct pb_cloud {
   int* meta;                     // [2] number of kept points, original index of the last kept point (-1: none)
   int* idx_img; float* range_img; float* xyz_img; float* rem_img; int* label_img; float* color_img; float* mask_img;
   float* fold_img; int* px_img; int* py_img; void* xf_img; void* yf_img; int* n_kept;
+  unsigned long long* bacc;      // [6] order-preserving keys of the kept points' bounds (min x, max x, min y, ...); NULL: not wanted
+  double* bnds_out;              // [6] get_bnds() of the kept points (laserscan.py:678-681), written by k_pb_prefix
 };
 struct pb_args { pb_cloud c[LT_PB_MAX]; int n_clouds; };
 
@@ -423,6 +425,15 @@ __device__ __forceinline__ int pb_key_index(unsigned long long k) {
   return (lo & 0x80000000u) ? (int)(lo & 0x7fffffffu) : (int)(0x7fffffffu - lo);
 }
 
+// order-preserving map double -> uint64 (and back): unsigned comparison of the keys == comparison of the values
+__device__ __forceinline__ unsigned long long pb_ord(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double pb_unord(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
 // MODE 0: the single-key variants (NEW on any dtype, OLD on float32).  MODE 1: OLD on float64 -- depth minimum only.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_pb_project(pb_args A, T pi_t, T abs_fov_down, T fov, int H, int W,
@@ -444,6 +455,24 @@ __global__ __launch_bounds__(256) void k_pb_project(pb_args A, T pi_t, T abs_fov
   }
   const unsigned long long m = __ballot(keep);
   if ((threadIdx.x & 63) == 0 && i < c.n) c.keep[i >> 6] = m;
+  if (c.bacc && m) {  // (wave-uniform) bounds of the kept points: SemLaserScan.get_bnds after remove_points (laserscan.py:678-681)
+    const T* pts = (const T*)c.pts;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double q = keep ? (double)pts[3 * (size_t)i + a] : 0.0;
+      unsigned long long lo = keep ? pb_ord(q) : ~0ull, hi = keep ? pb_ord(q) : 0ull;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+      }
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&c.bacc[2 * a], lo);
+        atomicMax(&c.bacc[2 * a + 1], hi);
+      }
+    }
+  }
 }
 
 // OLD variant, float64: among the points that equal the cell's depth minimum the lowest index wins
@@ -497,6 +526,13 @@ __global__ __launch_bounds__(256) void k_pb_prefix(pb_args A) {
     c.meta[1] = last_s;
     if (c.n_kept) *c.n_kept = part[255];
   }
+  if (c.bacc && threadIdx.x < 6) {  // no kept point: (+inf, -inf) -- numpy's amin of an empty array raises
+    const unsigned long long k = c.bacc[threadIdx.x];
+    const bool is_min = (threadIdx.x & 1) == 0;
+    const bool none = is_min ? k == ~0ull : k == 0ull;
+    c.bnds_out[threadIdx.x] = none ? (is_min ? (double)INFINITY : -(double)INFINITY) : pb_unord(k);
+    c.bacc[threadIdx.x] = is_min ? ~0ull : 0ull;
+  }
 }
 
 template <typename T, int MODE>
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(256) void k_pb_resolve(pb_args A, int blocks_per_cl
   // fusion_lidar.py:260-264: float32, floor(c0 * 256 * 256 + c1 * 256 + c2))
   if (c.fold_img) c.fold_img[cell] = floorf((float)lab * 256.0f * 256.0f);
   if (c.color_img) {
-    const bool ok = has && lut && (int)lab < lut_len;
+    const bool ok = has && lut && lab < (unsigned)lut_len;
     c.color_img[3 * (size_t)cell] = ok ? lut[3 * (size_t)lab] : 0.f;
     c.color_img[3 * (size_t)cell + 1] = ok ? lut[3 * (size_t)lab + 1] : 0.f;
     c.color_img[3 * (size_t)cell + 2] = ok ? lut[3 * (size_t)lab + 2] : 0.f;
@@ -564,6 +600,7 @@ struct lt_projector {
   double* beams = nullptr;                  // [1024]
   double beams_host[1024];
   int n_beams_cached = -1;
+  unsigned long long* bacc = nullptr;       // [LT_PB_MAX][6] bounds accumulators, armed (min: ~0, max: 0); re-armed by k_pb_prefix
   float* img = nullptr;                     // lt_deform_scan_dev: [n][3][H * W] source images (range, remission, folded label)
   size_t img_cap = 0;                       // floats
   std::mutex mu;
@@ -657,13 +694,18 @@ extern "C" int lt_projector_create(lt_projector** pj, int device) {
   }
   p->device = dev;
   if (hipMalloc((void**)&p->meta, LT_PB_MAX * 2 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&p->beams, 1024 * sizeof(double)) != hipSuccess) {
+      hipMalloc((void**)&p->beams, 1024 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&p->bacc, LT_PB_MAX * 6 * sizeof(unsigned long long)) != hipSuccess) {
     if (p->meta) (void)hipFree(p->meta);
+    if (p->beams) (void)hipFree(p->beams);
     delete p;
     (void)hipGetLastError();
     lt_set_error("lt_projector_create: out of device memory");
     return LT_ERR_NO_MEMORY;
   }
+  unsigned long long arm[LT_PB_MAX * 6];
+  for (int k = 0; k < LT_PB_MAX * 6; ++k) arm[k] = (k & 1) ? 0ull : ~0ull;
+  LT_HIP(hipMemcpy(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice));
   *pj = p;
   return LT_OK;
 }
@@ -675,6 +717,7 @@ extern "C" int lt_projector_destroy(lt_projector* p) {
   pj_free(p);
   if (p->meta) (void)hipFree(p->meta);
   if (p->beams) (void)hipFree(p->beams);
+  if (p->bacc) (void)hipFree(p->bacc);
   if (p->img) (void)hipFree(p->img);
   delete p;
   return LT_OK;
@@ -727,7 +770,8 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
       c.idx_img = o.idx; c.range_img = o.range; c.xyz_img = o.xyz; c.rem_img = o.rem; c.label_img = o.label;
       c.color_img = o.color; c.mask_img = o.mask; c.fold_img = o.label_folded; c.px_img = o.proj_x; c.py_img = o.proj_y;
       c.xf_img = o.proj_xf; c.yf_img = o.proj_yf; c.n_kept = o.n_kept;
-      need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept;
+      c.bacc = o.bnds ? p->bacc + 6 * k : nullptr; c.bnds_out = o.bnds;
+      need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept || o.bnds;
     }
     for (int k = A.n_clouds; k < LT_PB_MAX; ++k) { A.c[k] = A.c[0]; A.c[k].n = 0; A.c[k].block0 = 0x7fffffff; }
     const int rc = is_f64 ? pj_run<double>(p, A, blocks, old_f64, need_prefix, fov_up, fov_down, H, W, n_beams, flags,

@@ -1702,6 +1702,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   }
   t->n = (size_t)n;
   t->voxel_size = (float)voxel_size;
+  t->voxel_size_d = voxel_size;
   t->trunc_margin = (float)(voxel_size * 5);  // fusion_lidar.py:31
   t->fov_up_deg = fov_up;
   t->fov_down_deg = fov_down;
@@ -1919,6 +1920,60 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   return LT_OK;
 }
 
+// ---- LT_TSDF_HOST_MODE: the reference's numpy branch of `integrate` (FUSION_GPU_MODE == 0, fusion_lidar.py:290-388) --------
+// What the reference runs wherever pycuda is absent -- and the only fusion mode of it that can be run next to this library
+// without an NVIDIA GPU (goldens F8, F13, F14).  NOT the CUDA kernel's arithmetic: the voxel is projected in float64 (world
+// coordinate = float32 origin + index * float64 voxel size, :299-300; norm / arctan2 / arcsin / the pixel in float64,
+// :316-331), the field-of-view test is on the float64 pitch (:341-342), tsdf is the plain running average with the float32
+// product `tsdf * w_old`, the float64 sum and quotient, rounded to float32 on the store (:352-366), the colour is averaged
+// per channel in float32 with numpy's round-half-even (:372-388), remissions are not integrated (:390-392).  One thread per
+// voxel, z fastest; expression by expression, no contraction (the file is compiled with -ffp-contract=off).
+__global__ __launch_bounds__(256) void k_tsdf_integrate_host_mode(
+    float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol, int dim_x, int dim_y, int dim_z,
+    double ox, double oy, double oz, double voxel_size, int im_h, int im_w, double trunc_margin, float obs_weight, double fov_up,
+    double fov_down, const float* __restrict__ color_im, const float* __restrict__ depth_im) {
+  const size_t n = (size_t)dim_x * dim_y * dim_z;
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  const int iz = (int)(v % dim_z), iy = (int)((v / dim_z) % dim_y), ix = (int)(v / ((size_t)dim_z * dim_y));
+  const double x = ox + (double)ix * voxel_size, y = oy + (double)iy * voxel_size, z = oz + (double)iz * voxel_size;
+  const double depth = sqrt(x * x + y * y + z * z);  // np.linalg.norm(cam_pts, 2, axis=0): sqrt(add.reduce(x * x))
+  const double fov = fabs(fov_down) + fabs(fov_up);
+  const double yaw = -atan2(y, x);
+  const double pitch = asin(z / depth);
+  double proj_x = 0.5 * (yaw / LT_PI_D + 1.0);
+  double proj_y = 1.0 - (pitch + fabs(fov_down)) / fov;
+  proj_x *= (double)im_w;
+  proj_y *= (double)im_h;
+  // np.minimum / np.maximum propagate NaN; NaN.astype(np.int32) is INT_MIN: such a voxel fails `pix >= 0` below
+  const double fx = fmax(0.0, fmin((double)(im_w - 1), floor(proj_x)));
+  const double fy = fmax(0.0, fmin((double)(im_h - 1), floor(proj_y)));
+  if (proj_x != proj_x || proj_y != proj_y) return;
+  const int pix_x = (int)fx, pix_y = (int)fy;
+  if (!(pix_x >= 0 && pix_x < im_w && pix_y >= 0 && pix_y < im_h && pitch < fov_up && pitch > fov_down)) return;
+  const double depth_val = (double)depth_im[(size_t)pix_y * im_w + pix_x];
+  const double depth_diff = depth_val - depth;
+  if (!(depth_val > 0.0 && depth_diff >= -trunc_margin)) return;
+  const double dist = fmin(1.0, depth_diff / trunc_margin);
+  const float w_old = weight_vol[v];
+  const float w_new = w_old + obs_weight;
+  weight_vol[v] = w_new;
+  const float tw = tsdf_vol[v] * w_old;
+  tsdf_vol[v] = (float)(((double)tw + dist) / (double)w_new);
+  const float old_color = color_vol[v];
+  const float old_b = floorf(old_color / 65536.0f);
+  const float old_g = floorf((old_color - old_b * 256.0f * 256.0f) / 256.0f);
+  const float old_r = old_color - old_b * 256.0f * 256.0f - old_g * 256.0f;
+  const float new_color = color_im[(size_t)pix_y * im_w + pix_x];
+  float new_b = floorf(new_color / 65536.0f);
+  float new_g = floorf((new_color - new_b * 256.0f * 256.0f) / 256.0f);
+  float new_r = new_color - new_b * 256.0f * 256.0f - new_g * 256.0f;
+  new_b = fminf(rintf((old_b * w_old + new_b) / w_new), 255.0f);
+  new_g = fminf(rintf((old_g * w_old + new_g) / w_new), 255.0f);
+  new_r = fminf(rintf((old_r * w_old + new_r) / w_new), 255.0f);
+  color_vol[v] = new_b * 256.0f * 256.0f + new_g * 256.0f + new_r;
+}
+
 extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im,
                                      int im_h, int im_w, float obs_weight, unsigned flags, void* stream_) {
   if (!t || !color_im || !depth_im || !rem_im || im_h <= 0 || im_w <= 0) {
@@ -1929,6 +1984,17 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
   LT_HIP(hipSetDevice(t->device));
   // other_params[6] * PI / 180.0 in double, stored to float (fusion_lidar.py:124-125); the launch passes the
   // degrees as float32 (:278-280)
+  if (flags & LT_TSDF_HOST_MODE) {
+    // self.fov_up / 180.0 * np.pi (fusion_lidar.py:308-309); every voxel is visited: no column stamps -> all_dirty
+    const double fu_d = t->fov_up_deg / 180.0 * LT_PI_D, fd_d = t->fov_down_deg / 180.0 * LT_PI_D;
+    hipLaunchKernelGGL(k_tsdf_integrate_host_mode, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, stream, t->tsdf, t->weight,
+                       t->color, t->dim[0], t->dim[1], t->dim[2], (double)t->origin[0], (double)t->origin[1], (double)t->origin[2],
+                       t->voxel_size_d, im_h, im_w, t->voxel_size_d * 5, obs_weight, fu_d, fd_d, color_im, depth_im);
+    LT_HIP(hipGetLastError());
+    t->all_dirty = 1;
+    t->n_obs += 1;
+    return LT_OK;
+  }
   const float fu = (float)((double)(float)t->fov_up_deg * LT_PI_D / 180.0);
   const float fd = (float)((double)(float)t->fov_down_deg * LT_PI_D / 180.0);
   // ---- a fresh volume, the class-aware update: driven by the pixels (k_tsdf_integrate_pix) --------------------------------
@@ -2027,7 +2093,7 @@ extern "C" int lt_tsdf_integrate_multi_dev(lt_tsdf* t, int n_obs, const float* c
   int px_bits = 1;
   while ((1 << px_bits) < im_w) ++px_bits;
   // the fused pass: the class-aware update of a FRESH volume, under the conditions of the pixel-centric integrate
-  const bool fuse = !pix_off && !multi_off && (flags & LT_TSDF_MERGE) && t->n_obs == 0 && !t->all_dirty && tan_ok &&
+  const bool fuse = !pix_off && !multi_off && (flags & LT_TSDF_MERGE) && !(flags & LT_TSDF_HOST_MODE) && t->n_obs == 0 && !t->all_dirty && tan_ok &&
                     30 - px_bits >= 12 && fabsf(fu) + fabsf(fd) > 0.f && n_obs >= 2;
   int done = 0;
   if (fuse) {

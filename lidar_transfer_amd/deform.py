@@ -10,6 +10,12 @@ library's device entry points on ONE HIP stream:
     -> ``write``: filter + pack ``velodyne/N.bin`` / ``labels/N.label`` (:1133-1178)
     =  ``lt_range_projection_batch_dev`` -> ``lt_fusion_scan_dev`` -> ``lt_pack_scan_dev``
 
+``mergemesh``  (:921-1012, the adaption config/lidar_transfer.yaml selects)
+    the scans merged into ONE cloud (:939-949), ``do_range_projection_new`` with the TARGET field of view onto the SOURCE
+    H x W (:929-931, :952-954), ``vol_bnds`` clipped IN PLACE by the rounded bounds of the kept points (:957-962), a fresh
+    ``TSDFVolume`` of the TARGET field of view (:968), one ``integrate``, rays of the target sensor, ray cast, ``write``
+    =  ``lt_range_projection_batch_dev`` (+ the bounds, one 48-byte read-back) -> ``lt_fusion_scan_dev`` -> ``lt_pack_scan_dev``
+
 ``cp``    (:827-861, :1121-1178)
     the merged cloud through ``do_range_projection_new(target fov, remove=True)`` + ``do_label_projection_new`` +
     ``do_reverse_projection_new`` (:841-845), then ``write`` with ``index > 0`` (:1133-1144)
@@ -39,7 +45,14 @@ class DeviceDeform:
     """
 
     def __init__(self, source, target, vol_bnds=None, voxel_size=0.1, beam_angles=None, t_beam_angles=None,
-                 preserve_float=False, device=None, merge=True):
+                 preserve_float=False, device=None, merge=True, fusion="cuda", mesh_volume=True):
+        """``fusion``: ``"cuda"`` -- the arithmetic of the reference's CUDA kernel (class-aware with ``merge``), or ``"numpy"`` --
+        that of its numpy branch (``FUSION_GPU_MODE == 0``, fusion_lidar.py:290-388; what goldens F13 / F14 are made by).
+        ``vol_bnds``: [3,2]; for :meth:`mergemesh` it is STATE, clipped in place call after call exactly as the reference
+        clips the one ``voxel_bounds`` array it hands every ``MultiSemLaserScan`` (lidar_deform.py:321-401,
+        laserscan.py:960-962, fusion_lidar.py:36) -- pass a numpy array to see it.  ``mesh_volume=False``: do not allocate the
+        fixed volume of :meth:`mesh` (a caller that only runs ``mergemesh``)."""
+        import numpy as np
         import torch
 
         from .fusion import DeviceMesh, TSDFVolume
@@ -57,9 +70,17 @@ class DeviceDeform:
         self.projector = Projector(idx)
         self._merge = _lib.LT_TSDF_MERGE if merge else 0
         self.vol = self.mesh_obj = self.scene = self.rayset = None
+        self._merge_flag, self._fusion, self._voxel_size, self._idx = bool(merge), fusion, voxel_size, idx
+        self._mm_vols = {}   # mergemesh: geometry -> TSDFVolume (the clipped bounds settle after a few output scans)
+        self.vol_bnds = None
         if vol_bnds is not None:
+            self.vol_bnds = vol_bnds if isinstance(vol_bnds, np.ndarray) else np.array(vol_bnds)
+            if self.vol_bnds.shape != (3, 2):
+                raise ValueError("DeviceDeform: vol_bnds is [3, 2] (rows x, y, z; columns min, max)")
             # the volume is the SOURCE sensor's (laserscan.py:886-887), the rays the TARGET's (:899-900)
-            self.vol = TSDFVolume(vol_bnds, voxel_size, self.fov_up, self.fov_down, device=idx, merge=merge)
+            if mesh_volume:
+                self.vol = TSDFVolume(self.vol_bnds, voxel_size, self.fov_up, self.fov_down, device=idx, merge=merge, mode=fusion)
+                self._merge = self.vol._flags
             self.mesh_obj = DeviceMesh(idx)
             self.scene = Scene(idx)
             rays = create_rays_device(self.t_fov_up, self.t_fov_down, self.t_H, self.t_W, device=idx)
@@ -125,6 +146,74 @@ class DeviceDeform:
                 timing.append(ev)
         return res
 
+    # ---- deform('mergemesh') + write ------------------------------------------------------------------------------------
+    def _mergemesh_volume(self, merged_bnds):
+        """laserscan.py:957-969 + fusion_lidar.py:33-37 on ``self.vol_bnds`` -- the same numpy statements on the same array,
+        in place -- and the device volume of the resulting geometry (kept per geometry: the bounds only ever shrink)."""
+        import numpy as np
+
+        from .fusion import TSDFVolume
+        vb = self.vol_bnds
+        mb = np.rint(merged_bnds).astype(int)                           # :957
+        vb[:, 0] = np.maximum(vb[:, 0], mb[:, 0])                       # :961
+        vb[:, 1] = np.minimum(vb[:, 1], mb[:, 1])                       # :962
+        as_given = np.array(vb, dtype=np.float64)
+        dim = np.ceil((vb[:, 1] - vb[:, 0]) / self._voxel_size).copy(order='C').astype(int)   # fusion_lidar.py:34-35
+        if (dim <= 0).any():
+            raise RuntimeError(f"DeviceDeform.mergemesh: the clipped volume is empty (bounds {vb.tolist()})")
+        vb[:, 1] = vb[:, 0] + dim * self._voxel_size                    # fusion_lidar.py:36 (an int array truncates, as there)
+        key = (tuple(float(x) for x in as_given.reshape(-1)),)
+        vol = self._mm_vols.pop(key, None)
+        if vol is None:
+            while len(self._mm_vols) >= 3:
+                self._mm_vols.pop(next(iter(self._mm_vols))).close()
+            vol = TSDFVolume(as_given, self._voxel_size, self.t_fov_up, self.t_fov_down, device=self._idx,
+                             merge=self._merge_flag, mode=self._fusion)   # (3) the TARGET field of view (:968-969)
+            assert tuple(int(x) for x in vol._vol_dim) == tuple(int(x) for x in dim)
+        self._mm_vols[key] = vol                                        # most recently used last
+        return vol
+
+    def mergemesh(self, clouds, origin=(0.0, 0.0, 0.0), pack=True):
+        """``clouds``: the (points, remissions, label) CUDA triples of the source scans, already in the primary scan's frame
+        (``apply_inv_pose``, laserscan.py:949: pose handling is out of scope).  Returns what :meth:`mesh` returns -- the
+        target scan's ``range`` / ``rem`` / ``label`` images, ``endpoints``, ``tri``, the merged cloud's source image under
+        ``source``, ``bin`` / ``label_file`` with ``pack`` -- plus ``vol_dim`` / ``vol_origin`` of this scan's volume.  One
+        read-back of 48 bytes (the kept points' bounds decide the volume's geometry) besides those of :meth:`mesh`."""
+        if self.vol_bnds is None:
+            raise RuntimeError("DeviceDeform.mergemesh: constructed without vol_bnds")
+        torch, lib = self._torch, self._lib
+        st = torch.cuda.current_stream(self.device)
+        pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
+        rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
+        lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]
+        # (1) + (2): the SOURCE image size and beam angles, the TARGET field of view (laserscan.py:929-931, :952-954)
+        src = self.projector.project([(pts, rem, lab)], self.t_fov_up, self.t_fov_down, self.H, self.W, new=True, remove=True,
+                                     beam_angles=self.beam_angles, outputs=("range", "rem", "label_folded", "bnds"),
+                                     stream=st)[0]
+        bnds = src["bnds"].cpu().numpy()      # (synchronises the stream)
+        if not (bnds[:, 0] <= bnds[:, 1]).all():
+            raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
+        vol = self._mergemesh_volume(bnds)
+        vp = C.c_void_p
+        cp, dp, rp = (vp * 1)(src["label_folded"].data_ptr()), (vp * 1)(src["range"].data_ptr()), (vp * 1)(src["rem"].data_ptr())
+        out = self.scene.alloc_outputs(self.n_rays, label_image=True)
+        org = (C.c_float * 3)(*[float(x) for x in origin])
+        flags = _lib.LT_TRACE_WRITE_MISSES | _lib.LT_TRACE_LABEL_IMAGE
+        with torch.cuda.device(self.device):
+            _lib.check(lib.lt_fusion_scan_dev(vol._h, self.mesh_obj._h, self.scene._h, self.rayset._h, 1, cp, dp, rp,
+                                              self.H, self.W, 1.0, vol._flags, org, out["endpoints"].data_ptr(),
+                                              out["endcolors"].data_ptr(), out["range"].data_ptr(),
+                                              out["endrem"].data_ptr(), out["tri"].data_ptr(), flags, vp(st.cuda_stream), 0),
+                       "lt_fusion_scan_dev")
+            res = dict(range=out["range"].view(self.t_H, self.t_W), rem=out["endrem"].view(self.t_H, self.t_W),
+                       label=out["endcolors"].view(self.t_H, self.t_W), endpoints=out["endpoints"], tri=out["tri"],
+                       source=src, n_verts=self.mesh_obj.n_verts, n_faces=self.mesh_obj.n_faces,
+                       vol_dim=tuple(int(x) for x in vol._vol_dim), vol_origin=vol._vol_origin.copy(), volume=vol)
+            if pack:
+                res["bin"], res["label_file"] = self._pack(out["endpoints"], False, out["endrem"], out["endcolors"], None,
+                                                           self.n_rays, st)
+        return res
+
     # ---- deform('cp') + write -----------------------------------------------------------------------------------------
     def cp(self, clouds, pack=True):
         """Closest point: the source scans merged into one cloud (laserscan.py:834-839), projected into the TARGET image
@@ -169,6 +258,9 @@ class DeviceDeform:
         return int(b.shape[0])
 
     def close(self):
+        for v in getattr(self, "_mm_vols", {}).values():
+            v.close()
+        self._mm_vols = {}
         for name in ("rayset", "scene", "mesh_obj", "vol", "projector"):
             obj = getattr(self, name, None)
             if obj is not None:

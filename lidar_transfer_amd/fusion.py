@@ -79,21 +79,28 @@ class TSDFVolume:
 
     Same constructor and ``integrate`` signature; the four volumes live in HBM (``lt_tsdf``) and every
     ``integrate`` is one launch of the HIP kernel -- no per-launch image round trip, no grid loop.
-    ``merge=True`` (default) is the class-aware branch the reference runs.  ``get_mesh`` / ``extract_mesh`` run
+    ``merge=True`` (default) is the class-aware branch the reference's CUDA kernel runs; ``mode="numpy"`` selects the
+    arithmetic of the reference's OTHER fusion mode instead -- its numpy branch (``FUSION_GPU_MODE == 0``, what it runs where
+    pycuda is absent, fusion_lidar.py:290-388: float64 voxel projection, plain running average, no remissions) -- on the
+    device (``LT_TSDF_HOST_MODE``; goldens F8 / F13 / F14 are made by that branch).  ``get_mesh`` / ``extract_mesh`` run
     marching cubes on the device (``lt_mc.hip``): the mesh is born in HBM and
     ``throw_rays_at_mesh`` renders it there.
     """
 
-    def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, device=None, merge=True):
+    def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, device=None, merge=True, mode="cuda"):
         import ctypes as C
 
         import torch
 
         from . import _lib
+        if mode not in ("cuda", "numpy"):
+            raise ValueError("TSDFVolume: mode is 'cuda' (the reference's kernel) or 'numpy' (its FUSION_GPU_MODE == 0 branch)")
         self._lib = _lib.load()
         self._C, self._torch, self._libmod = C, torch, _lib
         self.fov_up, self.fov_down = fov_up, fov_down
         self.merge = merge
+        self.mode = mode
+        self._flags = _lib.LT_TSDF_HOST_MODE if mode == "numpy" else (_lib.LT_TSDF_MERGE if merge else 0)
         self._vol_bnds = np.array(vol_bnds, dtype=np.float64).reshape(3, 2)
         self._voxel_size = float(voxel_size)
         self._trunc_margin = self._voxel_size * 5
@@ -141,7 +148,7 @@ class TSDFVolume:
         st = torch.cuda.current_stream(self.device)
         self._libmod.check(self._lib.lt_tsdf_integrate_dev(self._h, folded.data_ptr(), d.data_ptr(), r.data_ptr(),
                                                            d.shape[0], d.shape[1], float(obs_weight),
-                                                           self._libmod.LT_TSDF_MERGE if self.merge else 0,
+                                                           self._flags,
                                                            C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_dev")
         st.synchronize()  # the temporaries above must outlive the kernel
 
@@ -176,7 +183,7 @@ class TSDFVolume:
             cp[k], dp[k], rp[k] = c.data_ptr(), d.data_ptr(), r.data_ptr()
         st = torch.cuda.current_stream(self.device)
         self._libmod.check(self._lib.lt_tsdf_integrate_multi_dev(self._h, n, cp, dp, rp, h, w, float(obs_weight),
-                                                                 self._libmod.LT_TSDF_MERGE if self.merge else 0,
+                                                                 self._flags,
                                                                  C.c_void_p(st.cuda_stream)), "lt_tsdf_integrate_multi_dev")
         st.synchronize()  # the temporaries above must outlive the kernels
 

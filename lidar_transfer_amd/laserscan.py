@@ -55,7 +55,8 @@ class Projector:
     float32 or None, ``label`` [n] int32 / uint32 or None.  Outputs: ``idx`` (numbering of the KEPT points, -1 empty),
     ``range``, ``xyz``, ``rem``, ``label``, ``color`` (needs ``color_lut``), ``mask``, ``label_folded`` (what
     ``TSDFVolume.integrate`` folds from ``proj_label3``), ``proj_x`` / ``proj_y`` / ``proj_xf`` / ``proj_yf``, ``n_kept``
-    (a 1-element int32 tensor).  Empty cells: 0 / -1 / 0 for range / rem / xyz with ``new`` (laserscan.py:362-368), -1
+    (a 1-element int32 tensor), ``bnds`` (a [3,2] float64 tensor: ``get_bnds()`` of the kept points, laserscan.py:678-681).
+    Empty cells: 0 / -1 / 0 for range / rem / xyz with ``new`` (laserscan.py:362-368), -1
     everywhere for the old variant (:37-53)."""
 
     _IMG = {"idx": ("int32", 1), "range": ("float32", 1), "xyz": ("float32", 3), "rem": ("float32", 1), "label": ("int32", 1),
@@ -92,9 +93,12 @@ class Projector:
         for k, (pts, rem, lab) in enumerate(clouds):
             if pts.dtype != dt:
                 raise TypeError("all clouds of one call share one dtype")
+            for name, t in (("points", pts), ("remissions", rem), ("label", lab)):
+                if t is not None and not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == self.device):
+                    raise ValueError(f"Projector.project: {name} of cloud {k} must be a CUDA tensor on {self.device}")
             pts = pts.contiguous()
             rem = rem.to(torch.float32).contiguous() if rem is not None else None
-            lab = lab.to(torch.int32).contiguous() if (lab is not None and lab.dtype not in (torch.int32,)) else lab
+            lab = lab.to(torch.int32).contiguous() if lab is not None else None   # (uint32 labels: same bits)
             keep += [pts, rem, lab]
             cl[k].points = pts.data_ptr()
             cl[k].rem = rem.data_ptr() if rem is not None else None
@@ -106,6 +110,9 @@ class Projector:
                     continue
                 if name == "n_kept":
                     o[name] = torch.empty(1, dtype=torch.int32, device=self.device)
+                    continue
+                if name == "bnds":
+                    o[name] = torch.empty((3, 2), dtype=torch.float64, device=self.device)
                     continue
                 tdt, ch = self._IMG[name]
                 tdt = dt if tdt is None else getattr(torch, tdt)

@@ -225,3 +225,139 @@ def test_cp_adaption_on_random_configurations_equals_the_references_own_deform_a
         written += got["bin"].shape[0]
         dd.close()
     assert written > 50000
+
+
+# ---- the two mesh adaptions against the reference's OWN deform() + write() (goldens F13 / F14) --------------------------------
+def _gold(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _gold_clouds(g, prefix, n):
+    import torch
+    return [(torch.from_numpy(g[f"{prefix}_points{k}"]).cuda(), torch.from_numpy(g[f"{prefix}_rem{k}"]).cuda(),
+             torch.from_numpy(g[f"{prefix}_label{k}"].astype(np.int32)).cuda()) for k in range(n)]
+
+
+def _check_against_reference_scan(got, g, tag, volume=None, fov=None):
+    """Everything the reference's object was left with after deform() + write(): the written files' bytes, the images, the
+    mesh handed to the raytracer (sizes; arrays element for element after the scikit-image renumbering), the volumes."""
+    import torch
+    torch.cuda.synchronize()
+    assert got["n_verts"] == int(g[f"{tag}_n_verts"]) and got["n_faces"] == int(g[f"{tag}_n_faces"]), \
+        (tag, got["n_verts"], got["n_faces"], int(g[f"{tag}_n_verts"]), int(g[f"{tag}_n_faces"]))
+    assert np.array_equal(got["range"].cpu().numpy().view(np.int32), g[f"{tag}_proj_range"].view(np.int32)), tag
+    assert np.array_equal(got["label"].cpu().numpy(), g[f"{tag}_label_image"]), tag
+    assert np.array_equal(got["rem"].cpu().numpy().view(np.int32), g[f"{tag}_proj_remissions"].view(np.int32)), tag
+    assert np.array_equal(got["endpoints"].cpu().numpy().view(np.int32), g[f"{tag}_back_points"].view(np.int32)), tag
+    assert got["bin"].cpu().numpy().tobytes() == g[f"{tag}_bin"].tobytes(), tag
+    assert got["label_file"].cpu().numpy().tobytes() == g[f"{tag}_label"].tobytes(), tag
+    assert g[f"{tag}_bin"].size // 16 > 1500 and (g[f"{tag}_proj_range"] > 0).sum() > 1500
+    if volume is not None:
+        _check_volumes(volume, g, tag, fov)
+
+
+def _check_volumes(volume, g, tag, fov):
+    """The volumes against the reference's (numpy fusion mode).  A voxel may differ only where the reference itself is not
+    one function: numpy's float64 arctan2 / arcsin are not correctly rounded (SVML: 7 % / 30 % of a voxel lattice's angles are
+    an ulp off in numpy 2.2 / 1.26 on this image's CPU) and their last bit decides the pixel of a voxel that projects within
+    an ulp of a pixel boundary -- lattice voxels next to |x| == |y| do.  Every differing voxel must be such a one, and there
+    must be next to none of them."""
+    tsdf, weight, color, rem = [t.cpu().numpy() for t in volume.get_volume_tensors()]
+    assert tuple(tsdf.shape) == tuple(int(x) for x in g[f"{tag}_vol_dim"])
+    assert np.array_equal(volume._vol_origin, g[f"{tag}_vol_origin"])
+    assert float(np.abs(rem).max()) == 0.0          # the numpy branch integrates no remissions (fusion_lidar.py:390-392)
+    ref_t, ref_w, ref_c = g[f"{tag}_tsdf"], g[f"{tag}_weight"].astype(np.float32), g[f"{tag}_color"]
+    assert int((ref_w > 0).sum()) == int(g[f"{tag}_n_written"]) > 10000
+    diff = (tsdf.view(np.int32) != ref_t.view(np.int32)) | (weight != ref_w) | (color != ref_c)
+    idx = np.argwhere(diff)
+    assert len(idx) <= 1e-5 * tsdf.size, f"{tag}: {len(idx)} voxels differ from the reference's volumes"
+    H, W, fu, fd = fov
+    fur, fdr = fu / 180.0 * np.pi, fd / 180.0 * np.pi
+    vs = float(volume._voxel_size)
+    for ix, iy, iz in idx:
+        x, y, z = [float(volume._vol_origin[k]) + float(i) * vs for k, i in enumerate((ix, iy, iz))]
+        depth = np.sqrt(x * x + y * y + z * z)
+        pitch, yaw = np.arcsin(z / depth), -np.arctan2(y, x)
+        px = 0.5 * (yaw / np.pi + 1.0) * W
+        py = (1.0 - (pitch + abs(fdr)) / (abs(fdr) + abs(fur))) * H
+        on_boundary = min(abs(px - np.rint(px)), abs(py - np.rint(py)), abs(pitch - fur), abs(pitch - fdr)) < 1e-11
+        assert on_boundary, f"{tag}: voxel {(ix, iy, iz)} differs and is not on a pixel / field-of-view boundary (px {px!r} py {py!r})"
+    return len(idx)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_mesh_adaption_equals_the_references_own_deform_and_write(case):
+    """Golden F13 (tests/golden/make_golden_deform_mesh.py): the reference's `MultiSemLaserScan.deform('mesh', poses, idx)`
+    (laserscan.py:863-918) + `write()` run AS A WHOLE -- its projection loop, its `TSDFVolume.integrate` in the numpy fusion mode,
+    scikit-image 0.18.3's marching cubes, its C++ raytracer, its struct.pack writer -- on 1 / 3 / 2 seeded source scans.
+    `DeviceDeform.mesh(fusion="numpy")` of the same clouds: the same volumes, the same mesh, the same images, the same bytes."""
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = _gold("f13_deform_mesh.npz")
+    src = (int(g[f"{case}_source"][0]), int(g[f"{case}_source"][1]), float(g[f"{case}_source"][2]), float(g[f"{case}_source"][3]))
+    tgt = (int(g[f"{case}_target"][0]), int(g[f"{case}_target"][1]), float(g[f"{case}_target"][2]), float(g[f"{case}_target"][3]))
+    clouds = _gold_clouds(g, case, int(g[f"{case}_n_scans"]))
+    dd = DeviceDeform(src, tgt, g[f"{case}_bnds"].copy(), float(g[f"{case}_voxel"]), fusion="numpy")
+    for rep in range(2):          # twice: the volume's reset
+        got = dd.mesh(clouds)
+        _check_against_reference_scan(got, g, case, dd.vol, src)
+    # the mesh arrays themselves, numbered as scikit-image numbers them
+    v, f, c, r = dd.mesh_obj.renumber().tensors()
+    assert [_sha(v.cpu().numpy()), _sha(f.cpu().numpy()), _sha(c.cpu().numpy().astype(np.uint8)), _sha(r.cpu().numpy())] == \
+        [str(x) for x in g[f"{case}_mesh_sha"]]
+    dd.close()
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_mergemesh_adaption_equals_the_references_own_deform_and_write(case):
+    """Golden F14: the reference's `deform('mergemesh', poses, idx)` (laserscan.py:921-1012 -- the adaption its shipped
+    config selects) + `write()` as a whole, two output scans in a row on ONE `voxel_bounds` array: the merged cloud projected
+    with the target field of view onto the source H x W, `vol_bnds` clipped in place by the rounded bounds of the kept points,
+    a volume of the target field of view whose geometry therefore changes from scan to scan.  `DeviceDeform.mergemesh`:
+    the same geometry, volumes, mesh, images, bytes -- and the same bounds left behind in the caller's array."""
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = _gold("f14_deform_mergemesh.npz")
+    src = (int(g[f"{case}_source"][0]), int(g[f"{case}_source"][1]), float(g[f"{case}_source"][2]), float(g[f"{case}_source"][3]))
+    tgt = (int(g[f"{case}_target"][0]), int(g[f"{case}_target"][1]), float(g[f"{case}_target"][2]), float(g[f"{case}_target"][3]))
+    bnds = g[f"{case}_bnds"].copy()            # an int array, as lidar_deform.py:321 makes it from the YAML
+    dd = DeviceDeform(src, tgt, bnds, float(g[f"{case}_voxel"]), fusion="numpy", mesh_volume=False)
+    for step in range(2):
+        tag = f"{case}{step}"
+        got = dd.mergemesh(_gold_clouds(g, tag, int(g[f"{case}_n_scans"])))
+        assert got["vol_dim"] == tuple(int(x) for x in g[f"{tag}_vol_dim"]), (tag, got["vol_dim"])
+        assert np.array_equal(bnds, g[f"{tag}_bnds_after"]) and bnds.dtype == g[f"{tag}_bnds_after"].dtype
+        _check_against_reference_scan(got, g, tag, got["volume"], (src[0], src[1], tgt[2], tgt[3]))
+        v, f, c, r = dd.mesh_obj.renumber().tensors()
+        assert [_sha(v.cpu().numpy()), _sha(f.cpu().numpy()), _sha(c.cpu().numpy().astype(np.uint8)), _sha(r.cpu().numpy())] == \
+            [str(x) for x in g[f"{tag}_mesh_sha"]]
+    dd.close()
+
+
+def test_mergemesh_with_the_cuda_kernels_arithmetic_runs_on_the_same_geometry():
+    """The default fusion arithmetic (the reference's CUDA kernel, class-aware) through the same mergemesh chain: same volume
+    geometry and bounds bookkeeping as the reference's run (they do not depend on the fusion mode).  The image is NOT the
+    numpy-mode golden's: on a fresh volume the class-aware kernel leaves the voxels in FRONT of a labelled surface at their
+    initial tsdf 1 (other class, dist > weight 0: fusion_lidar.py:204-213), so its zero crossing sits a fraction of a voxel
+    closer to the sensor than the plain average's -- the same surface within half a voxel."""
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = _gold("f14_deform_mergemesh.npz")
+    case = "a"
+    src = (int(g[f"{case}_source"][0]), int(g[f"{case}_source"][1]), float(g[f"{case}_source"][2]), float(g[f"{case}_source"][3]))
+    tgt = (int(g[f"{case}_target"][0]), int(g[f"{case}_target"][1]), float(g[f"{case}_target"][2]), float(g[f"{case}_target"][3]))
+    bnds = g[f"{case}_bnds"].copy()
+    dd = DeviceDeform(src, tgt, bnds, float(g[f"{case}_voxel"]), mesh_volume=False)
+    for step in range(2):
+        tag = f"{case}{step}"
+        got = dd.mergemesh(_gold_clouds(g, tag, 1))
+        assert got["vol_dim"] == tuple(int(x) for x in g[f"{tag}_vol_dim"])
+        assert np.array_equal(bnds, g[f"{tag}_bnds_after"])
+        rng, want = got["range"].cpu().numpy(), g[f"{tag}_proj_range"]
+        both = (rng > 0) & (want > 0)
+        assert both.sum() > 0.9 * (want > 0).sum()
+        assert np.median(np.abs(rng[both] - want[both])) < 0.5 * float(g[f"{case}_voxel"])
+    dd.close()

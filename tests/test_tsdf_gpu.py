@@ -112,6 +112,24 @@ def test_plain_average_branch_vs_reference_numpy_cpu_mode():
     vol.close()
 
 
+def test_numpy_mode_equals_the_reference_numpy_cpu_mode():
+    """`mode="numpy"` (LT_TSDF_HOST_MODE: the arithmetic of the reference's numpy branch, fusion_lidar.py:290-388, float64
+    voxel projection) against the same golden volumes F8: tsdf, weight and colour bit for bit -- but for the handful of voxels
+    that project within an ulp of a pixel boundary, where numpy's own (not correctly rounded) arctan2 / arcsin decide by
+    their last bit (tests/test_deform_gpu.py::_check_volumes names them in the composed chains)."""
+    from lidar_transfer_amd.fusion import TSDFVolume
+    g = np.load(os.path.join(GOLD, "f8_tsdf_cpu_mode.npz"))
+    vol = TSDFVolume(g["bnds"], float(g["voxel"]), float(g["fov_up"]), float(g["fov_down"]), mode="numpy")
+    for _ in range(2):
+        vol.integrate(g["label3"], g["depth_im"], g["rem_im"], np.eye(4), obs_weight=1.)
+    tsdf, weight, color, rem = [t.cpu().numpy() for t in vol.get_volume_tensors()]
+    n = tsdf.size
+    diff = (tsdf.view(np.int32) != g["tsdf"].view(np.int32)) | (weight != g["weight"]) | (color != g["color"])
+    assert diff.sum() <= max(2, 1e-5 * n), f"{diff.sum()} of {n} voxels differ"
+    assert (g["weight"] > 0).sum() > 0.02 * n and float(np.abs(rem).max()) == 0.0
+    vol.close()
+
+
 def test_class_aware_branch_degenerates_to_the_pinned_average_for_a_single_class():
     """The strongest pin of `merge == true` available without running CUDA: when every pixel carries label 0 -- the
     label the fresh colour volume holds -- the class-aware kernel only ever takes its same-class branch
