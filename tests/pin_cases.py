@@ -115,3 +115,59 @@ def deform_cp_clouds(k):
     return out
 
 
+
+
+# ---- golden F15 (tests/golden/make_golden_mc_full.py): marching cubes + ray cast at the DEFAULT volume size -----------------
+MC_FULL_DIMS, MC_FULL_VOXEL, MC_FULL_ORIGIN = (2000, 2000, 200), 0.05, (-50.0, -50.0, -5.0)
+MC_FULL_SENSOR = (64, 2048, 3.0, -25.0)
+_MC_FULL_BOXES = [(9.0, 4.0, 2.5, 3.5, 2.25, 50.0), (-8.5, -6.0, 3.0, 2.0, 3.5, 50.0), (3.0, -11.0, 1.0, 2.25, 1.5, 10.0),
+                  (-4.0, 10.0, 4.5, 1.5, 2.0, 50.0), (12.0, -9.0, 0.25, 0.25, 4.0, 80.0), (-13.0, 2.0, 2.0, 5.0, 2.75, 50.0),
+                  (5.5, 13.0, 1.0, 2.25, 1.5, 10.0), (-2.0, -14.5, 6.0, 1.0, 3.0, 50.0)]
+
+
+def mc_full_fields(xp, device=None):
+    """(tsdf, color_vol, rem_vol) float32 [2000, 2000, 200] -- the reference's DEFAULT volume (config/lidar_transfer.yaml:6-9:
+    +-50 m x +-50 m x +-5 m at 5 cm, 800 M voxels) holding a truncated signed distance field of a street scene: a piecewise
+    linear ground, eight boxes / a pole, observed inside +-18 m of the sensor, +1 elsewhere and behind the truncation band
+    as `integrate` leaves it.  `xp` is numpy (tests/golden/make_golden_mc_full.py, on the host) or torch (the GPU test, on the
+    device): the field is built ONLY from +, -, *, abs, min, max, comparisons on float32 arrays (one rounding per operation in
+    either library, no contraction across operations; the 1-D coordinate tables come from numpy on the host either way), so
+    both produce the same 2.4 G floats bit for bit without 9.6 GB travelling in a fixture."""
+    nx, ny, nz = MC_FULL_DIMS
+    vs = MC_FULL_VOXEL
+    ax = [(np.float64(MC_FULL_ORIGIN[k]) + np.arange(n, dtype=np.float64) * vs).astype(np.float32)
+          for k, n in enumerate(MC_FULL_DIMS)]
+
+    def tri(u, period):                          # triangle wave in [0, 1], exact operations only
+        t = u.astype(np.float64) / period
+        return np.abs(2.0 * (t - np.floor(t + 0.5))).astype(np.float32)
+
+    if xp is np:
+        arr = lambda a: np.ascontiguousarray(a, dtype=np.float32)            # noqa: E731
+        full = lambda shape, v: np.full(shape, v, np.float32)                # noqa: E731
+    else:
+        arr = lambda a: xp.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)   # noqa: E731
+        full = lambda shape, v: xp.full(shape, v, dtype=xp.float32, device=device)            # noqa: E731
+    x, y, z = arr(ax[0]).reshape(nx, 1, 1), arr(ax[1]).reshape(1, ny, 1), arr(ax[2]).reshape(1, 1, nz)
+    gx, gy = arr(tri(ax[0], 21.0)).reshape(nx, 1, 1), arr(tri(ax[1], 31.0)).reshape(1, ny, 1)
+    h = (gx * np.float32(0.25)) * gy + np.float32(-1.73)     # ground height [nx, ny, 1]
+    sd = z - h                                                # > 0 above the ground  [nx, ny, nz]
+    lab = full((nx, ny, nz), 40.0)
+    for cx, cy, hx, hy, top, lb in _MC_FULL_BOXES:
+        dx = xp.abs(x - np.float32(cx)) - np.float32(hx)
+        dy = xp.abs(y - np.float32(cy)) - np.float32(hy)
+        d = xp.maximum(xp.maximum(dx, dy), z - np.float32(top))   # Chebyshev box distance
+        lab = xp.where(d < sd, np.float32(lb) if xp is np else full((), lb), lab)
+        sd = xp.minimum(sd, d)
+    tsdf = xp.minimum(xp.maximum(sd * np.float32(4.0), np.float32(-1.0) if xp is np else full((), -1.0)),
+                      np.float32(1.0) if xp is np else full((), 1.0))      # sd / (5 voxels) clipped to [-1, 1]
+    one = np.float32(1.0) if xp is np else full((), 1.0)
+    unseen = (sd < np.float32(-0.25)) | (xp.maximum(xp.abs(x), xp.abs(y)) > np.float32(18.0))
+    tsdf = xp.where(unseen, one, tsdf)
+    color = lab * np.float32(65536.0)
+    rem = (arr(tri(ax[0], 7.0)).reshape(nx, 1, 1) * np.float32(0.5) + arr(tri(ax[1], 5.0)).reshape(1, ny, 1) * np.float32(0.25)) \
+        + arr(tri(ax[2], 3.0)).reshape(1, 1, nz) * np.float32(0.125)
+    rem = rem + (sd * np.float32(0.0))           # (broadcast to the full shape)
+    if xp is np:
+        return np.ascontiguousarray(tsdf), np.ascontiguousarray(color), np.ascontiguousarray(rem)
+    return tsdf.contiguous(), color.contiguous(), rem.contiguous()
