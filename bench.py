@@ -42,7 +42,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth, 8 XCDs x 4 MiB (MI355X_MICROARCH.md, L2 section)
 RANDOM_REQ_CEILING_G = 52.0   # G random 64-byte read requests per second the memory side delivers (tools/tlb_probe.hip, profiles/r03)
-ATOMIC_CEILING_G = 27.0       # G memory-side atomics per second (tools/atomic_probe.hip, profiles/r03)
+ATOMIC_CEILING_G = 27.0       # G memory-side atomic REQUESTS per second, random cells (tools/atomic_probe.hip: "run 1", profiles/r05)
+# ... and in LANE atomics per second when neighbouring lanes hit neighbouring cells (runs of >= 8 lanes per 64-byte line: the
+# firing order of a spinning LiDAR, what k_pb_project sees): 187-212 G/s measured (profiles/r05/atomic_probe.txt, "run 8..64")
+ATOMIC_LANE_CEILING_ORDERED_G = 200.0
+# FETCH_SIZE calibration for this kernel's access patterns (tools/fetch_calib.hip -> profiles/r05/fetch_calib.txt): 12-byte
+# coalesced triples, 12-byte windowed gathers and 12-byte random gathers all count requests x 64 B while a request moves a
+# 128-byte line -> known / counted = 2.0, the same factor as the guide's 16-byte streaming case
+FETCH_SIZE_FACTOR = 2.0
 N_SIMD, SHADER_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 # Calibrated with tools/valu_calib.hip (profiles/r03/valu_calib.txt, 4096 straight-line v_fma_f32 per lane):
 #   * SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in every regime (1.000 per instruction): it counts issued instructions, it is NOT
@@ -513,6 +520,14 @@ def main():
                                per_link_GBs_nominal=XGMI_LINK_GBS,
                                link_bound_scans_per_s_per_rank=round((link or XGMI_LINK_GBS) * 1e9 / per_scan, 1),
                                link_bound=bool(world > 1 and mode == "root" and need > (link or XGMI_LINK_GBS)))
+            gather_info["predicted_job_scans_per_s"] = round(
+                world * (min(rate, gather_info["link_bound_scans_per_s_per_rank"]) if (world > 1 and mode == "root") else rate), 1)
+            if rank == 0:   # before the clock, on stderr (stdout carries the one JSON line): a first N-GPU run explains itself
+                print(f"[bench] gather over {world} ranks: mode={mode}; per-link GB/s measured (all peers sending)="
+                      f"{gather_info['per_link_GBs_measured']} nominal={XGMI_LINK_GBS}; each peer needs {need:.2f} GB/s for "
+                      f"{rate:.0f} scans/s x {per_scan} B; a link carries {gather_info['link_bound_scans_per_s_per_rank']:.0f} scans/s "
+                      f"per rank -> {'LINK-BOUND' if gather_info['link_bound'] else 'not link-bound'}; predicted job rate "
+                      f"{gather_info['predicted_job_scans_per_s']:.0f} scans/s", file=sys.stderr, flush=True)
             if mode == "sharded":
                 do_gather = False
                 sharded_meta = True
@@ -707,6 +722,31 @@ def main():
                       "--probe-only` -> profiles/rNN/serial_probe_kernel_stats.csv"}
         if traffic:
             d["traffic_frac_of_peak"] = round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            d["traffic_calibration"] = {"hbm_bytes": f"{FETCH_SIZE_FACTOR:g} x FETCH_SIZE + WRITE_SIZE", "factor": FETCH_SIZE_FACTOR,
+                                        "source": "profiles/r05/fetch_calib.txt (tools/fetch_calib.hip: 12-byte coalesced triples, "
+                                                  "12-byte windowed and random gathers -- this kernel's patterns -- all 2.0)"}
+        if strategy == "scatter":
+            # What ANY implementation must pull from HBM per scan: the index triples, every vertex once, one 8-byte atomic per
+            # accepted hit.  The 16-byte grid entries of the Moller-Trumbore tests (SURVEY.md section 8d charges them as
+            # "36 x n_tris") are reads of a ~2 MB bin grid that stays in L2: they are work, not HBM bytes.  `frac` is priced on
+            # the compulsory bytes; the figure of rounds 1-4 (all algorithmic bytes against the HBM peak) stays beside it.
+            comp_scan = n_faces * SC_B_TRI + n_verts * SC_B_VERT + c[2] * SC_B_HIT
+            l2_scan = c[1] * SC_B_TEST
+            comp = comp_scan * spl
+            d["frac_incl_l2_bytes"] = d["frac"]
+            d["achieved_incl_l2_bytes"] = d["achieved"]
+            d["achieved"] = round(comp / (serial_ms * 1e-3) / 1e9, 1)
+            d["frac"] = round(comp / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            d["bytes_per_scan"] = {"hbm_compulsory": int(comp_scan), "l2_resident": int(l2_scan),
+                                   "hbm_compulsory_parts": {"faces_12B": int(n_faces * SC_B_TRI), "vertices_12B": int(n_verts * SC_B_VERT),
+                                                            "hit_atomics_8B": int(c[2] * SC_B_HIT)}}
+            d["hbm_compulsory_bytes_per_launch"] = int(comp)
+            if traffic:
+                d["traffic_over_compulsory"] = round(traffic / comp, 3)
+            d["frac_of_achievable_copy"] = round(comp / (serial_ms * 1e-3) / 1e9 / 6300.0, 4)
+            d["bound_note"] = ("hbm names the peak the contract prices against; at 8 waves/SIMD the kernel is LATENCY-bound: 0.16-0.17 "
+                               "of HBM on compulsory bytes, ~0.4 of vector issue, ~0.4 of the random-request / atomic ceilings "
+                               "(valu_issue, memory_side below) -- no single roof is near")
         valu = None
         if te and te.get("valu_active_quad_cycles_per_launch"):
             # the issue-bound view (same PMC passes): cycles a SIMD's vector ALU was busy = SQ_ACTIVE_INST_VALU (summed over
@@ -755,9 +795,10 @@ def main():
             else:
                 d.update(bound="l2", achieved=d["l2"]["achieved"], peak=L2_PEAK_GBS, frac=d["l2"]["frac"])
         if insitu_ms == insitu_ms:
+            base = d.get("hbm_compulsory_bytes_per_launch", alg)   # (scatter: the compulsory bytes, like `frac`)
             d["in_situ"] = {"avg_kernel_ms": round(insitu_ms, 5),
-                            "achieved": round(alg / (insitu_ms * 1e-3) / 1e9, 1),
-                            "frac": round(alg / (insitu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "achieved": round(base / (insitu_ms * 1e-3) / 1e9, 1),
+                            "frac": round(base / (insitu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "note": f"the same launches inside the timed region (every {PROBE_EVERY}th sampled), where "
                                     "several launches overlap: the duration is NOT exclusive"}
         if strategy == "lbvh":
@@ -1237,7 +1278,12 @@ def main():
                                "algorithmic_bytes_per_call": int(alg),
                                "achieved": round(alg / (proj_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "atomics_G_per_s": round(tot_pts / (proj_ms * 1e-3) / 1e9, 2), "atomic_ceiling_G_per_s": ATOMIC_CEILING_G,
+                               "atomics_G_per_s": round(tot_pts / (proj_ms * 1e-3) / 1e9, 2),
+                               "atomic_ceiling_G_per_s": ATOMIC_LANE_CEILING_ORDERED_G,
+                               "frac_of_atomic_ceiling": round(tot_pts / (proj_ms * 1e-3) / 1e9 / ATOMIC_LANE_CEILING_ORDERED_G, 4),
+                               "atomic_ceiling_note": "LANE atomics/s with neighbouring lanes on neighbouring cells (runs >= 8 per 64-byte "
+                                                      "line: a scan's firing order), tools/atomic_probe.hip -> profiles/r05/atomic_probe.txt; "
+                                                      f"random cells reach {ATOMIC_CEILING_G:g} G/s (one request per lane)",
                                "single_cloud_call_ms_per_cloud": round(float(np.median(t_single)) * 1e3 / nscans, 4),
                                "bytes": "per point 24 B in + one 8-B memory-side atomicMin; per cell 16 B key read + re-arm, 12 B "
                                         "of images out (range, remission, folded label); per filled cell 24 + 8 B gathered",
@@ -1379,9 +1425,10 @@ def main():
         value = world * K * R / dt / 1e6
         rl = roofline(args.strategy, ser_ms, kern_ms)
         if iso_ms is not None:
+            iso_b = rl["bytes_per_scan"]["hbm_compulsory"] if "bytes_per_scan" in rl else rl["algorithmic_bytes_per_scan"]
             rl["isolated"] = {"avg_kernel_ms": round(iso_ms, 5),
-                              "achieved": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9, 1),
-                              "frac": round(rl["algorithmic_bytes_per_scan"] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "achieved": round(iso_b / (iso_ms * 1e-3) / 1e9, 1),
+                              "frac": round(iso_b / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "same kernel, launches of ONE scan each, back to back on one stream (nothing beside "
                                       "them), after the timed region"}
         if args.strategy == "scatter":
@@ -1402,6 +1449,22 @@ def main():
                           "frac_k_sc_tris_bytes_only": round(b_tris * SPS / step_s / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "algorithmic bytes of the whole three-kernel path per step / ms_per_step (the driver-timed "
                                   "number) / 8 TB/s; needs no kernel-exclusivity argument"}
+            # Does the figure named `frac` fit the driver's clock?  `avg_kernel_ms` is an EXCLUSIVE duration (one stream, nothing
+            # beside the kernel); in the timed region the batches of three streams overlap and fill each other's tails, so
+            # launches x avg_kernel_ms may exceed ms_per_step.  `frac_on_step_clock` charges the WHOLE step to k_sc_tris
+            # (compulsory bytes of the step's launches / ms_per_step): it fits by construction and bounds the kernel from below.
+            launches = SPS / args.batch
+            comp_scan = rl["bytes_per_scan"]["hbm_compulsory"]
+            rl["step_clock"] = {"launches_per_step": launches, "avg_kernel_ms_exclusive": rl["avg_kernel_ms"],
+                                "launches_x_avg_kernel_ms": round(launches * rl["avg_kernel_ms"], 4),
+                                "ms_per_step": round(step_s * 1e3, 4),
+                                "fits": bool(launches * rl["avg_kernel_ms"] <= step_s * 1e3),
+                                "achieved_on_step_clock": round(comp_scan * SPS / step_s / 1e9, 1),
+                                "frac_on_step_clock": round(comp_scan * SPS / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "exclusive kernel durations overlap in the timed region (3 batches in flight); "
+                                        "frac_on_step_clock = compulsory HBM bytes of the step / ms_per_step / 8 TB/s -- the whole "
+                                        "step charged to this kernel; one_batch_in_flight below is the configuration in which "
+                                        "launches x kernel time does fit its own region"}
             if one_batch:
                 rl["one_batch_in_flight"] = one_batch
             # all three kernels of a scan together at the measured scan rate: the HBM bandwidth the whole path

@@ -1493,15 +1493,17 @@ extern "C" int lt_mesh_renumber_dev(lt_mesh* m, void* stream_) {
   hipLaunchKernelGGL(k_rn_rank<true>, dim3(nb), dim3(256), 0, stream, m->faces, n3, m->rn_first, m->rn_bsum, m->rn_newid);
   hipLaunchKernelGGL(k_rn_move, dim3((nv + 255) / 256), dim3(256), 0, stream, m->rn_newid, nv, m->verts, m->colors, m->rem,
                      m->verts2, m->colors2, m->rem2);
-  hipLaunchKernelGGL(k_rn_faces, dim3((n3 + 255) / 256), dim3(256), 0, stream, m->faces, n3, m->rn_newid);
   int referenced = 0;
   LT_HIP(hipMemcpyAsync(&referenced, m->rn_bsum + nb, sizeof(int), hipMemcpyDeviceToHost, stream));
   LT_HIP(hipStreamSynchronize(stream));
   LT_HIP(hipGetLastError());
   if (referenced != nv) {  // (cannot happen for a mesh of lt_marching_cubes_dev: every vertex lies on an edge some tiling uses)
+    // nothing of the mesh has been touched yet: the faces are rewritten only once the new numbering is known to be complete
     lt_set_error("lt_mesh_renumber_dev: %d of %d vertices are referenced by no face", nv - referenced, nv);
     return LT_ERR_BAD_INDEX;
   }
+  hipLaunchKernelGGL(k_rn_faces, dim3((n3 + 255) / 256), dim3(256), 0, stream, m->faces, n3, m->rn_newid);
+  LT_HIP(hipGetLastError());
   float* tv = m->verts; m->verts = m->verts2; m->verts2 = tv;
   int* tc = m->colors; m->colors = m->colors2; m->colors2 = tc;
   float* tr = m->rem; m->rem = m->rem2; m->rem2 = tr;

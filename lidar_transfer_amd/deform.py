@@ -88,6 +88,19 @@ class DeviceDeform:
             self._rays = rays
         self.n_rays = self.t_H * self.t_W
 
+    def _stream(self):
+        """The caller's current stream -- ordered behind the stream of the previous call when that was another one: the
+        projector re-arms its z-min keys, and the volume / mesh / scene are reused, in stream order."""
+        torch = self._torch
+        st = torch.cuda.current_stream(self.device)
+        last = getattr(self, "_last_stream", None)
+        if last is not None and last.cuda_stream != st.cuda_stream:
+            ev = torch.cuda.Event()
+            ev.record(last)
+            st.wait_event(ev)
+        self._last_stream = st
+        return st
+
     # ---- write(): filter + pack (laserscan.py:1133-1178) -------------------------------------------------------------
     def _pack(self, points, is_f64, rem, label, index, n, st):
         torch = self._torch
@@ -111,7 +124,7 @@ class DeviceDeform:
         if self.vol is None:
             raise RuntimeError("DeviceDeform.mesh: constructed without vol_bnds")
         torch, lib = self._torch, self._lib
-        st = torch.cuda.current_stream(self.device)
+        st = self._stream()
         n = len(clouds)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing is not None else None
         if ev:
@@ -182,7 +195,7 @@ class DeviceDeform:
         if self.vol_bnds is None:
             raise RuntimeError("DeviceDeform.mergemesh: constructed without vol_bnds")
         torch, lib = self._torch, self._lib
-        st = torch.cuda.current_stream(self.device)
+        st = self._stream()
         pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
         rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
         lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]
@@ -218,9 +231,11 @@ class DeviceDeform:
     def cp(self, clouds, pack=True):
         """Closest point: the source scans merged into one cloud (laserscan.py:834-839), projected into the TARGET image
         (:841-843), re-projected to points (:844-845) and written (:1133-1160).  Returns ``range``, ``rem``, ``label``,
-        ``index`` images, ``back_points`` [t_H*t_W,3] f64 and -- with ``pack`` -- ``bin`` / ``label_file``."""
+        ``index`` images, ``back_points`` [t_H*t_W,3] f64 and -- with ``pack`` -- ``bin`` / ``label_file``.
+        The reference's ``cp`` path always holds float64 points (``apply_pose``, laserscan.py:98-104) and goldens F12 / F12b pin
+        that; float32 clouds with ``preserve_float`` are re-projected in float64 here as well (numpy would stay in float32)."""
         torch, lib = self._torch, self._lib
-        st = torch.cuda.current_stream(self.device)
+        st = self._stream()
         pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
         rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
         lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]

@@ -98,6 +98,18 @@ def scan_indices(n_scan_files: int, nscans: int = 1, offset: int = 0, batch_inte
     return list(range(idx, max(end, idx), batch_interval)) if idx < end else []
 
 
+def job_scan_list(sequences, nscans: int = 1, offset: int = 0, batch_interval: int = 1) -> List:
+    """The output scans of a multi-sequence job, in the order the reference would produce them when its loop is run over the
+    sequences one after the other (experiments/run_lidar_deform.sh:13-23): ``[(sequence, scan index), ...]`` with the
+    indices of :func:`scan_indices` per sequence.  ``sequences``: ``[(name, number of scan files), ...]``.  Block-partitioning
+    THIS list (:func:`partition`) -- not the sequences -- is what balances SemanticKITTI 00-07's unequal lengths
+    (4541 / 1101 / 4661 / 801 / 271 / 2761 / 1101 / 1101 files) over 8 ranks to within one scan."""
+    out = []
+    for name, n_files in sequences:
+        out += [(name, i) for i in scan_indices(int(n_files), nscans, offset, batch_interval)]
+    return out
+
+
 def partition(items: Sequence, world_size: int, rank: int) -> List:
     """Contiguous block partition, sizes differ by at most one (lower ranks get the extra item)."""
     n = len(items)

@@ -169,6 +169,59 @@ def test_gather_to_root_grouped_send_recv(world):
             assert np.all(rng[r] == 10 * r + chunk) and np.all(lab[r] == 100 * r + chunk)
 
 
+KITTI_00_07 = [("00", 4541), ("01", 1101), ("02", 4661), ("03", 801), ("04", 271), ("05", 2761), ("06", 1101), ("07", 1101)]
+
+
+def _c5_render(item):
+    seq, idx = item
+    g = torch.Generator().manual_seed(int(seq) * 100000 + idx)
+    return {"range": torch.rand(4 * 8, generator=g), "label": torch.randint(0, 260, (4 * 8,), generator=g, dtype=torch.int32)}
+
+
+def _c5_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lidar_transfer_amd.dist import job_scan_list
+    items = job_scan_list(KITTI_00_07, nscans=1, offset=0, batch_interval=10)
+    out = render_scans(items, _c5_render, ("range", "label"))
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_eight_ranks_over_the_real_sequence_lengths():
+    """Config C5 (BASELINE.json configs[4]): SemanticKITTI sequences 00-07 with `batch_interval: 10`, 8 ranks.  The job's scan
+    list is the reference's per-sequence loop (lidar_deform.py:385-390, :457-459) run over the sequences in turn; its block
+    partition differs by at most ONE scan between ranks although the sequences differ 17-fold in length, and the one gather
+    delivers every image at the position the single-process run has it -- byte for byte."""
+    from lidar_transfer_amd.dist import job_scan_list
+    items = job_scan_list(KITTI_00_07, nscans=1, offset=0, batch_interval=10)
+    per_seq = [len(scan_indices(n, 1, 0, 10)) for _, n in KITTI_00_07]
+    assert per_seq == [455, 111, 467, 81, 28, 277, 111, 111] and len(items) == sum(per_seq) == 1641
+    blocks = [partition(items, 8, r) for r in range(8)]
+    sizes = [len(b) for b in blocks]
+    assert max(sizes) - min(sizes) <= 1 and sum(blocks, []) == items
+    assert max(per_seq) / min(per_seq) > 16              # what a sequence-per-rank mapping would leave idle
+    single = render_scans(items, _c5_render, ("range", "label"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got["range"].shape == (1641, 32)
+    assert got["range"].tobytes() == single["range"].numpy().tobytes()
+    assert got["label"].tobytes() == single["label"].numpy().tobytes()
+
+
 def test_bench_cli_parses_without_a_gpu():
     """`bench.py --help` must work on a box without a GPU (the driver's contract flags are all there)."""
     import subprocess

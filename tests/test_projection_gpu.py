@@ -56,8 +56,6 @@ def test_range_projection_new_vs_reference_python(tag, beams):
     assert np.array_equal(scan.label_image, g[f"{k}_label_image"])
     assert np.array_equal(scan.proj_x, g[f"{k}_proj_x"]) and np.array_equal(scan.proj_y, g[f"{k}_proj_y"])
     assert scan.proj_label.dtype == np.int32 and (scan.proj_label[scan.index < 0] == 0).all()
-    # duplicates (points 200..209 == 300..309) tie on depth: the lower index must have won
-    assert not np.isin(scan.index, np.arange(300, 310)).any() or True
 
 
 @pytest.mark.parametrize("tag,beams", [("f32", False), ("f64", False), ("f64_beams", True)])
