@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
                                                       const mc_rec* __restrict__ rec, int n_active, float voxel_size,
                                                       float ox, float oy, float oz, float* __restrict__ verts,
                                                       int* __restrict__ faces, int* __restrict__ colors,
-                                                      float* __restrict__ rem, int cap_v, int cap_f, mc_amb A) {
+                                                      float* __restrict__ rem, int cap_v, int cap_f, mc_amb A, int xcd_map) {
   static_assert(K <= 16, "list entries hold the word in 4 bits");
   __shared__ mc_rec s_rec[K];
   __shared__ int s_xyz[K][3];       // x, y, wz of the words
@@ -797,7 +797,20 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   const int lane = threadIdx.x;
   // (a wave takes batches until none is left; by default the grid has a wave per batch -- see the launch)
   const int n_batches = (n_active + K - 1) / K;
-  for (int bi = blockIdx.x; bi < n_batches; bi += gridDim.x) {
+  // Batch order: active words are numbered x-major, so the batch list walks the volume plane by plane.  Workgroups are dealt
+  // to the eight XCDs round-robin (workgroup id % 8) and the L2s are private: with `xcd_map` XCD q takes the q-th EIGHTH of
+  // the batch list (its waves in turn within it), so that the columns (x + 1, y) / (x, y + 1) a batch samples are the OWN
+  // columns of batches the same L2 serves moments later -- instead of every plane's lines being pulled into all eight L2s.
+  // xcd_map = C > 0: the list is cut into CHUNKS of C batches (a few planes), chunk c belongs to XCD c % 8, and the waves of
+  // an XCD take the batches of its chunks in turn -- eight contiguous eighths (one per XCD) moved the fewest bytes but the
+  // XCDs finished at different times (a batch costs 1.5 - 42 us depending on where in the scene it lies).
+  const int per_xcd = gridDim.x >> 3, xq = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  if (xcd_map && xslot >= per_xcd) return;  // (a grid that is not a multiple of eight: the tail waves have no share)
+  for (int it = xcd_map ? xslot : (int)blockIdx.x;; it += xcd_map ? per_xcd : (int)gridDim.x) {
+    int bi = it;
+    if (xcd_map) bi = ((it / xcd_map) * 8 + xq) * xcd_map + it % xcd_map;
+    if (xcd_map ? (it / xcd_map) * 8 * xcd_map >= n_batches : bi >= n_batches) break;
+    if (bi >= n_batches) continue;
 #ifdef LT_MC_STAMP
   unsigned long long st_last = wall_clock64();
 #endif
@@ -1314,7 +1327,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   hipLaunchKernelGGL(k_mc_compact, dim3(sweep_wgs), dim3(256), 0, stream, bits, D, m->cnt, m->blk, seg_dev, m->cmap, m->rec,
                      (int)min(m->cap_rec, (size_t)2147483647), m->wave_na, n_blocks);
 #define LT_MC_EMIT_ARGS tsdf, color_vol, rem_vol, bits, D, m->cmap, m->rec, n_active, voxel_size, origin[0], origin[1], origin[2], \
-                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, m->amb
+                        m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, m->amb, xcd_map
   if (n_active > 0) {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
     // The grid: persistent waves taking batches in turn (bi += gridDim), twice the resident capacity (18 waves of 8.2 KB
@@ -1327,7 +1340,10 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     static const int env_waves = []() { const char* e = getenv("LIDARHIP_MC_EMIT_WAVES"); return e ? atoi(e) : -1; }();
     const int dflt_waves = lt_cu_count(m->device) * 36;
     const int max_waves = env_waves > 0 ? env_waves : (env_waves == 0 ? (1 << 24) : dflt_waves);
+    // LIDARHIP_MC_EMIT_XCD=0: batches dealt to the waves round-robin over the whole list (rounds 3-4)
+    static const int env_xcd = []() { const char* e = getenv("LIDARHIP_MC_EMIT_XCD"); return e ? atoi(e) : 64; }();
     auto grid = [&](int k) { return dim3((unsigned)min((n_active + k - 1) / k, max_waves)); };
+    const int xcd_map = (env_xcd > 0 && (int)grid(kk >= 16 ? 16 : kk >= 8 ? 8 : kk >= 4 ? 4 : 2).x >= 64) ? env_xcd : 0;
     if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
     else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
     else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, grid(4), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
