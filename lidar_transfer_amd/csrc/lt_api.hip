@@ -311,6 +311,10 @@ extern "C" int lt_scene_status(lt_scene* s) {
     lt_set_error("mesh has faces referencing vertices outside [0, n_verts); those faces were ignored");
     return LT_ERR_BAD_INDEX;
   }
+  if (f & LT_FLAG_HIER_OVERFLOW) {
+    lt_set_error("LBVH build: a hierarchy window overflowed (internal error); rebuild with LIDARHIP_HIER=seg");
+    return LT_ERR_HIP;
+  }
   return LT_OK;
 }
 

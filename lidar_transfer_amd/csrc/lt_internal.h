@@ -149,6 +149,7 @@ struct lt_tsdf {
 #define LT_BOUNDS_BLOCKS 256
 #define LT_DBG_WAVES 16384   // wave start/end clocks kept by a LT_TRACE_COUNT launch (debug)
 #define LT_FLAG_BAD_INDEX 1u
+#define LT_FLAG_HIER_OVERFLOW 2u  // lt_build.hip, k_agg_*: a window left more roots than LT_AGG_C (cannot happen for <= 62-bit strings)
 #define LT_TRACE_DEBUG_STEPS 0x4000u  // internal trace flag: `tri` receives the node steps of each ray (k_trace4)
 #define LT_TRACE_DEBUG_TIMES 0x8000u  // internal trace flag: per-wave wall-clock stamps into the counters area
 
