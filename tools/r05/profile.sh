@@ -1,4 +1,4 @@
-# Round-4 evidence, everything under gpurun_out/r05/ (summaries copied to profiles/r05/ afterwards):
+# Round-5 evidence, everything under gpurun_out/r05/ (summaries copied to profiles/r05/ afterwards):
 #   valu_calib*           what one wave64 VALU instruction costs / the unit of the SQ counters (tools/valu_calib.hip)
 #   serial_probe/         rocprofv3 --kernel-trace --stats of `bench.py --probe-only`: ONLY launches of the timed region's
 #                         shape, exclusive on one stream -> roofline.avg_kernel_ms reproducible from a CSV
