@@ -171,3 +171,52 @@ def mc_full_fields(xp, device=None):
     if xp is np:
         return np.ascontiguousarray(tsdf), np.ascontiguousarray(color), np.ascontiguousarray(rem)
     return tsdf.contiguous(), color.contiguous(), rem.contiguous()
+
+
+# ---- goldens F13b / F14b (tests/golden/make_golden_deform_mesh_fuzz.py): random configurations of the two mesh adaptions -----
+N_DEFORM_MESH_CASES = 16
+
+
+def deform_mesh_case(k):
+    """(adaption, source (H, W, fu, fd), target, n_scans, vol_bnds [3,2] as the YAML would give it, voxel, scene seeds)"""
+    rng = np.random.default_rng(7100 + k)
+    adaption = "mesh" if k % 2 == 0 else "mergemesh"
+    src = (int(rng.choice([16, 24, 32])), int(rng.choice([256, 360, 512])), float(rng.choice([3.0, 10.0, 15.0])),
+           -float(rng.choice([20.0, 25.0, 30.0])))
+    tgt = src if rng.random() < 0.3 else (int(rng.choice([8, 16, 32])), int(rng.choice([128, 256, 500])),
+                                          float(rng.choice([2.0, 10.0])), -float(rng.choice([16.6, 25.0, 30.0])))
+    n_scans = int(rng.integers(1, 4))
+    voxel = float(rng.choice([0.1, 0.2, 0.25]))
+    ext = int(rng.choice([6, 8, 10])) if voxel < 0.2 else int(rng.choice([8, 10, 12]))
+    bnds = np.array([[-ext, ext], [-ext + int(rng.integers(0, 3)), ext], [-int(rng.integers(2, 4)), int(rng.integers(1, 4))]])
+    if rng.random() < 0.4:
+        bnds = bnds.astype(np.float64)       # (a caller that passes floats: no truncation in fusion_lidar.py:36)
+    seeds = (int(rng.integers(100, 10000)), int(rng.integers(100, 10000)))
+    return adaption, src, tgt, n_scans, bnds, voxel, seeds
+
+
+def deform_mesh_clouds(seed, n_scans, src, render):
+    """Source scans of a seeded street scene as the source sensor sees it from the origin: the hit points of `render(verts,
+    faces, colors, rem, H, W, fu, fd) -> (endpoints [R,3] f32, label [R] i32, rem [R] f32, range [R] f32)` -- the reference's
+    raytracer in the generator, this library's (bit-identical, goldens F2-F5) in the GPU test -- and noisy, thinned copies."""
+    from lidar_transfer_amd.synth import synth_scene
+    H, W, fu, fd = src
+    v, f, c, r = synth_scene(seed % 64, 20000, bounds=(-12, 12, -12, 12, -3, 3), n_boxes=6, n_poles=6)
+    ends, lab, rem, rng_im = render(v, f, c, r, H, W, fu, fd)
+    hit = np.asarray(rng_im) > 0
+    pts0 = np.asarray(ends, np.float32).reshape(-1, 3)[hit].astype(np.float64)
+    lab0 = np.asarray(lab).reshape(-1)[hit].astype(np.uint32)
+    rem0 = np.asarray(rem, np.float32).reshape(-1)[hit]
+    rng = np.random.default_rng(seed)
+    scans = []
+    for k in range(n_scans):
+        keep = rng.random(len(pts0)) > (0.0 if k == 0 else 0.1)
+        p = pts0[keep] * (1.0 + (rng.normal(0, 0.002, (int(keep.sum()), 1)) if k else 0.0))
+        lb = lab0[keep].copy()
+        if k:
+            lb[rng.random(len(lb)) < 0.02] = 50
+        p = np.concatenate([p, np.zeros((1, 3))])
+        lb = np.concatenate([lb, [40]]).astype(np.uint32)
+        rm = np.concatenate([rem0[keep], [0.5]]).astype(np.float32)
+        scans.append((np.ascontiguousarray(p), rm, lb))
+    return scans
