@@ -9,7 +9,7 @@ rebuilds them.
     /opt/conda/bin/python3.9 tests/golden/make_golden_deform_mesh_fuzz.py
 
 `f13b_deform_mesh_fuzz.npz`: per output scan SHA-256 of the bytes of velodyne/N.bin and labels/N.label, of `proj_range` and
-`label_image`, the volume's dimensions, the bounds array afterwards, the numbers of written voxels / faces / points.  Only data."""
+`label_image`, the volume's dimensions, the bounds array afterwards, the numbers of written voxels / faces / points, and the two images.  Only data."""
 import hashlib
 import os
 import sys
@@ -63,6 +63,10 @@ def main():
             rec[f"{tag}_counts"] = np.array([out[f"{tag}_n_written"], out[f"{tag}_n_faces"], out[f"{tag}_bin"].size // 16,
                                              int((out[f"{tag}_proj_range"] > 0).sum())])
             rec[f"{tag}_cloud_sha"] = np.array(sha(np.concatenate([c[0].reshape(-1) for c in clouds])))
+            # the images themselves (a few KB each): where a boundary voxel (numpy's last-bit arctan2 / arcsin) reaches the mesh the
+            # consumer must be able to say HOW MANY pixels it moved
+            assert out[f"{tag}_label_image"].max() < 256
+            rec[f"{tag}_range"], rec[f"{tag}_limg"] = out[f"{tag}_proj_range"], out[f"{tag}_label_image"].astype(np.uint8)
     np.savez_compressed(os.path.join(HERE, "f13b_deform_mesh_fuzz.npz"), **rec)
     print("f13b_deform_mesh_fuzz.npz", os.path.getsize(os.path.join(HERE, "f13b_deform_mesh_fuzz.npz")), "bytes")
 

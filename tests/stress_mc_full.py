@@ -4,7 +4,7 @@
 triangle scene), extracted on the device and by the CPU oracle (oracle/lt_mc_oracle.c = scikit-image 0.18.3's arrays, goldens
 F10 / F10b) from the downloaded fields.  The same vertices, the same face stream, and after lt_mesh_renumber_dev the same
 arrays element for element.  One-off (the oracle walks 800 M cells single-threaded and needs ~25 GB of host memory): run by
-hand / by tools/r04_final.sh, not by pytest."""
+hand / by tools/r04/r04_final.sh, not by pytest."""
 import os
 import sys
 import time

@@ -414,9 +414,14 @@ def test_mesh_adaptions_on_random_configurations_equal_the_references_own_deform
             if have == want and got["n_faces"] == n_faces:
                 exact += 1
             else:
-                inexact.append((tag, got["n_faces"] - n_faces, int((got["range"] > 0).sum().item()) - n_hit))
+                rng_, lab_ = got["range"].cpu().numpy(), got["label"].cpu().numpy()
+                dpix = int((rng_.view(np.int32) != g[f"{tag}_range"].view(np.int32)).sum())
+                dlab = int((lab_ != g[f"{tag}_limg"].astype(np.int32)).sum())
+                dmax = float(np.abs(rng_ - g[f"{tag}_range"]).max())
+                inexact.append((tag, got["n_faces"] - n_faces, dpix, dlab, round(dmax, 4), rng_.size))
         dd.close()
-    print(f"\nF13b / F14b: {exact} output scans reproduced to the byte; others (tag, d faces, d hit pixels): {inexact}")
+    print(f"\nF13b / F14b: {exact} output scans reproduced to the byte; others (tag, d faces, differing range pixels, differing "
+          f"labels, max |d range| m, pixels): {inexact}")
     assert exact >= 22 and len(inexact) <= 2
-    for tag, dfaces, dhit in inexact:
-        assert abs(dfaces) <= 64 and abs(dhit) <= 8, (tag, dfaces, dhit)
+    for tag, dfaces, dpix, dlab, dmax, npix in inexact:   # a boundary voxel moved a handful of vertices: a few pixels, centimetres
+        assert abs(dfaces) <= 64 and dpix <= 0.01 * npix and dlab <= 2 and dmax < 0.2, (tag, dfaces, dpix, dlab, dmax)

@@ -1,5 +1,5 @@
 """Randomised comparisons with the two checkers that ARE the reference's code run here -- short versions of the stress runs of
-tools/r04_final.sh (tests/stress_mc.py 300 volumes, tests/stress_tsdf_ref.py 300 configurations; profiles/r04/gpu_suite.txt)."""
+tools/r04/r04_final.sh (tests/stress_mc.py 300 volumes, tests/stress_tsdf_ref.py 300 configurations; profiles/r04/gpu_suite.txt)."""
 import os
 import sys
 

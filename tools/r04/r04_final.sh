@@ -12,7 +12,7 @@ mkdir -p gpurun_out/r04
 timeout 900 python -m pytest tests/test_tsdf_ref_kernel_gpu.py -m gpu -q -s 2>&1 | grep -E "reference kernel|default volume|passed|failed" > gpurun_out/r04/tsdf_ref_kernel.txt
 # yardstick for the LBVH build's sort (ms_sort in the bench line): the ROCm library's device radix sort on the same job
 (/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/sort_probe tools/sort_probe.hip 2>/dev/null && /tmp/sort_probe && /tmp/sort_probe 2500000) > gpurun_out/r04/sort_probe.txt 2>&1
-bash tools/r04_profile.sh > gpurun_out/r04/profile.log 2>&1
+bash tools/r04/r04_profile.sh > gpurun_out/r04/profile.log 2>&1
 { LIDARHIP_DEBUG_TSDF=1 python tools/prof_chain.py 3 --ranges 2>&1 | grep -v amdgpu.ids | tail -6
   python tools/prof_chain.py 2 5 --ranges 2>&1 | grep -v amdgpu.ids | tail -2; } > gpurun_out/r04/pix_counts.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r04/chain5 -o s -- python $GRAFT_REPO_ROOT/tools/prof_chain.py 6 5 > /dev/null 2>&1)
@@ -27,5 +27,5 @@ done > gpurun_out/r04/bench_gather_modes.jsonl
 # the other BASELINE configurations through the same bench (parity-test cases; for the record)
 for w in C1 C3 C4; do python bench.py --workload $w --scenes 24 --no-cpu-baseline --no-e2e --no-chain 2>/dev/null | tail -1; done > gpurun_out/r04/bench_configs.jsonl
 # k_sc_tris variants on this box: SQ_BUSY_CYCLES + duration of the batch launch
-bash tools/r04_sc_variants.sh > gpurun_out/r04/sc_variants.log 2>&1
+bash tools/r04/r04_sc_variants.sh > gpurun_out/r04/sc_variants.log 2>&1
 cat gpurun_out/r04/gpu_suite.txt; tail -c 400 gpurun_out/r04/bench.json
