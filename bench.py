@@ -1289,6 +1289,49 @@ def main():
                                         "of images out (range, remission, folded label); per filled cell 24 + 8 B gathered",
                                "kernels": ["k_pb_project", "k_pb_resolve"]}}
 
+    def mergemesh_from_points(n=8):
+        """`deform('mergemesh')` + `write()` -- the adaption the reference's shipped config selects (config/lidar_transfer.yaml:3,
+        `number_of_scans: 1`; laserscan.py:921-1012, :1121-1178) -- from ONE 120 k-point source cloud at the reference's default
+        volume parameters (voxel_bounds +-50 / +-50 / +-5 m given as the YAML's ints, voxel 0.05 m): target-FOV projection onto
+        the source image, the kept points' bounds read back (48 bytes), `vol_bnds` clipped in place, a volume of that geometry,
+        one class-aware integrate, marching cubes, ray cast, pack.  Parity of the chain: goldens F14 / F14b (pytest -m gpu);
+        here: wall clock per output scan, and that a second DeviceDeform gives the same bytes."""
+        from lidar_transfer_amd.deform import DeviceDeform
+        if torch.cuda.get_device_properties(dev).total_memory < 60 * 2**30 or args.target:
+            return None
+        w = workers[0]
+        w.set_mesh(*scenes[0])
+        o = w.render(raysets[0], origin)
+        torch.cuda.synchronize()
+        hit = o["tri"] >= 0
+        cloud = [(o["endpoints"][hit].double().contiguous(), o["endrem"][hit].contiguous(),
+                  o["endcolors"][hit][:, 2].contiguous().to(torch.int32))]
+        sensor = (H, W, wl["fov_up"], wl["fov_down"])
+        res = []
+        for rep in range(2):
+            bnds = np.array([-50, 50, -50, 50, -5, 5]).reshape(3, 2)
+            dd = DeviceDeform(sensor, sensor, bnds, 0.05, device=local_rank, mesh_volume=False)
+            for _ in range(3):
+                got = dd.mergemesh(cloud)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                got = dd.mergemesh(cloud)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            res.append((float(np.median(ts)), got["bin"].clone(), got["label_file"].clone(), got["range"].clone(), got["vol_dim"],
+                        bnds.tolist(), got["n_faces"]))
+            dd.close()
+        same = bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and
+                    torch.equal(res[0][3].view(torch.int32), res[1][3].view(torch.int32)))
+        return {"what": "DeviceDeform.mergemesh: one 120 k-point cloud -> projection (target FOV) -> bounds read-back -> volume of the "
+                        "clipped geometry -> integrate -> marching cubes -> ray cast -> packed .bin / .label bytes",
+                "ms_per_output_scan": round(min(r_[0] for r_ in res) * 1e3, 4), "points_in": int(cloud[0][0].shape[0]),
+                "vol_dim": list(res[0][4]), "vol_bnds_after": res[0][5], "mesh_faces": int(res[0][6]),
+                "points_written": int(res[0][1].shape[0]), "hit_fraction": round(float((res[0][3] > 0).float().mean().item()), 4),
+                "verified": same, "parity": "goldens F14 / F14b (tests/test_deform_gpu.py): the reference's own deform('mergemesh') + write()"}
+
     def e2e_pipelined(n_scans=200, depth=4):
         """The same host-buffer work for a SEQUENCE of scans (the reference's loop over output scans): lt_hostpipe keeps
         `depth` scans in flight -- uploads of scans i+1, i+2 (two uploader threads) | render of scan i | download of scan
@@ -1425,6 +1468,7 @@ def main():
     chain5 = guarded("fusion_chain_nscans5", fusion_chain, 4, 5) if (chain and rank == 0 and world == 1) else None
 
     from_points = guarded("deform_from_points", deform_from_points) if (chain and rank == 0 and world == 1) else None
+    mergemesh_leg = guarded("mergemesh_from_points", mergemesh_from_points) if (chain and rank == 0 and world == 1) else None
     if chain:
         chain["pipelined"] = (pipelined or [None, None])[0]
     if chain5:
@@ -1527,6 +1571,8 @@ def main():
             out["fusion_chain"] = chain
         if chain5:
             out["fusion_chain_nscans5"] = chain5
+        if mergemesh_leg:
+            out["mergemesh_from_points"] = mergemesh_leg
         if from_points:
             out["deform_from_points"] = from_points
             out["projection"] = from_points["projection"]
