@@ -425,3 +425,42 @@ def test_mesh_adaptions_on_random_configurations_equal_the_references_own_deform
     assert exact >= 22 and len(inexact) <= 2
     for tag, dfaces, dpix, dlab, dmax, npix in inexact:   # a boundary voxel moved a handful of vertices: a few pixels, centimetres
         assert abs(dfaces) <= 64 and dpix <= 0.01 * npix and dlab <= 2 and dmax < 0.2, (tag, dfaces, dpix, dlab, dmax)
+
+
+def test_mergemesh_error_paths_and_geometry_cache():
+    """What the reference does with degenerate input it does by crashing in numpy (`amin` of an empty array, a negative volume
+    dimension); here: the same conditions raise before any volume is made.  And the per-geometry volumes: the bounds only
+    ever shrink, a handful of geometries per sequence -- at most three are kept."""
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    g = _gold("f14_deform_mergemesh.npz")
+    src = (32, 512, 3.0, -25.0)
+    clouds = _gold_clouds(g, "a0", 1)
+    dd = DeviceDeform(src, src, None, 0.1)
+    with pytest.raises(RuntimeError):
+        dd.mergemesh(clouds)                      # constructed without vol_bnds
+    dd.close()
+    bnds = np.array([[-7, 7], [-7, 7], [-2, 3]])
+    dd = DeviceDeform(src, src, bnds, 0.1, mesh_volume=False)
+    with pytest.raises(RuntimeError):
+        dd.mesh(clouds)                           # the fixed volume of the `mesh` adaption was not asked for
+    far = [(clouds[0][0] * 0.0, clouds[0][1], clouds[0][2])]          # every point at depth 0: nothing survives the projection
+    with pytest.raises(ValueError):
+        dd.mergemesh(far)
+    assert np.array_equal(bnds, [[-7, 7], [-7, 7], [-2, 3]])          # (untouched by the failed call)
+    above = [(clouds[0][0] + torch.tensor([0.0, 0.0, 40.0], dtype=torch.float64, device="cuda"), clouds[0][1], clouds[0][2])]
+    b2 = np.array([[-7, 7], [-7, 7], [-2, 3]])
+    d2 = DeviceDeform(src, (32, 512, 89.0, -25.0), b2, 0.1, mesh_volume=False)
+    with pytest.raises(RuntimeError):
+        d2.mergemesh(above)                       # the points' bounds lie outside the allowed volume: an empty clipped volume
+    d2.close()
+    # geometries: shrink the cloud step by step -> new bounds -> new volumes; never more than three alive
+    pts, rem, lab = clouds[0]
+    for k, lim in enumerate((6.4, 5.4, 4.4, 3.4, 2.6)):
+        keep = (pts[:, 0] < lim) & (pts.norm(dim=1) > 0)
+        got = dd.mergemesh([(pts[keep].contiguous(), rem[keep].contiguous(), lab[keep].contiguous())])
+        torch.cuda.synchronize()
+        assert len(dd._mm_vols) <= 3 and got["vol_dim"][0] == int(round((bnds[0, 1] - bnds[0, 0]) / 0.1))
+        assert (got["range"] > 0).sum().item() > 50
+    assert bnds[0, 1] <= 3 and len(dd._mm_vols) == 3
+    dd.close()

@@ -225,6 +225,24 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.Stats) == 80  # lt_stats layout (entries_culled added in round 3)
 
 
+def test_header_compiles_as_plain_c_and_its_structs_match_the_ctypes_mirrors(tmp_path):
+    """include/lidarhip.h is the boundary: a C compiler must take it as it is (no C++ / HIP types), and the structs the Python
+    side fills (lt_stats, lt_cloud, lt_proj_images incl. round 5's `bnds`) must have the sizes of their ctypes mirrors."""
+    import ctypes
+    import subprocess
+    from lidar_transfer_amd import _lib
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lidarhip.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %u %u\\n", sizeof(lt_stats), sizeof(lt_cloud), sizeof(lt_proj_images),\n'
+                   '         offsetof(lt_proj_images, bnds), (unsigned)LT_TSDF_MERGE, (unsigned)LT_TSDF_HOST_MODE);\n  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_lib.Stats) and got[1] == ctypes.sizeof(_lib.Cloud)
+    assert got[2] == ctypes.sizeof(_lib.ProjImages) and got[3] == _lib.ProjImages.bnds.offset
+    assert got[4] == _lib.LT_TSDF_MERGE and got[5] == _lib.LT_TSDF_HOST_MODE
+
+
 def test_c_trace_argument_checks_raise_before_any_device_work():
     from lidar_transfer_amd.raytracer import C_Trace
     f32, i32 = np.float32, np.int32
