@@ -168,6 +168,8 @@ class DeviceDeform:
         from .fusion import TSDFVolume
         vb = self.vol_bnds
         mb = np.rint(merged_bnds).astype(int)                           # :957
+        # (no short cut for "nothing clipped": with float bounds fusion_lidar.py:34-36 re-derives the upper bounds from
+        # ceil((max - min) / voxel) every scan, and that can GROW the volume by a voxel per call -- the statements are run as they are)
         vb[:, 0] = np.maximum(vb[:, 0], mb[:, 0])                       # :961
         vb[:, 1] = np.minimum(vb[:, 1], mb[:, 1])                       # :962
         as_given = np.array(vb, dtype=np.float64)
@@ -203,15 +205,16 @@ class DeviceDeform:
         src = self.projector.project([(pts, rem, lab)], self.t_fov_up, self.t_fov_down, self.H, self.W, new=True, remove=True,
                                      beam_angles=self.beam_angles, outputs=("range", "rem", "label_folded", "bnds"),
                                      stream=st)[0]
-        bnds = src["bnds"].cpu().numpy()      # (synchronises the stream)
-        if not (bnds[:, 0] <= bnds[:, 1]).all():
-            raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
-        vol = self._mergemesh_volume(bnds)
+        # (everything the host can prepare goes before the read-back: the GPU idles from the read-back to the next launch)
         vp = C.c_void_p
         cp, dp, rp = (vp * 1)(src["label_folded"].data_ptr()), (vp * 1)(src["range"].data_ptr()), (vp * 1)(src["rem"].data_ptr())
         out = self.scene.alloc_outputs(self.n_rays, label_image=True)
         org = (C.c_float * 3)(*[float(x) for x in origin])
         flags = _lib.LT_TRACE_WRITE_MISSES | _lib.LT_TRACE_LABEL_IMAGE
+        bnds = src["bnds"].cpu().numpy()      # (synchronises the stream)
+        if not (bnds[:, 0] <= bnds[:, 1]).all():
+            raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
+        vol = self._mergemesh_volume(bnds)
         with torch.cuda.device(self.device):
             _lib.check(lib.lt_fusion_scan_dev(vol._h, self.mesh_obj._h, self.scene._h, self.rayset._h, 1, cp, dp, rp,
                                               self.H, self.W, 1.0, vol._flags, org, out["endpoints"].data_ptr(),
