@@ -152,9 +152,6 @@ extern "C" int lt_scene_destroy(lt_scene* s) {
   if (s->sc_cell) (void)hipFree(s->sc_cell);
   if (s->sc_large) (void)hipFree(s->sc_large);
   if (s->sc_slices) (void)hipFree(s->sc_slices);
-#ifdef LT_SC_WIN
-  if (s->sc_win) (void)hipFree(s->sc_win);
-#endif
   if (s->sc_large_count) (void)hipFree(s->sc_large_count);
   for (int k = 0; k < s->have_events; ++k) (void)hipEventDestroy(s->ev[k]);
   free(s);

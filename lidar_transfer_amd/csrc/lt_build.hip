@@ -812,365 +812,6 @@ __global__ __launch_bounds__(256) void k_hierarchy4_big(const uint32_t* __restri
   }
 }
 
-// ---- bottom-up hierarchy in LDS windows (round 5; LIDARHIP_HIER=agg -- measured, NOT the default) --------------------------
-// Verdict of the measurement (profiles/r05/lbvh_hier_ab.txt): node for node the same array as the kernels above on five
-// meshes from 300 to 1 M triangles, and 2.3 x SLOWER -- k_agg_leaves 51 us, two upper levels 49 us each, the top 54 us against
-// k_seg_sub + k_seg_top + k_hierarchy4 + k_hierarchy4_big = 87 us.  The climb is a serial chain: a wave runs until its
-// deepest lane has reached the window's top (~22 merges in a radix tree over 512 Morton-sorted leaves), each merge an LDS
-// exchange + the sibling's half + a 128-byte node store, with ever fewer lanes alive; the top-down kernels search every
-// node's range and fetch its boxes in parallel, and their long chains (the big nodes) get a wave each.  Kept as the A/B partner.
-// The SAME tree and the SAME 4-wide nodes as k_hierarchy4 / k_hierarchy4_big above -- Karras' binary radix tree over the
-// sorted (key, index) strings, numbered as there, every entry's box the union of its leaves' padded boxes (min / max: exact
-// whatever the order of the reduction) -- built the other way round: instead of every node finding its key range and then
-// FETCHING the boxes of its (up to four) grandchild ranges from a segment tree in HBM (k_seg_sub / k_seg_top: 21 us to
-// build; 8 levels x ~1.5 us of cold memory-side latency per walk; a second kernel for the nodes whose ranges leave the key
-// window), neighbouring subtrees are MERGED upwards and the boxes travel with them (Apetrei's agglomerative construction):
-//   * a node over the leaves [l, r] is the left child of the node that splits at r when delta(r, r + 1) > delta(l - 1, l),
-//     else the right child of the node that splits at l - 1 (the two deltas are never equal: the strings are distinct);
-//   * whoever arrives second at a split (one LDS atomicExch per arrival) forms the parent: its children's boxes are what
-//     the two arrivers carry, its grandchildren's boxes are what its children were formed from -- the 4-wide node is
-//     written on the spot; the first arriver leaves its record in LDS and ends.
-// A workgroup owns a WINDOW of LT_AGG_W consecutive items (level 1: sorted leaves; level 2: the roots level 1 left over, in
-// leaf order; ...) and merges what lies inside; a subtree whose parent needs the other side of a window boundary is a ROOT
-// of the window and goes to the next level as one item (its range, its split, its two child boxes: 64 B).  All
-// synchronisation is LDS atomics and workgroup barriers: no agent-scope fences, deterministic, no inter-workgroup
-// communication inside a launch.  Three launches for a 1 M-triangle mesh: 1 954 windows -> ~35 k roots -> 69 windows ->
-// ~1 k roots -> one workgroup that repeats the step until a single root -- the tree's -- is left.
-#ifndef LT_AGG_W
-#define LT_AGG_W 512
-#endif
-#define LT_AGG_C 128   // roots a window may hand on (the two flanks of its subtree forest: <= 2 x 62 levels)
-struct agg_item { int l, r, g, pad; float b[12]; };  // leaves [l, r]; g = last leaf of the left child, (b[0..5], b[6..11]) the
-                                                     // children's boxes; a single leaf: g = -1, b[0..5] = its box
-static_assert(sizeof(agg_item) == 64, "agg_item is 64 bytes");
-
-__device__ __forceinline__ int agg_delta(const uint32_t* __restrict__ keys, int n, int i) {  // delta(i, i + 1); -1 off the ends
-  if (i < 0 || i + 1 >= n) return -1;
-  const uint32_t a = keys[i], b = keys[i + 1];
-  return a != b ? __clz((int)(a ^ b)) : 32 + __clz(i ^ (i + 1));
-}
-__device__ __forceinline__ void agg_put(float4* __restrict__ O, int k, const float* b, int ref) {
-  O[2 * k] = make_float4(b[0], b[1], b[2], b[3]);
-  O[2 * k + 1] = make_float4(b[4], b[5], __int_as_float(ref), 0.f);
-}
-
-// LDS-only ordering: DS instructions of a wave execute in issue order, so all that is needed between "write my slot" and
-// "announce my arrival" is that the compiler keeps the order and the writes have left the wave (a workgroup-scope fence
-// would also wait for the 128-byte node stores of the previous merge: one memory round trip per level of the climb)
-#define LT_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// One pass over a window of `wn` items.  MODE 0: the items are the sorted leaves [w0, w0 + wn) (boxes in `leafbox`, 2 float4
-// each); MODE 1: items[s_src[t]] (roots written by an EARLIER launch); MODE 2: items[w0 + t], written by THIS workgroup in
-// an earlier pass (loads must not be served from a stale L1 line: volatile).  Returns (the same value in every thread)
-// the number of roots; the first LT_AGG_C of them are written to `out` in leaf order.  NT: threads of the workgroup.
-//
-// LDS protocol.  The slot of the node that splits at local position sp is (s_half[sp][0], s_half[sp][1]): whoever arrives from
-// the LEFT writes its own box and five words about itself into half 0, from the RIGHT into half 1 -- no race, and once both are
-// in, the two halves ARE the node's record: its children's boxes, its range [half0.l, half1.r], its split half0.r.  An
-// arriver carries its own box and its own children's boxes in registers; of its sibling it reads the half and -- when an
-// entry of the 4-wide node needs them -- the sibling's children's boxes (the sibling's own slot; an item's 64-byte record).
-// s_flag[sp]: 0 nobody yet, 1 / 2 the left / right child waits, 3 formed.
-struct agg_half { float b[6]; int l, r, ab, self, g; };  // ab = a | b << 16 (items); self: slot >= 0, or -1 - t for item t; g: split leaf or -1
-// (48-byte halves moved with three 16-byte LDS accesses: k_agg_leaves 51 -> 63 us -- two workgroups per CU instead of three)
-template <int MODE, bool OUT_VOL, int NT>
-__device__ __forceinline__ int agg_window(const uint32_t* __restrict__ keys, int n, const float4* __restrict__ leafbox,
-                                          const agg_item* items, const int* s_src, int w0, int wn, agg_item* out,
-                                          float4* __restrict__ nodes4, int* s_dl, int* s_flag, int* s_owner,
-                                          agg_half (*s_half)[2], int* s_misc) {
-  const int tid = threadIdx.x;
-  auto item_at = [&](int t) -> const agg_item* { return MODE == 1 ? &items[s_src[t]] : &items[w0 + t]; };
-  auto item_meta = [&](int t) -> int4 {
-    if (MODE == 0) return make_int4(w0 + t, w0 + t, -1, 0);
-    if (MODE == 2) { const volatile int* q = (const volatile int*)item_at(t); return make_int4(q[0], q[1], q[2], 0); }
-    return *(const int4*)item_at(t);
-  };
-  auto item_boxes = [&](int t, float* B) {  // the 12 floats of item t (MODE 0: 6)
-    if (MODE == 0) {
-      const float4 lo = leafbox[2 * (size_t)(w0 + t)], hi = leafbox[2 * (size_t)(w0 + t) + 1];
-      B[0] = lo.x; B[1] = lo.y; B[2] = lo.z; B[3] = hi.x; B[4] = hi.y; B[5] = hi.z;
-#pragma unroll
-      for (int k = 6; k < 12; ++k) B[k] = 0.f;
-    } else if (MODE == 2) {
-      const volatile float* q = (const volatile float*)item_at(t)->b;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) B[k] = q[k];
-    } else {
-      const float4* q = (const float4*)item_at(t)->b;
-      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-      B[0] = q0.x; B[1] = q0.y; B[2] = q0.z; B[3] = q0.w; B[4] = q1.x; B[5] = q1.y; B[6] = q1.z; B[7] = q1.w;
-      B[8] = q2.x; B[9] = q2.y; B[10] = q2.z; B[11] = q2.w;
-    }
-  };
-  for (int t = tid; t < wn; t += NT) {
-    const int4 m = item_meta(t);
-    s_dl[t + 1] = agg_delta(keys, n, m.y);     // between item t and item t + 1 (the last one: towards the next window)
-    if (t == 0) s_dl[0] = agg_delta(keys, n, m.x - 1);
-    s_flag[t] = 0;
-    s_owner[t] = 0;
-  }
-  __syncthreads();
-  for (int t0 = tid; t0 < wn; t0 += NT) {
-    // the node this thread carries: leaves [l, r], items [a, b], own split g (leaf index; -1: a single leaf), where its record
-    // lives (`self`: slot >= 0, or -1 - t for item t), its children's boxes C (valid when g >= 0), its own box T
-    const int4 m0 = item_meta(t0);
-    int l = m0.x, r = m0.y, g = m0.z, a = t0, b = t0, self = -1 - t0;
-    float C[12], T[6];
-    item_boxes(t0, C);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      T[k] = g >= 0 ? fminf(C[k], C[6 + k]) : C[k];
-      T[3 + k] = g >= 0 ? fmaxf(C[3 + k], C[9 + k]) : C[3 + k];
-    }
-    for (;;) {
-      const int dL = s_dl[a], dR = s_dl[b + 1];
-      const bool right = dR > dL;  // merges with its right neighbour: it is the LEFT child of the node that splits at b
-      if (right ? (b == wn - 1) : (a == 0)) {  // the parent lies across the window's edge (or this is the tree's root)
-        s_owner[a] = self >= 0 ? self + 1 : self;
-        break;
-      }
-      const int sp = right ? b : a - 1;
-      agg_half* mine = &s_half[sp][right ? 0 : 1];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) mine->b[k] = T[k];
-      mine->l = l; mine->r = r; mine->ab = a | (b << 16); mine->self = self; mine->g = g;
-      LT_LDS_FENCE();  // the half before the arrival is seen
-      const int old = atomicExch(&s_flag[sp], right ? 1 : 2);
-      if (old == 0) break;    // first at the split: the sibling will find the half
-      LT_LDS_FENCE();
-      const agg_half* sib = &s_half[sp][right ? 1 : 0];
-      float S[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) S[k] = sib->b[k];
-      const int s_l = sib->l, s_r = sib->r, s_ab = sib->ab, s_self = sib->self, s_g = sib->g;
-      s_flag[sp] = 3;
-      const int gP = right ? r : s_r;  // last leaf of the left child
-      const int lP = right ? l : s_l, rP = right ? s_r : r;
-      const int aP = right ? a : (s_ab & 0xFFFF), bP = right ? (s_ab >> 16) : b;
-      const int cntL = gP - lP + 1, cntR = rP - gP;
-      const int gL = right ? g : s_g, gR = right ? s_g : g;
-      if (rP - lP + 1 > LT_LEAF_MAX || (lP == 0 && rP == n - 1)) {
-        float SC[12];  // the sibling's children's boxes, when an entry needs them
-        if ((right ? cntR : cntL) > LT_LEAF_MAX) {
-          if (s_self >= 0) {
-            const agg_half* h = s_half[s_self];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { SC[k] = h[0].b[k]; SC[6 + k] = h[1].b[k]; }
-          } else {
-            item_boxes(-1 - s_self, SC);
-          }
-        }
-        const float* TLp = right ? T : S;
-        const float* TRp = right ? S : T;
-        const float* CL = right ? C : SC;
-        const float* CR = right ? SC : C;
-        // Karras' number of the parent: its last leaf when it is a left child (merges to the right), else its first
-        const int idx = s_dl[bP + 1] > s_dl[aP] ? rP : lP;
-        float4* O = nodes4 + 8 * (size_t)idx;
-        int ne = 0;
-        if (cntL <= LT_LEAF_MAX) agg_put(O, ne++, TLp, leaf_ref(lP, cntL));
-        else {
-          const int c0 = gL - lP + 1, c1 = gP - gL;
-          agg_put(O, ne++, CL, c0 <= LT_LEAF_MAX ? leaf_ref(lP, c0) : gL);
-          agg_put(O, ne++, CL + 6, c1 <= LT_LEAF_MAX ? leaf_ref(gL + 1, c1) : gL + 1);
-        }
-        if (cntR <= LT_LEAF_MAX) agg_put(O, ne++, TRp, leaf_ref(gP + 1, cntR));
-        else {
-          const int c0 = gR - gP, c1 = rP - gR;
-          agg_put(O, ne++, CR, c0 <= LT_LEAF_MAX ? leaf_ref(gP + 1, c0) : gR);
-          agg_put(O, ne++, CR + 6, c1 <= LT_LEAF_MAX ? leaf_ref(gR + 1, c1) : gR + 1);
-        }
-        const float inf = INFINITY;
-        const float E[6] = {inf, inf, inf, inf, inf, inf};  // mn = mx = +inf: no ray enters
-        for (; ne < 4; ++ne) agg_put(O, ne, E, 0x7fffffff);
-      }
-      // the parent becomes the carried node
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const float tk = T[k], sk = S[k];
-        C[k] = right ? tk : sk;
-        C[6 + k] = right ? sk : tk;
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { T[k] = fminf(T[k], S[k]); T[3 + k] = fmaxf(T[3 + k], S[3 + k]); }
-      l = lP; r = rP; g = gP; a = aP; b = bP; self = sp;
-    }
-  }
-  __syncthreads();
-  // roots: the nodes that stopped at an edge (s_owner) and the first arrivers nobody joined (s_flag 1 / 2)
-  for (int t = tid; t < wn; t += NT) {
-    const int f = s_flag[t];
-    if (f == 1 || f == 2) {
-      const agg_half* h = &s_half[t][f - 1];
-      s_owner[h->ab & 0xFFFF] = h->self >= 0 ? h->self + 1 : h->self;
-    }
-  }
-  __syncthreads();
-  // rank of a root = roots that start before it: NT lanes x (W / NT) positions, wave prefix + LDS partials
-  int* s_part = s_misc;  // [NT / 64]
-  constexpr int PER = LT_AGG_W / NT;
-  int mine_[PER], cnt = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int t = tid * PER + k;
-    mine_[k] = (t < wn && s_owner[t] != 0) ? 1 : 0;
-    cnt += mine_[k];
-  }
-  int inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int q = __shfl_up(inc, o, 64);
-    if ((tid & 63) >= o) inc += q;
-  }
-  if ((tid & 63) == 63) s_part[tid >> 6] = inc;
-  __syncthreads();
-  int base = inc - cnt, total = 0;
-#pragma unroll
-  for (int w = 0; w < NT / 64; ++w) {
-    if (w < (tid >> 6)) base += s_part[w];
-    total += s_part[w];
-  }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int t = tid * PER + k;
-    if (mine_[k]) {
-      if (base < LT_AGG_C) {
-        const int code = s_owner[t];
-        int4 m;
-        float B[12];
-        if (code > 0) {  // a node formed here: its two halves
-          const agg_half* h = s_half[code - 1];
-          m = make_int4(h[0].l, h[1].r, h[0].r, 0);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) { B[q] = h[0].b[q]; B[6 + q] = h[1].b[q]; }
-        } else {         // an item that found no partner inside the window: handed on as it came
-          m = item_meta(-1 - code);
-          item_boxes(-1 - code, B);
-        }
-        if (OUT_VOL) {
-          volatile int* o = (volatile int*)&out[base];
-          o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = 0;
-#pragma unroll
-          for (int q = 0; q < 12; ++q) ((volatile float*)o)[4 + q] = B[q];
-        } else {
-          float4* o = (float4*)&out[base];
-          o[0] = make_float4(__int_as_float(m.x), __int_as_float(m.y), __int_as_float(m.z), 0.f);
-          o[1] = make_float4(B[0], B[1], B[2], B[3]);
-          o[2] = make_float4(B[4], B[5], B[6], B[7]);
-          o[3] = make_float4(B[8], B[9], B[10], B[11]);
-        }
-      }
-      ++base;
-    }
-  }
-  __syncthreads();  // (the LDS arrays are reused by the caller's next window)
-  return total;
-}
-
-#define LT_AGG_LDS                                                                                            \
-  __shared__ int s_dl[LT_AGG_W + 1], s_flag[LT_AGG_W], s_owner[LT_AGG_W], s_misc[16], s_src[LT_AGG_W];         \
-  __shared__ agg_half s_half[LT_AGG_W][2]
-
-// level 1: windows of LT_AGG_W sorted leaves, a thread per leaf
-__global__ __launch_bounds__(LT_AGG_W) void k_agg_leaves(const uint32_t* __restrict__ keys, int n, const float4* __restrict__ leafbox,
-                                                         agg_item* __restrict__ out_items, int* __restrict__ out_counts,
-                                                         float4* __restrict__ nodes4, unsigned* __restrict__ flags) {
-  LT_AGG_LDS;
-  const int w = blockIdx.x, w0 = w * LT_AGG_W, wn = min(LT_AGG_W, n - w0);
-  const int total = agg_window<0, false, LT_AGG_W>(keys, n, leafbox, nullptr, s_src, w0, wn, out_items + (size_t)w * LT_AGG_C, nodes4,
-                                                   s_dl, s_flag, s_owner, s_half, s_misc);
-  if (threadIdx.x == 0) {
-    out_counts[w] = min(total, LT_AGG_C);
-    if (total > LT_AGG_C) atomicOr(flags, LT_FLAG_HIER_OVERFLOW);  // (cannot happen: see LT_AGG_C)
-  }
-}
-
-// The upper levels.  Workgroup w takes the root lists of `group` consecutive windows of the level below (in_counts[c] roots
-// at in_items[c * LT_AGG_C ...]; group <= 64), as ONE list in leaf order, and reduces it: passes over windows of LT_AGG_W items,
-// each pass leaving the roots of its windows as the next list, until the list fits one window's output (<= LT_AGG_C roots:
-// normally after the first pass -- 8 windows bring ~150 items) -- or, FINAL (one workgroup over all windows), until a single
-// item is left: the root of the tree, whose node was written when it was formed.  scratch: two lists per workgroup for the
-// passes in between.
-template <bool FINAL>
-__global__ __launch_bounds__(LT_AGG_W) void k_agg_upper(const uint32_t* __restrict__ keys, int n,
-                                                        const agg_item* __restrict__ in_items, const int* __restrict__ in_counts,
-                                                        int n_in_windows, int group, agg_item* scratch,
-                                                        agg_item* __restrict__ out_items, int* __restrict__ out_counts,
-                                                        float4* __restrict__ nodes4, unsigned* __restrict__ flags) {
-  LT_AGG_LDS;
-  __shared__ int s_cpre[65];
-  constexpr int NT = LT_AGG_W;
-  const int tid = threadIdx.x;
-  const int c_lo = blockIdx.x * group, c_hi = min(n_in_windows, c_lo + group);
-  if (tid == 0) {
-    int run = 0;
-    for (int c = c_lo; c < c_hi; ++c) { s_cpre[c - c_lo] = run; run += in_counts[c]; }
-    s_cpre[max(c_hi - c_lo, 0)] = run;
-  }
-  __syncthreads();
-  int total = c_hi > c_lo ? s_cpre[c_hi - c_lo] : 0;
-  const size_t cap_list = (size_t)((group * LT_AGG_C + LT_AGG_W - 1) / LT_AGG_W) * LT_AGG_C;  // roots one pass can leave
-  agg_item* bufA = scratch + (size_t)blockIdx.x * 2 * cap_list;
-  agg_item* bufB = bufA + cap_list;
-  agg_item* cur = nullptr;  // nullptr: the incoming lists (through s_src)
-  agg_item* nxt = bufA;
-  const int goal = FINAL ? 1 : LT_AGG_C;
-  int guard = 0;
-  bool first = true;
-  auto source_of = [&](int q) -> int {  // item q of the concatenation of the incoming lists: its place in in_items
-    int c = 0;
-    for (int step = 32; step >= 1; step >>= 1)
-      if (c + step < c_hi - c_lo && s_cpre[c + step] <= q) c += step;
-    return (c_lo + c) * LT_AGG_C + (q - s_cpre[c]);
-  };
-  while ((first ? total > 1 : total > goal) && guard++ < 64) {
-    int produced = 0;
-    for (int w0 = 0; w0 < total; w0 += LT_AGG_W) {
-      const int wn = min(LT_AGG_W, total - w0);
-      int r;
-      if (cur == nullptr) {
-        for (int t = tid; t < wn; t += NT) s_src[t] = source_of(w0 + t);
-        __syncthreads();
-        r = agg_window<1, true, NT>(keys, n, nullptr, in_items, s_src, 0, wn, nxt + produced, nodes4, s_dl, s_flag, s_owner, s_half,
-                                    s_misc);
-      } else {
-        r = agg_window<2, true, NT>(keys, n, nullptr, cur, s_src, w0, wn, nxt + produced, nodes4, s_dl, s_flag, s_owner, s_half,
-                                    s_misc);
-      }
-      if (r > LT_AGG_C && tid == 0) atomicOr(flags, LT_FLAG_HIER_OVERFLOW);
-      produced += min(r, LT_AGG_C);
-    }
-    __threadfence();
-    __syncthreads();
-    if (!first && produced >= total) {  // no progress: cannot happen (a window of >= 2 items always merges its closest pair)
-      if (tid == 0) atomicOr(flags, LT_FLAG_HIER_OVERFLOW);
-      break;
-    }
-    total = produced;
-    cur = nxt;
-    nxt = (nxt == bufA) ? bufB : bufA;
-    first = false;
-  }
-  if (!FINAL) {
-    // the list that is left (<= LT_AGG_C items; an incoming list of one item untouched) goes out
-    for (int t = tid; t < min(total, LT_AGG_C); t += NT) {
-      float* o = (float*)&out_items[(size_t)blockIdx.x * LT_AGG_C + t];
-      if (cur == nullptr) {
-        const float* q = (const float*)&in_items[source_of(t)];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = q[k];
-      } else {
-        const volatile float* q = (const volatile float*)&cur[t];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = q[k];
-      }
-    }
-    if (tid == 0) {
-      out_counts[blockIdx.x] = min(total, LT_AGG_C);
-      if (total > LT_AGG_C) atomicOr(flags, LT_FLAG_HIER_OVERFLOW);
-    }
-  }
-}
-
 // ---- host orchestration -----------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -1223,57 +864,13 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
     hipLaunchKernelGGL(k_gather, dim3(cdiv(np, 256)), dim3(256), 0, stream, s->verts, s->faces, s->n_verts, n, np,
                        s->vals[cur], s->params, s->tris, s->seg);
     LT_MARK();  // 4
-    // LIDARHIP_HIER=agg: the bottom-up hierarchy in LDS windows (k_agg_*: the same nodes bit for bit, tools/r05/hier_ab.py, but
-    // 203 us against 87 us on the 1 M-triangle mesh -- profiles/r05/lbvh_hier_ab.txt); default: segment tree + top-down nodes
-    static const bool hier_seg = []() { const char* e = getenv("LIDARHIP_HIER"); return !(e && strcmp(e, "agg") == 0); }();
-    // Levels of the bottom-up hierarchy: windows of LT_AGG_W leaves, then groups of LT_AGG_G windows of the level below until
-    // at most 32 windows are left for the final workgroup.  Scratch in the (otherwise unused) binary-node array: per level its
-    // root lists (LT_AGG_C items a window) and, above level 1, the workgroups' lists between passes.
-    constexpr int LT_AGG_G = 8;
-    int agg_w[16], agg_levels = 0;
-    size_t agg_need = 0;
-    {
-      int w = cdiv(n, LT_AGG_W);
-      agg_w[agg_levels++] = w;
-      agg_need += (size_t)w * LT_AGG_C;
-      while (w > 32 && agg_levels < 15) {
-        w = cdiv(w, LT_AGG_G);
-        agg_w[agg_levels++] = w;
-        agg_need += (size_t)w * LT_AGG_C + (size_t)w * 2 * cdiv(LT_AGG_G * LT_AGG_C, LT_AGG_W) * LT_AGG_C;
-      }
-      agg_need += (size_t)2 * cdiv(32 * LT_AGG_C, LT_AGG_W) * LT_AGG_C;  // the final workgroup's lists
-    }
-    size_t agg_counts = 0;
-    for (int k = 0; k < agg_levels; ++k) agg_counts += (size_t)agg_w[k];
-    const bool use_agg = !hier_seg && !lt_binary_path() && n >= 2 && agg_need <= (size_t)s->cap_faces &&
-                         agg_counts <= (size_t)1024 * cdiv(s->cap_faces, LT_SORT_TILE);
-    if (np >= 2 && !use_agg) {
+    if (np >= 2) {
       const int sub = np < LT_SEG_SUB ? np : LT_SEG_SUB;
       hipLaunchKernelGGL(k_seg_sub, dim3(np / sub), dim3(256), 0, stream, s->seg, np, sub);
       if (np / sub > 1) hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, stream, s->seg, np / sub);
     }
     LT_MARK();  // 5
-    if (use_agg) {
-      agg_item* base = (agg_item*)s->nodes;
-      int* cnt = (int*)s->hist;  // (the sort is done with it)
-      const float4* leafbox = s->seg + 2 * (size_t)np;
-      agg_item* items = base;
-      base += (size_t)agg_w[0] * LT_AGG_C;
-      hipLaunchKernelGGL(k_agg_leaves, dim3(agg_w[0]), dim3(LT_AGG_W), 0, stream, s->keys[cur], n, leafbox, items, cnt, s->nodes4,
-                         s->flags);
-      for (int k = 1; k < agg_levels; ++k) {
-        agg_item* out_items = base;
-        base += (size_t)agg_w[k] * LT_AGG_C;
-        agg_item* scratch = base;
-        base += (size_t)agg_w[k] * 2 * cdiv(LT_AGG_G * LT_AGG_C, LT_AGG_W) * LT_AGG_C;
-        hipLaunchKernelGGL(k_agg_upper<false>, dim3(agg_w[k]), dim3(LT_AGG_W), 0, stream, s->keys[cur], n, items, cnt, agg_w[k - 1],
-                           LT_AGG_G, scratch, out_items, cnt + agg_w[k - 1], s->nodes4, s->flags);
-        items = out_items;
-        cnt += agg_w[k - 1];
-      }
-      hipLaunchKernelGGL(k_agg_upper<true>, dim3(1), dim3(LT_AGG_W), 0, stream, s->keys[cur], n, items, cnt, agg_w[agg_levels - 1],
-                         agg_w[agg_levels - 1], base, (agg_item*)nullptr, (int*)nullptr, s->nodes4, s->flags);
-    } else if (lt_binary_path()) {  // A/B: binary nodes for k_trace (one ray per lane)
+    if (lt_binary_path()) {  // A/B: binary nodes for k_trace (one ray per lane)
       hipLaunchKernelGGL(k_hierarchy, dim3(cdiv(n > 1 ? n - 1 : 1, 256)), dim3(256), 0, stream, s->keys[cur], n, np,
                          s->seg, s->nodes);
     } else {
@@ -1311,8 +908,8 @@ int lt_build_launch(lt_scene* s, hipStream_t stream, lt_stats* stats) {
   return LT_OK;
 }
 
-// debug helpers (not part of the documented ABI): fill / fetch the 4-wide node array of a scene (tools/r05/hier_ab.py compares
-// the two hierarchy builders node for node)
+// debug helpers (not part of the documented ABI): fill / fetch the 4-wide node array of a scene (tests pin the node array of
+// seeded meshes by SHA-256: a change of the sort or of the hierarchy kernels must leave it bit-identical)
 extern "C" int lt_debug_nodes4_fill(lt_scene* s, int byte) {
   if (!s || !s->nodes4) return LT_ERR_INVALID_ARG;
   LT_HIP(hipSetDevice(s->device));

@@ -95,10 +95,6 @@ struct lt_scene {
   int2* sc_slices;              // [sc_cap_queue] queue of (block, first candidate) slices
   int* sc_large_count;          // [4]: [0] queued big triangles, [1] queued slices; reset by k_sc_resolve
   int sc_cap_cells, sc_cap_queue;
-#ifdef LT_SC_WIN
-  int* sc_win;                  // experiment (-DLT_SC_WIN=n, lt_scatter.hip): first vertex of every triangle block's LDS window
-  int sc_cap_win;
-#endif
   int built;
   hipStream_t last_stream;
   hipEvent_t probe[2];   // caller's events to record around the dominant kernel of the next cast (one shot)

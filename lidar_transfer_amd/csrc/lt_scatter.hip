@@ -541,7 +541,7 @@ template <bool PUSH, bool WIDE>
 __device__ __forceinline__ void sc_setup(sc_shared& S, const float* __restrict__ verts, const int* __restrict__ faces,
                                          int n_verts, int n_faces, int first, float ox, float oy, float oz,
                                          const rs_params& P, int* __restrict__ large, int* __restrict__ large_count,
-                                         unsigned* __restrict__ flags, sc_one& rA, sc_one& rB, int win0 = 0) {
+                                         unsigned* __restrict__ flags, sc_one& rA, sc_one& rB) {
   const int tid = threadIdx.x;
   rA.cnt = 0; rA.a0 = 0; rB.cnt = 0; rB.a0 = 0;
   const int fA = first + tid, fB = first + 256 + tid;
@@ -552,52 +552,12 @@ __device__ __forceinline__ void sc_setup(sc_shared& S, const float* __restrict__
   }
   // Every load below is unconditional (a lane without a triangle, or with a bad index, reads element 0): nothing the
   // compiler could want to wait for stands between the two index loads and the six vertex loads.
-#ifdef LT_SC_PRIO  // experiment: a wave that is about to issue its gathers goes first (the others are computing)
-  __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef LT_SC_WIN
-  // VERDICT r04 item 5 (experiment): the block's vertices lie in a short index window (a marching-cubes / grid mesh numbers
-  // its vertices almost in face order): the window [win0, win0 + LT_SC_WIN) -- win0 from k_sc_win's table -- is loaded
-  // COALESCED, together with the index triples, and the six gathers read LDS; an index outside the window takes the global
-  // gather.  The point: no vertex load waits for an index load.
-  __shared__ float s_winv[3 * LT_SC_WIN];
-  constexpr int WPT = (3 * LT_SC_WIN + 255) / 256;
-  float wreg[WPT];
-  {
-    const size_t lim = 3 * (size_t)n_verts;
-#pragma unroll
-    for (int k = 0; k < WPT; ++k) {
-      const size_t q = 3 * (size_t)win0 + (size_t)(k * 256 + tid);
-      wreg[k] = (k * 256 + tid < 3 * LT_SC_WIN && q < lim) ? verts[q] : 0.f;
-    }
-  }
-#endif
   const i3 iA = *at<WIDE>((const i3*)faces, (unsigned)(hasA ? fA : 0));
   i3 iB = iA;
   if (LT_SC_T2 > 0) iB = *at<WIDE>((const i3*)faces, (unsigned)(hasB ? fB : 0));
   const unsigned nv = (unsigned)n_verts;
   const bool okA = hasA && (unsigned)iA.x < nv && (unsigned)iA.y < nv && (unsigned)iA.z < nv;
   const bool okB = hasB && (unsigned)iB.x < nv && (unsigned)iB.y < nv && (unsigned)iB.z < nv;
-#ifdef LT_SC_WIN
-#pragma unroll
-  for (int k = 0; k < WPT; ++k)
-    if (k * 256 + tid < 3 * LT_SC_WIN) s_winv[k * 256 + tid] = wreg[k];
-  __syncthreads();
-  auto vert = [&](unsigned idx) -> f3 {
-    const unsigned rel = idx - (unsigned)win0;
-    if (rel < (unsigned)LT_SC_WIN) return f3{s_winv[3 * rel], s_winv[3 * rel + 1], s_winv[3 * rel + 2]};
-    return *at<WIDE>((const f3*)verts, idx);
-  };
-  const f3 A0 = vert(okA ? (unsigned)iA.x : (unsigned)win0);
-  const f3 A1 = vert(okA ? (unsigned)iA.y : (unsigned)win0);
-  const f3 A2 = vert(okA ? (unsigned)iA.z : (unsigned)win0);
-  f3 B0 = A0, B1 = A1, B2 = A2;
-  if (LT_SC_T2 > 0) {
-    B0 = vert(okB ? (unsigned)iB.x : (unsigned)win0);
-    B1 = vert(okB ? (unsigned)iB.y : (unsigned)win0);
-    B2 = vert(okB ? (unsigned)iB.z : (unsigned)win0);
-  }
-#else
   const f3 A0 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.x : 0u);
   const f3 A1 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.y : 0u);
   const f3 A2 = *at<WIDE>((const f3*)verts, okA ? (unsigned)iA.z : 0u);
@@ -607,15 +567,7 @@ __device__ __forceinline__ void sc_setup(sc_shared& S, const float* __restrict__
     B1 = *at<WIDE>((const f3*)verts, okB ? (unsigned)iB.y : 0u);
     B2 = *at<WIDE>((const f3*)verts, okB ? (unsigned)iB.z : 0u);
   }
-#endif
-#ifdef LT_SC_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
   if (PUSH && ((hasA && !okA) || (hasB && !okB))) atomicOr(flags, LT_FLAG_BAD_INDEX);
-#if defined(LT_SC_STOP) && LT_SC_STOP == 1  // instruction-count experiment (tools/sc_sections.sh): loads only
-  rA.cnt = (A0.x + A1.y + A2.z + B0.x + B1.y + B2.z == 12345.f) ? 1 : 0;
-  return;
-#endif
   if (okA) rA = sc_record<PUSH>(S, tid, fA, A0, A1, A2, ox, oy, oz, P, large, large_count);
   if (LT_SC_T2 > 0 && okB) rB = sc_record<PUSH>(S, 256 + tid, fB, B0, B1, B2, ox, oy, oz, P, large, large_count);
 }
@@ -755,9 +707,6 @@ struct sc_job {
   rs_params P; const float4* grid; const float4* sdirs; const float4* dirs;  // its ray set (P: by value, see lt_rayset)
   unsigned long long* cell; int* large; int* large_count; int2* slices;
   unsigned* flags; unsigned long long* counters;
-#ifdef LT_SC_WIN
-  int* win;
-#endif
   float* endpoints; int* endcolors; float* range; float* endrem; int* tri;  // its images
   float ox, oy, oz;
   int n_verts, n_faces, n_rays, cap_slices;
@@ -782,25 +731,6 @@ __device__ __forceinline__ int sc_find_job(const int (&block0)[LT_SC_MAX_BATCH],
   return j;
 }
 
-#ifdef LT_SC_WIN
-// experiment: the smallest vertex index of every block of LT_SC_T faces (12 B per face read once more: the price of the window)
-__global__ __launch_bounds__(256) void k_sc_win(const sc_batch B) {
-  __shared__ int red[4];
-  const int j = sc_find_job(B.tris_block0, (int)blockIdx.x);
-  const sc_job& J = B.job[j];
-  const int lb = (int)blockIdx.x - B.tris_block0[j];
-  int m = 0x7fffffff;
-  for (int k = threadIdx.x; k < 3 * LT_SC_T; k += 256) {
-    const size_t q = 3 * (size_t)lb * LT_SC_T + k;
-    if (q < 3 * (size_t)J.n_faces) { const int v = J.faces[q]; m = (v >= 0 && v < m) ? v : m; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) { m = min(min(red[0], red[1]), min(red[2], red[3])); J.win[lb] = m == 0x7fffffff ? 0 : m; }
-}
-#endif
 
 // One workgroup = LT_SC_T consecutive triangles of one scan: phase A, prefix sum, phase B over its first ~B.cap
 // candidates; what is left is queued as (workgroup, first candidate) slices for k_sc_rest.
@@ -815,17 +745,8 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
   const rs_params P = J.P;
   const float ox = J.ox, oy = J.oy, oz = J.oz;
   sc_one rA, rB;
-#ifdef LT_SC_WIN
-  sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, J.large, J.large_count, J.flags, rA,
-                       rB, J.win[lb]);
-#else
   sc_setup<true, WIDE>(S, J.verts, J.faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, J.large, J.large_count, J.flags, rA,
                        rB);
-#endif
-#if defined(LT_SC_STOP) && LT_SC_STOP <= 2  // ... up to the angular bounds and the LDS record
-  if (rA.cnt + rB.cnt == 0x7fffffff) J.counters[7] = 1;
-  return;
-#endif
   int total, preA, preB;
   sc_prefix(S, rA, rB, preA, preB, total);
   // The workgroup keeps the triangles that start below the cap; exactly one slot sees the crossing and its lane queues
@@ -852,10 +773,6 @@ __global__ __launch_bounds__(256) void k_sc_tris(const sc_batch B) {
     }
   }
   __syncthreads();
-#if defined(LT_SC_STOP) && LT_SC_STOP == 3  // ... up to the prefix sums and the cap
-  if (S.kept == 0x7fffffff) J.counters[7] = 1;
-  return;
-#endif
   const int kept = S.kept;
   unsigned n_tests = 0, n_cand = 0;
   sc_round_robin<COUNT, WIDE, 256, (LT_SC_T > 256 ? 512 : 256)>(S.pre, S.q0, S.q1, S.q2, P, J.grid, J.sdirs, J.cell, first, 0,
@@ -897,11 +814,7 @@ __global__ __launch_bounds__(256) void k_sc_rest(const sc_batch B) {
     const int2 sl = J.slices[q];
     const int first = sl.x * LT_SC_T;
     sc_one rA, rB;
-#ifdef LT_SC_WIN
-    sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, nullptr, nullptr, nullptr, rA, rB, J.win[sl.x]);
-#else
     sc_setup<false, WIDE>(S, verts, faces, J.n_verts, J.n_faces, first, ox, oy, oz, P, nullptr, nullptr, nullptr, rA, rB);
-#endif
     int total, preA, preB;
     sc_prefix(S, rA, rB, preA, preB, total);
     __syncthreads();
@@ -1176,14 +1089,6 @@ static int sc_reserve(lt_scene* s, int n_faces, int n_rays, hipStream_t stream) 
     LT_HIP(hipMalloc((void**)&s->sc_slices, cap * sizeof(int2)));
     s->sc_cap_queue = (int)cap;
   }
-#ifdef LT_SC_WIN
-  if (n_faces / LT_SC_T + 2 > s->sc_cap_win) {
-    if (s->sc_win) { LT_HIP(hipDeviceSynchronize()); (void)hipFree(s->sc_win); s->sc_win = nullptr; }
-    const int cap = (n_faces + n_faces / 4 + 1024) / LT_SC_T + 2;
-    LT_HIP(hipMalloc((void**)&s->sc_win, (size_t)cap * sizeof(int)));
-    s->sc_cap_win = cap;
-  }
-#endif
   return LT_OK;
 }
 
@@ -1218,9 +1123,6 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     J.P = r->prm_host; J.grid = r->grid; J.sdirs = r->sdirs; J.dirs = r->dirs;
     J.cell = s->sc_cell; J.large = s->sc_large; J.large_count = s->sc_large_count; J.slices = s->sc_slices;
     J.flags = s->flags; J.counters = s->counters;
-#ifdef LT_SC_WIN
-    J.win = s->sc_win;
-#endif
     J.endpoints = it[i].endpoints; J.endcolors = it[i].endcolors; J.range = it[i].range; J.endrem = it[i].endrem;
     J.tri = it[i].tri;
     J.ox = it[i].origin[0]; J.oy = it[i].origin[1]; J.oz = it[i].origin[2];
@@ -1256,9 +1158,6 @@ static int sc_launch_batch(const sc_item* it, int n_items, unsigned flags, hipSt
     else hipLaunchKernelGGL((KERNEL<false, false>), GRID, b, 0, stream, B); \
   } while (0)
   if (tb > 0) {
-#ifdef LT_SC_WIN
-    hipLaunchKernelGGL(k_sc_win, dim3(tb), b, 0, stream, B);
-#endif
     if (probe && probe->probe[0]) LT_HIP(hipEventRecord(probe->probe[0], stream));
     SC_LAUNCH(k_sc_tris, dim3(tb));
     if (probe) {

@@ -16,6 +16,10 @@ from typing import Callable, Dict, List, Optional, Sequence
 XGMI_LINK_GBS = 64.0
 
 
+#: scan files of SemanticKITTI sequences 00-07 (configuration C5 of BASELINE.json)
+C5_SEQUENCES = [("00", 4541), ("01", 1101), ("02", 4661), ("03", 801), ("04", 271), ("05", 2761), ("06", 1101), ("07", 1101)]
+
+
 class _StagedWork:
     """A transfer of device tensors over a backend that only moves host memory (gloo): the payload is staged through
     host buffers, `wait()` completes the transport and -- on the receiving side -- copies into the device tensors.  This

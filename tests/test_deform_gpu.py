@@ -2,10 +2,14 @@
 :1121-1178, from point clouds without leaving HBM) against the STEP-BY-STEP API of this package -- whose steps are each pinned
 to the reference (projection: goldens F6 / F9; fusion: F8 + the C restatement; ray cast: goldens C1-C4 of the real reference;
 reverse projection and write(): golden F7)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COLOR_DICT = {0: [0, 0, 0], 10: [245, 150, 100], 40: [255, 0, 255], 48: [75, 0, 75], 50: [0, 200, 255],
               70: [0, 175, 0], 80: [150, 240, 255]}
 SRC = (32, 512, 3.0, -25.0)
@@ -172,7 +176,6 @@ def test_cp_adaption_equals_the_references_own_deform_and_write(pf):
     """Golden F12 (tests/golden/make_golden_deform.py): the reference's `MultiSemLaserScan.deform('cp', poses, idx)` + `write()`
     run AS A WHOLE on three seeded source scans (identity poses) -- the bytes of velodyne/NNNNNN.bin and labels/NNNNNN.label and
     the images `deform` leaves on the object.  `DeviceDeform.cp` of the same clouds must produce the same bytes."""
-    import os
     import torch
     from lidar_transfer_amd.deform import DeviceDeform
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f12_deform_cp.npz"))
@@ -390,7 +393,7 @@ def test_mesh_adaptions_on_random_configurations_equal_the_references_own_deform
         rs.close(); sc.close()
         return res
 
-    exact, inexact = 0, []
+    exact, inexact, table = 0, [], []
     for k in range(int(g["n_cases"])):
         adaption, src, tgt, n_scans, bnds, voxel, seeds = pin_cases.deform_mesh_case(k)
         bnds = bnds.copy()
@@ -403,28 +406,42 @@ def test_mesh_adaptions_on_random_configurations_equal_the_references_own_deform
                    for p, r, l in clouds]
             got = dd.mesh(dev) if adaption == "mesh" else dd.mergemesh(dev)
             torch.cuda.synchronize()
-            vol = dd.vol if adaption == "mesh" else got["volume"]
-            assert tuple(int(x) for x in vol._vol_dim) == tuple(int(x) for x in g[f"{tag}_vol_dim"]), tag
+            vol_dim = dd.vol._vol_dim if adaption == "mesh" else got["vol_dim"]
+            assert tuple(int(x) for x in vol_dim) == tuple(int(x) for x in g[f"{tag}_vol_dim"]), tag
             if adaption == "mergemesh":
                 assert np.array_equal(bnds, g[f"{tag}_bnds_after"]) and bnds.dtype == g[f"{tag}_bnds_after"].dtype, tag
             want = [str(x) for x in g[f"{tag}_sha"]]
             have = [_sha(got["bin"].cpu().numpy()), _sha(got["label_file"].cpu().numpy()), _sha(got["range"].cpu().numpy()),
                     _sha(got["label"].cpu().numpy())]
             n_written, n_faces, n_points, n_hit = [int(x) for x in g[f"{tag}_counts"]]
-            if have == want and got["n_faces"] == n_faces:
+            rng_, lab_ = got["range"].cpu().numpy(), got["label"].cpu().numpy()
+            dpix = int((rng_.view(np.int32) != g[f"{tag}_range"].view(np.int32)).sum())
+            dlab = int((lab_ != g[f"{tag}_limg"].astype(np.int32)).sum())
+            dmax = float(np.abs(rng_ - g[f"{tag}_range"]).max())
+            row = {"tag": tag, "adaption": adaption, "bytes_equal": bool(have == want and got["n_faces"] == n_faces),
+                   "dfaces": int(got["n_faces"] - n_faces), "dpix": dpix, "dlab": dlab, "dmax_m": dmax, "pixels": int(rng_.size)}
+            table.append(row)
+            if row["bytes_equal"]:
                 exact += 1
+                assert dpix == 0 and dlab == 0 and dmax == 0.0, row
             else:
-                rng_, lab_ = got["range"].cpu().numpy(), got["label"].cpu().numpy()
-                dpix = int((rng_.view(np.int32) != g[f"{tag}_range"].view(np.int32)).sum())
-                dlab = int((lab_ != g[f"{tag}_limg"].astype(np.int32)).sum())
-                dmax = float(np.abs(rng_ - g[f"{tag}_range"]).max())
-                inexact.append((tag, got["n_faces"] - n_faces, dpix, dlab, round(dmax, 4), rng_.size))
+                inexact.append(row)
         dd.close()
-    print(f"\nF13b / F14b: {exact} output scans reproduced to the byte; others (tag, d faces, differing range pixels, differing "
-          f"labels, max |d range| m, pixels): {inexact}")
+    # the per-scan table, for profiles/rNN/ (the closing script copies it): what is claimed is what is asserted below
+    art = os.environ.get("LT_TEST_ARTIFACTS", os.path.join(ROOT, "gpurun_out", "artifacts"))
+    try:
+        os.makedirs(art, exist_ok=True)
+        with open(os.path.join(art, "f13b_f14b_table.json"), "w") as fh:
+            json.dump({"what": "F13b / F14b: DeviceDeform.mesh / .mergemesh (fusion='numpy') against the reference's own deform() + "
+                               "write(), per output scan", "exact": exact, "rows": table}, fh, indent=1)
+    except OSError:
+        pass
+    print(f"\nF13b / F14b: {exact} of {len(table)} output scans reproduced to the byte; others: {inexact}")
     assert exact >= 22 and len(inexact) <= 2
-    for tag, dfaces, dpix, dlab, dmax, npix in inexact:   # a boundary voxel moved a handful of vertices: a few pixels, centimetres
-        assert abs(dfaces) <= 64 and dpix <= 0.01 * npix and dlab <= 2 and dmax < 0.2, (tag, dfaces, dpix, dlab, dmax)
+    # a voxel on a pixel boundary (numpy's own last-bit arctan2, `_check_volumes`) moved a vertex: north_star's tolerance holds --
+    # every range within 1e-4 m, NO label differs, at most 16 of the scan's pixels differ at all
+    for row in inexact:
+        assert row["dmax_m"] <= 1e-4 and row["dlab"] == 0 and row["dpix"] <= 16 and abs(row["dfaces"]) <= 64, row
 
 
 def test_mergemesh_error_paths_and_geometry_cache():

@@ -247,3 +247,53 @@ def test_bench_under_torchrun_one_rank_rccl(gather):
     assert out["config"]["gather"]["mode"] == gather
     assert ("sharded" in out["config"]["parallelism"]) == (gather == "sharded")
     assert np.isfinite(out["value"]) and out["value"] > 0
+
+
+def test_bench_line_is_compact_and_complete(tmp_path):
+    """the default command's shape on a small configuration: ONE stdout line < 8 KB with the contract keys, a compact
+    roofline and cpu_baseline"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "C1",
+                          "--scenes", "4", "--cpu-reps", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) < 8000, (len(lines), len(res.stdout))
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    rl, cb = out["roofline"], out["cpu_baseline"]
+    assert rl["kernel"] == "k_sc_tris" and rl["bound"] == "hbm" and 0 < rl["frac"] < 1 and rl["avg_kernel_ms"] > 0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3 and rl["step_clock"]["frac_on_step_clock"] > 0
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert out["verified"] is True and out["dtype"] == "f32" and out["scaling"] == "weak"
+
+
+def test_bench_job_c5_eight_ranks_sharing_the_gpu_equals_single_process(tmp_path):
+    """Configuration C5 reduced (SemanticKITTI 00-07's real scan-count ratios / 100 = 169 output scans, 64 x 2048 images,
+    20 k-triangle meshes) through bench.py's OWN chunked gather: 8 ranks (gloo transport, all on cuda:0 -- the one-GPU
+    box) block-partition the job, render their unequal blocks and gather range + label images on rank 0 in pieces inside
+    the timed region; what rank 0 holds equals the single-process run byte for byte."""
+    common = ["--job", "c5/100", "--tris", "20000", "--scenes", "8", "--streams", "8", "--warmup", "1", "--no-cpu-baseline"]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common], capture_output=True, text=True, timeout=900,
+                        env=dict(base, LT_BENCH_DUMP=one))
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", *common],
+                        capture_output=True, text=True, timeout=1500,
+                        env=dict(base, LT_BENCH_DUMP=eight, LT_BENCH_SHARE_GPU="1", LT_BENCH_BACKEND="gloo", LT_BENCH_GATHER="root",
+                                 OMP_NUM_THREADS="4"))
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    l1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    l8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][0])
+    assert l1["n_gpus"] == 1 and l8["n_gpus"] == 8 and l8["scaling"] == "strong" and l8["config"]["gather"]["mode"] == "root"
+    assert l1["verified"] is True and l8["verified"] is True
+    a, b = np.load(one), np.load(eight)
+    assert a["range"].shape == (169, 64 * 2048) and b["range"].shape == a["range"].shape
+    assert a["range"].tobytes() == b["range"].tobytes() and a["label"].tobytes() == b["label"].tobytes()
+    assert (a["range"] > 0).mean() > 0.5

@@ -933,3 +933,20 @@ def test_lbvh_on_degenerate_morton_trees(oracle):
             _assert_bits(a[k], ref[k], f"scatter {k} n={n}")
             _assert_bits(b[k], ref[k], f"lbvh {k} n={n}")
         assert int((ref["tri"] >= 0).sum()) > 100
+
+
+def test_lbvh_node_array_is_pinned():
+    """The 4-wide node array Scene.build writes on five seeded meshes (300 ... 1 M triangles), by SHA-256 (digests recorded
+    with round 5's three-kernels-per-digit sort and segment-tree hierarchy, tools/nodes4_digest.py): the sort is stable and
+    the hierarchy deterministic, so ANY correct re-implementation of either (round 6: the one-pass-per-digit sort) must
+    reproduce the array bit for bit -- including which nodes are never written."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import nodes4_digest
+    want = {"s0_300": "c8bf9696b448e94b8dc430eb52d5cf92e5302685ab91e8eead9a87d04cf33c8c",
+            "s1_5000": "050f4c60ecd95455e9e499ef8b16aee968f124f95211c71cc3d2bc2a2e036f49",
+            "s0_20000": "4861dd6d0265c2b8e6cb07a85cbc585e5bf77149fadfdb4c3e19912a574ed83e",
+            "s2_200000": "2bb99f9066fb393c76f5a6e89abf28107704d146479a964f6d2edeee3f7845f5",
+            "s0_1000000": "59e63c6b0565fc31ee67834ad4543ba88ed0c8b7bf9cb6d69e6e5634960ef79b"}
+    assert nodes4_digest.digests() == want
