@@ -424,6 +424,56 @@ int lt_deform_scan_dev(lt_projector* projector, lt_tsdf* vol, lt_mesh* mesh, lt_
                        float* endpoints, int* endcolors, float* range, float* endrem, int* tri, unsigned trace_flags,
                        void* stream, int sync);
 
+/* ---- deform('mergemesh'): the volume geometry as device-resident state ---------------------------------------------
+ *
+ * The reference's default adaption clips ONE voxel_bounds array output scan after output scan (auxiliary/laserscan.py:957-962
+ * on the array lidar_deform.py:321 hands every MultiSemLaserScan; auxiliary/fusion_lidar.py:33-37 then re-derives its upper
+ * bounds): a scan's volume depends on every earlier scan of the SEQUENCE.  lt_mm_state holds that array in HBM;
+ * lt_mm_geometry_dev applies the five numpy statements to it in stream order, from the kept points' bounds the projection
+ * left on the device (lt_proj_images.bnds), and mirrors the outcome into a pinned host record behind an event -- no
+ * stream synchronisation between projection and fusion.  lt_mm_geometry_get waits for that event only (passed already
+ * when the caller has read the chain's mesh sizes) and returns the record. */
+typedef struct lt_mm_state lt_mm_state;
+typedef struct lt_mm_geometry {
+  double bnds_given[6]; /* the bounds after the clip (:961-962): what TSDFVolume(vol_bnds, ...) is constructed from */
+  double bnds_after[6]; /* ... after fusion_lidar.py:36: what the reference leaves in the caller's array            */
+  int dim[3];           /* ceil((max - min) / voxel_size), fusion_lidar.py:34                                         */
+  int status;           /* 0 ok; 1 no point survived the projection (state untouched; numpy raises in amin);          */
+                        /* 2 the clipped volume is empty (state holds the clip; the reference dies in np.ones)        */
+  int ticket;           /* the call's ordinal on its state (set by lt_mm_geometry_get): later calls hold later state  */
+  int reserved;
+} lt_mm_geometry;
+/* vol_bnds = {xmin, xmax, ymin, ymax, zmin, zmax}; bounds_are_int: the caller's array has an integer dtype (the YAML's
+ * ints: fusion_lidar.py:36 then truncates). */
+int lt_mm_state_create(lt_mm_state** state, const double* vol_bnds, int bounds_are_int, double voxel_size, int device);
+int lt_mm_state_destroy(lt_mm_state* state);
+/* New bounds for a new sequence (the reference starts one process per sequence, experiments/run_lidar_deform.sh). */
+int lt_mm_state_reset(lt_mm_state* state, const double* vol_bnds, void* stream);
+/* point_bnds: DEVICE [6] as lt_proj_images.bnds.  *ticket names the record.  The kernels of successive calls on one state
+ * run in the order of the calls, whatever their streams (each waits for the previous call's event).  seq >= 0: the call is
+ * scan `seq` of its sequence (numbered from 0 since create / reset) and waits on the HOST until scans 0 .. seq - 1 have made
+ * theirs -- several chains (threads, streams) of one sequence; seq < 0: the caller keeps the order itself.  point_bnds ==
+ * NULL with seq >= 0: the scan gives up its turn (it failed before its projection); *ticket = -1. */
+int lt_mm_geometry_dev(lt_mm_state* state, const double* point_bnds, int seq, int* ticket, void* stream);
+int lt_mm_geometry_get(lt_mm_state* state, int ticket, lt_mm_geometry* out);
+
+/* deform('mergemesh') of ONE output scan in ONE call (auxiliary/laserscan.py:921-1012; the interpreter lock of a Python
+ * caller is released for all of it): `cloud` -- the merged source scans -- through do_range_projection_new(fov, remove=True)
+ * into images the projector owns (fov_up / fov_down: the TARGET's, H x W: the SOURCE's, laserscan.py:929-931, :952-954) ->
+ * lt_mm_geometry_dev(mm, seq) on the kept points' bounds -> with `vol` != NULL (the volume of the geometry the caller
+ * EXPECTS, i.e. the previous scan's): lt_fusion_scan_dev on it, then lt_mm_geometry_get -> *geo; *done = 1 when vol was
+ * built from exactly geo->bnds_given (the images are this scan's), else 0: the caller makes the volume of geo->bnds_given
+ * and calls lt_mergemesh_rerun_dev, which runs the chain on the images the projector still holds.  With vol == NULL the
+ * call waits for the record and returns *done = 0.  geo->status != 0: *done = 0, nothing else to do. */
+int lt_mergemesh_scan_dev(lt_projector* projector, lt_mm_state* mm, int seq, lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene,
+                          lt_rayset* rayset, const lt_cloud* cloud, int is_f64, double fov_up, double fov_down, int H, int W,
+                          const double* beam_angles, int n_beams, float obs_weight, unsigned tsdf_flags, const float* origin,
+                          float* endpoints, int* endcolors, float* range, float* endrem, int* tri, unsigned trace_flags,
+                          void* stream, lt_mm_geometry* geo, int* done);
+int lt_mergemesh_rerun_dev(lt_projector* projector, lt_tsdf* vol, lt_mesh* mesh, lt_scene* scene, lt_rayset* rayset, int H, int W,
+                           float obs_weight, unsigned tsdf_flags, const float* origin, float* endpoints, int* endcolors,
+                           float* range, float* endrem, int* tri, unsigned trace_flags, void* stream);
+
 /* ---- after the render: back-projection, scan packing, comparison ------------------------------- */
 
 /* xyz of every cell from its range and pixel coordinates; replaces LaserScan.do_reverse_projection_new
@@ -459,6 +509,11 @@ const char* lt_last_error(void);
 
 /* Library version string, e.g. "lidarhip 0.1 (gfx950)". */
 const char* lt_version(void);
+
+/* Layout version of the structs this header declares (lt_proj_images, lt_stats, lt_mm_geometry ...): a caller compiled
+ * against another header must not pass them.  lt_abi_version() returns the library's; the Python binding compares at load. */
+#define LT_ABI_VERSION 6
+int lt_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,9 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_fusion_scan_dev", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
            "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free", "lt_projector_create",
            "lt_projector_destroy", "lt_range_projection_batch_dev", "lt_mesh_renumber_dev",
-           "lt_tsdf_integrate_multi_dev", "lt_deform_scan_dev"]
+           "lt_tsdf_integrate_multi_dev", "lt_deform_scan_dev", "lt_mm_state_create", "lt_mm_state_destroy", "lt_mm_state_reset",
+           "lt_mm_geometry_dev", "lt_mm_geometry_get", "lt_mergemesh_scan_dev", "lt_mergemesh_rerun_dev", "lt_abi_version"]
+LT_ABI_VERSION = 6   # include/lidarhip.h: layout version of the structs mirrored below
 
 
 class Stats(C.Structure):
@@ -56,6 +58,12 @@ class ProjImages(C.Structure):
     """Mirror of ``lt_proj_images``: the [H*W] DEVICE images of one cloud; NULL = not wanted."""
     _fields_ = [(k, C.c_void_p) for k in ("idx", "range", "xyz", "rem", "label", "color", "mask", "label_folded", "proj_x",
                                            "proj_y", "proj_xf", "proj_yf", "n_kept", "bnds")]
+
+
+class MMGeometry(C.Structure):
+    """Mirror of ``lt_mm_geometry``: the volume geometry of one ``mergemesh`` output scan."""
+    _fields_ = [("bnds_given", C.c_double * 6), ("bnds_after", C.c_double * 6), ("dim", C.c_int * 3), ("status", C.c_int),
+                ("ticket", C.c_int), ("reserved", C.c_int)]
 
 
 _lib = None
@@ -180,6 +188,21 @@ def load():
     lib.lt_deform_scan_dev.restype = C.c_int
     for name in ("lt_projector_create", "lt_projector_destroy", "lt_range_projection_batch_dev"):
         getattr(lib, name).restype = C.c_int
+    lib.lt_mm_state_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int]
+    lib.lt_mm_state_destroy.argtypes = [vp]
+    lib.lt_mm_state_reset.argtypes = [vp, C.POINTER(C.c_double), vp]
+    lib.lt_mm_geometry_dev.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), vp]
+    lib.lt_mergemesh_scan_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(Cloud), C.c_int, C.c_double, C.c_double, C.c_int,
+                                          C.c_int, vp, C.c_int, C.c_float, C.c_uint, fp, vp, vp, vp, vp, vp, C.c_uint, vp,
+                                          C.POINTER(MMGeometry), C.POINTER(C.c_int)]
+    lib.lt_mergemesh_rerun_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint, fp, vp, vp, vp, vp, vp, C.c_uint, vp]
+    lib.lt_mm_geometry_get.argtypes = [vp, C.c_int, C.POINTER(MMGeometry)]
+    for name in ("lt_mm_state_create", "lt_mm_state_destroy", "lt_mm_state_reset", "lt_mm_geometry_dev", "lt_mm_geometry_get",
+                 "lt_mergemesh_scan_dev", "lt_mergemesh_rerun_dev", "lt_abi_version"):
+        getattr(lib, name).restype = C.c_int
+    lib.lt_abi_version.argtypes = []
+    if lib.lt_abi_version() != LT_ABI_VERSION:  # a stale prebuilt library: its structs are laid out differently
+        raise RuntimeError(f"{path}: ABI version {lib.lt_abi_version()} != {LT_ABI_VERSION} of this binding (rebuild the library)")
     _lib = lib
     return lib
 

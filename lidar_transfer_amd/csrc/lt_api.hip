@@ -27,6 +27,7 @@ int lt_cu_count(int device) {
 
 extern "C" const char* lt_last_error(void) { return g_err; }
 extern "C" const char* lt_version(void) { return "lidarhip 0.1 (gfx950)"; }
+extern "C" int lt_abi_version(void) { return LT_ABI_VERSION; }
 
 template <typename T>
 static int dev_alloc(T** p, size_t count) {

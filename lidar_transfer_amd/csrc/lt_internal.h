@@ -111,6 +111,7 @@ struct lt_tsdf {
   float voxel_size, trunc_margin;
   double voxel_size_d;  // as given (the numpy branch of the reference computes with the Python float, fusion_lidar.py:300)
   double fov_up_deg, fov_down_deg;
+  double bnds_given[6];  // vol_bnds as passed to lt_tsdf_create (lt_mergemesh_scan_dev: is this the volume of a scan's geometry?)
   size_t n;
   float *tsdf, *weight, *color, *rem;
   // sparse bookkeeping (lt_tsdf.hip): an (x, y) COLUMN of dim_z voxels is "dirty" when an integrate since the last

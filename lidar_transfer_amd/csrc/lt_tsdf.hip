@@ -1679,6 +1679,7 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   lt_tsdf* t = (lt_tsdf*)calloc(1, sizeof(lt_tsdf));
   if (!t) return LT_ERR_NO_MEMORY;
   t->device = device;
+  memcpy(t->bnds_given, vol_bnds, sizeof(t->bnds_given));
   double n = 1;
   for (int k = 0; k < 3; ++k) {  // fusion_lidar.py:33-36
     t->dim[k] = (int)ceil((vol_bnds[2 * k + 1] - vol_bnds[2 * k]) / voxel_size);

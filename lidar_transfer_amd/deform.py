@@ -14,7 +14,9 @@ library's device entry points on ONE HIP stream:
     the scans merged into ONE cloud (:939-949), ``do_range_projection_new`` with the TARGET field of view onto the SOURCE
     H x W (:929-931, :952-954), ``vol_bnds`` clipped IN PLACE by the rounded bounds of the kept points (:957-962), a fresh
     ``TSDFVolume`` of the TARGET field of view (:968), one ``integrate``, rays of the target sensor, ray cast, ``write``
-    =  ``lt_range_projection_batch_dev`` (+ the bounds, one 48-byte read-back) -> ``lt_fusion_scan_dev`` -> ``lt_pack_scan_dev``
+    =  ``lt_range_projection_batch_dev`` (+ the kept points' bounds, left on the device) -> ``lt_mm_geometry_dev`` (the five
+       numpy statements on the device-resident bounds, record mirrored to pinned memory) -> ``lt_fusion_scan_dev`` on the
+       PREVIOUS scan's geometry (checked afterwards, re-run when the bounds moved) -> ``lt_pack_scan_dev``
 
 ``cp``    (:827-861, :1121-1178)
     the merged cloud through ``do_range_projection_new(target fov, remove=True)`` + ``do_label_projection_new`` +
@@ -33,6 +35,92 @@ from . import _lib
 from .raytracer import RaySet, Scene
 
 
+class MergeMeshState:
+    """The ONE ``voxel_bounds`` array ``deform('mergemesh')`` clips output scan after output scan (laserscan.py:957-962 +
+    fusion_lidar.py:33-37 on the array lidar_deform.py:321 passes to every ``MultiSemLaserScan``), as device-resident state
+    (``lt_mm_state``): a scan's volume geometry depends on EVERY earlier scan of its sequence, so the scans of a sequence
+    go through :meth:`geometry` in order -- ``seq`` numbers them when several chains (host threads, streams) share the state
+    -- and a job that is cut into blocks (``lidar_transfer_amd.dist``) starts every block at a sequence boundary or replays
+    the bounds of the scans before it (:func:`lidar_transfer_amd.dist.mergemesh_blocks`).  ``vol_bnds``: the caller's
+    [3, 2] numpy array; it is kept current (``bnds_after`` of the latest scan) like the reference's.  :meth:`reset` = a
+    new sequence (the reference starts a new process with the configured bounds per sequence)."""
+
+    def __init__(self, vol_bnds, voxel_size, device):
+        import threading
+
+        import numpy as np
+        self._lib = _lib.load()
+        self._np = np
+        self.vol_bnds = vol_bnds if isinstance(vol_bnds, np.ndarray) else np.array(vol_bnds)
+        if self.vol_bnds.shape != (3, 2):
+            raise ValueError("vol_bnds is [3, 2] (rows x, y, z; columns min, max)")
+        self.voxel_size = float(voxel_size)
+        self.device = int(device)
+        self.is_int = bool(np.issubdtype(self.vol_bnds.dtype, np.integer))
+        h = C.c_void_p()
+        b = (C.c_double * 6)(*[float(x) for x in self.vol_bnds.reshape(-1)])
+        _lib.check(self._lib.lt_mm_state_create(C.byref(h), b, int(self.is_int), self.voxel_size, self.device), "lt_mm_state_create")
+        self._h = h
+        self._turn = threading.Lock()
+        self.pred = None         # bnds_given of the latest VERIFIED scan: what the next chain is launched on
+        self._settled_ticket = -1
+        self.stats = dict(scans=0, waited=0, rerun=0)
+
+    def reset(self, vol_bnds=None, stream=None):
+        """Sequence boundary: the bounds go back to ``vol_bnds`` (default: what the array held at construction is NOT
+        remembered -- pass the configured bounds) and the next scan waits for its geometry instead of assuming the last one."""
+        np = self._np
+        if vol_bnds is not None:
+            self.vol_bnds[...] = np.asarray(vol_bnds).reshape(3, 2)
+        b = (C.c_double * 6)(*[float(x) for x in self.vol_bnds.reshape(-1)])
+        with self._turn:
+            _lib.check(self._lib.lt_mm_state_reset(self._h, b, C.c_void_p(stream.cuda_stream if stream is not None else 0)),
+                       "lt_mm_state_reset")
+            self.pred = None   # (the caller has completed the scans of the previous sequence: FusionScanPipeline.reset_bounds flushes)
+
+    def geometry(self, bnds, stream, seq=None):
+        """Queue the bounds statements for one scan behind its projection (``bnds``: the projector's device [3, 2] float64);
+        with ``seq`` (the scan's number in its sequence, from 0 since construction / :meth:`reset`) the call waits on the host
+        until scans 0 .. seq - 1 have queued theirs (several chains share the state)."""
+        t = C.c_int(0)
+        _lib.check(self._lib.lt_mm_geometry_dev(self._h, C.c_void_p(bnds.data_ptr()), -1 if seq is None else int(seq), C.byref(t),
+                                                C.c_void_p(stream.cuda_stream)), "lt_mm_geometry_dev")
+        return t.value
+
+    def skip(self, seq):
+        """a scan that failed before its geometry call gives up its turn (no-op when the call was made after all)"""
+        t = C.c_int(0)
+        self._lib.lt_mm_geometry_dev(self._h, None, int(seq), C.byref(t), None)
+
+    def get(self, ticket):
+        g = _lib.MMGeometry()
+        _lib.check(self._lib.lt_mm_geometry_get(self._h, int(ticket), C.byref(g)), "lt_mm_geometry_get")
+        return g
+
+    def settle(self, ticket, geo):
+        """The scan's record is in: mirror the bounds it left behind into the caller's array (the latest scan wins) and make
+        its geometry the prediction for the chains launched from now on."""
+        np = self._np
+        with self._turn:
+            if ticket > self._settled_ticket:
+                self._settled_ticket = ticket
+                if geo.status != 1:
+                    self.vol_bnds[...] = np.array(list(geo.bnds_after)).reshape(3, 2)   # (exact: ints are ints already)
+                if geo.status == 0:
+                    self.pred = tuple(geo.bnds_given)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lt_mm_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceDeform:
     """One chain of device objects (projector, TSDF volume, mesh, scene, ray set of the target sensor) that turns the
     source scans of one output scan into the target sensor's scan.
@@ -45,13 +133,14 @@ class DeviceDeform:
     """
 
     def __init__(self, source, target, vol_bnds=None, voxel_size=0.1, beam_angles=None, t_beam_angles=None,
-                 preserve_float=False, device=None, merge=True, fusion="cuda", mesh_volume=True):
+                 preserve_float=False, device=None, merge=True, fusion="cuda", mesh_volume=True, rayset=None, mm_state=None):
         """``fusion``: ``"cuda"`` -- the arithmetic of the reference's CUDA kernel (class-aware with ``merge``), or ``"numpy"`` --
         that of its numpy branch (``FUSION_GPU_MODE == 0``, fusion_lidar.py:290-388; what goldens F13 / F14 are made by).
         ``vol_bnds``: [3,2]; for :meth:`mergemesh` it is STATE, clipped in place call after call exactly as the reference
         clips the one ``voxel_bounds`` array it hands every ``MultiSemLaserScan`` (lidar_deform.py:321-401,
         laserscan.py:960-962, fusion_lidar.py:36) -- pass a numpy array to see it.  ``mesh_volume=False``: do not allocate the
-        fixed volume of :meth:`mesh` (a caller that only runs ``mergemesh``)."""
+        fixed volume of :meth:`mesh` (a caller that only runs ``mergemesh``).  ``rayset`` / ``mm_state``: a shared target ray set
+        (read-only) and a shared :class:`MergeMeshState` -- several chains of one sequence (``FusionScanPipeline``)."""
         import numpy as np
         import torch
 
@@ -73,6 +162,10 @@ class DeviceDeform:
         self._merge_flag, self._fusion, self._voxel_size, self._idx = bool(merge), fusion, voxel_size, idx
         self._mm_vols = {}   # mergemesh: geometry -> TSDFVolume (the clipped bounds settle after a few output scans)
         self.vol_bnds = None
+        self._mm_state, self._mm_own = mm_state, mm_state is None
+        self._rayset_own = rayset is None
+        if mm_state is not None and vol_bnds is None:
+            vol_bnds = mm_state.vol_bnds
         if vol_bnds is not None:
             self.vol_bnds = vol_bnds if isinstance(vol_bnds, np.ndarray) else np.array(vol_bnds)
             if self.vol_bnds.shape != (3, 2):
@@ -83,9 +176,12 @@ class DeviceDeform:
                 self._merge = self.vol._flags
             self.mesh_obj = DeviceMesh(idx)
             self.scene = Scene(idx)
-            rays = create_rays_device(self.t_fov_up, self.t_fov_down, self.t_H, self.t_W, device=idx)
-            self.rayset = RaySet(rays, self.t_H)
-            self._rays = rays
+            if rayset is None:
+                rays = create_rays_device(self.t_fov_up, self.t_fov_down, self.t_H, self.t_W, device=idx)
+                self.rayset = RaySet(rays, self.t_H)
+                self._rays = rays
+            else:
+                self.rayset = rayset
         self.n_rays = self.t_H * self.t_W
 
     def _stream(self):
@@ -160,71 +256,213 @@ class DeviceDeform:
         return res
 
     # ---- deform('mergemesh') + write ------------------------------------------------------------------------------------
-    def _mergemesh_volume(self, merged_bnds):
-        """laserscan.py:957-969 + fusion_lidar.py:33-37 on ``self.vol_bnds`` -- the same numpy statements on the same array,
-        in place -- and the device volume of the resulting geometry (kept per geometry: the bounds only ever shrink)."""
-        import numpy as np
+    def _mm(self):
+        if self._mm_state is None:
+            self._mm_state = MergeMeshState(self.vol_bnds, self._voxel_size, self._idx)
+            self.vol_bnds = self._mm_state.vol_bnds
+        return self._mm_state
 
-        from .fusion import TSDFVolume
-        vb = self.vol_bnds
-        mb = np.rint(merged_bnds).astype(int)                           # :957
-        # (no short cut for "nothing clipped": with float bounds fusion_lidar.py:34-36 re-derives the upper bounds from
-        # ceil((max - min) / voxel) every scan, and that can GROW the volume by a voxel per call -- the statements are run as they are)
-        vb[:, 0] = np.maximum(vb[:, 0], mb[:, 0])                       # :961
-        vb[:, 1] = np.minimum(vb[:, 1], mb[:, 1])                       # :962
-        as_given = np.array(vb, dtype=np.float64)
-        dim = np.ceil((vb[:, 1] - vb[:, 0]) / self._voxel_size).copy(order='C').astype(int)   # fusion_lidar.py:34-35
-        if (dim <= 0).any():
-            raise RuntimeError(f"DeviceDeform.mergemesh: the clipped volume is empty (bounds {vb.tolist()})")
-        vb[:, 1] = vb[:, 0] + dim * self._voxel_size                    # fusion_lidar.py:36 (an int array truncates, as there)
-        key = (tuple(float(x) for x in as_given.reshape(-1)),)
-        vol = self._mm_vols.pop(key, None)
-        if vol is None:
-            while len(self._mm_vols) >= 3:
-                self._mm_vols.pop(next(iter(self._mm_vols))).close()
-            vol = TSDFVolume(as_given, self._voxel_size, self.t_fov_up, self.t_fov_down, device=self._idx,
-                             merge=self._merge_flag, mode=self._fusion)   # (3) the TARGET field of view (:968-969)
-            assert tuple(int(x) for x in vol._vol_dim) == tuple(int(x) for x in dim)
-        self._mm_vols[key] = vol                                        # most recently used last
-        return vol
-
-    def mergemesh(self, clouds, origin=(0.0, 0.0, 0.0), pack=True):
-        """``clouds``: the (points, remissions, label) CUDA triples of the source scans, already in the primary scan's frame
-        (``apply_inv_pose``, laserscan.py:949: pose handling is out of scope).  Returns what :meth:`mesh` returns -- the
-        target scan's ``range`` / ``rem`` / ``label`` images, ``endpoints``, ``tri``, the merged cloud's source image under
-        ``source``, ``bin`` / ``label_file`` with ``pack`` -- plus ``vol_dim`` / ``vol_origin`` of this scan's volume.  One
-        read-back of 48 bytes (the kept points' bounds decide the volume's geometry) besides those of :meth:`mesh`."""
+    def reset_bounds(self, vol_bnds=None):
+        """A new sequence: ``vol_bnds`` (the configured bounds) replaces what the previous sequence's scans left in the array,
+        as a fresh process of the reference would (experiments/run_lidar_deform.sh runs lidar_deform.py per sequence)."""
         if self.vol_bnds is None:
-            raise RuntimeError("DeviceDeform.mergemesh: constructed without vol_bnds")
-        torch, lib = self._torch, self._lib
+            raise RuntimeError("DeviceDeform.reset_bounds: constructed without vol_bnds")
+        self._mm().reset(vol_bnds, self._stream())
+
+    def mergemesh_bounds(self, clouds, seq=None):
+        """The bounds bookkeeping of :meth:`mergemesh` WITHOUT the scan: projection of the merged cloud + the bounds statements
+        on the device state, nothing read back.  For a rank of a multi-GPU job whose block starts inside a sequence
+        (``lidar_transfer_amd.dist.mergemesh_plan``: the scans before the block are replayed through this)."""
+        if self.vol_bnds is None:
+            raise RuntimeError("DeviceDeform.mergemesh_bounds: constructed without vol_bnds")
+        torch = self._torch
+        mm = self._mm()
         st = self._stream()
         pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
         rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
         lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]
-        # (1) + (2): the SOURCE image size and beam angles, the TARGET field of view (laserscan.py:929-931, :952-954)
         src = self.projector.project([(pts, rem, lab)], self.t_fov_up, self.t_fov_down, self.H, self.W, new=True, remove=True,
-                                     beam_angles=self.beam_angles, outputs=("range", "rem", "label_folded", "bnds"),
-                                     stream=st)[0]
-        # (everything the host can prepare goes before the read-back: the GPU idles from the read-back to the next launch)
+                                     beam_angles=self.beam_angles, outputs=("range", "bnds"), stream=st)[0]
+        with mm._turn:
+            mm.pred = None   # (the next scan waits for its own record: the replayed ones were not verified on the host)
+        return mm.geometry(src["bnds"], st, seq)
+
+    def _mergemesh_volume(self, given, dim):
+        """The device volume of one geometry -- constructed from the bounds as laserscan.py:961-962 leave them, like the
+        reference's TSDFVolume(vol_bnds, ...) (:968), which derives ``dim`` and the origin from them (fusion_lidar.py:33-37).
+        Kept per geometry, most recently used last: the bounds only ever shrink and settle after a few scans of a sequence.
+        At most three, and ONE when a volume exceeds 4 GiB (the default +-50 / +-50 / +-5 m at 5 cm is 12.8 GB): an evicted
+        volume is closed -- a caller still holding it from an earlier result gets a RuntimeError, not freed memory."""
+        import numpy as np
+
+        from .fusion import TSDFVolume
+        key = tuple(float(x) for x in given)
+        vol = self._mm_vols.pop(key, None)
+        if vol is None:
+            nbytes = 16 * int(dim[0]) * int(dim[1]) * int(dim[2])
+            keep = 0 if nbytes > (4 << 30) else 2
+            while len(self._mm_vols) > keep:
+                self._mm_vols.pop(next(iter(self._mm_vols))).close()
+            vol = TSDFVolume(np.array(key).reshape(3, 2), self._voxel_size, self.t_fov_up, self.t_fov_down, device=self._idx,
+                             merge=self._merge_flag, mode=self._fusion)   # (3) the TARGET field of view (:968-969)
+            assert tuple(int(x) for x in vol._vol_dim) == tuple(int(x) for x in dim)
+        self._mm_vols[key] = vol
+        return vol
+
+    def mergemesh(self, clouds, origin=(0.0, 0.0, 0.0), pack=True, out=None, seq=None, source_images=False):
+        """``clouds``: the (points, remissions, label) CUDA triples of the source scans, already in the primary scan's frame
+        (``apply_inv_pose``, laserscan.py:949: pose handling is out of scope).  Returns what :meth:`mesh` returns -- the
+        target scan's ``range`` / ``rem`` / ``label`` images, ``endpoints``, ``tri``, the merged cloud's source image under
+        ``source``, ``bin`` / ``label_file`` with ``pack`` -- plus ``vol_dim`` / ``vol_origin`` / ``vol_bnds_after`` of this
+        scan's volume.  The kept points' bounds never visit the host before the fusion: the geometry statements run on the
+        device (:class:`MergeMeshState`), the chain is launched on the previous scan's geometry and verified against the
+        record afterwards (``mm_state.stats``: scans / waited = no prediction yet / rerun = the bounds moved).  ``seq``: this
+        scan's number in its sequence when several chains share the state.  By default the whole scan is ONE native call
+        (``lt_mergemesh_scan_dev``; the source image stays inside the projector); ``source_images=True`` composes it from
+        the public steps instead and returns the merged cloud's images under ``source``."""
+        if self.vol_bnds is None:
+            raise RuntimeError("DeviceDeform.mergemesh: constructed without vol_bnds")
+        torch, lib = self._torch, self._lib
+        mm = self._mm()
+        if not source_images:
+            return self._mergemesh_native(mm, clouds, origin, pack, out, seq)
+        try:
+            st = self._stream()
+            pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
+            rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
+            lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]
+            # (1) + (2): the SOURCE image size and beam angles, the TARGET field of view (laserscan.py:929-931, :952-954)
+            src = self.projector.project([(pts, rem, lab)], self.t_fov_up, self.t_fov_down, self.H, self.W, new=True, remove=True,
+                                         beam_angles=self.beam_angles, outputs=("range", "rem", "label_folded", "bnds"),
+                                         stream=st)[0]
+        except BaseException:
+            if seq is not None:
+                mm.skip(seq)
+            raise
+        ticket = mm.geometry(src["bnds"], st, seq)
         vp = C.c_void_p
         cp, dp, rp = (vp * 1)(src["label_folded"].data_ptr()), (vp * 1)(src["range"].data_ptr()), (vp * 1)(src["rem"].data_ptr())
-        out = self.scene.alloc_outputs(self.n_rays, label_image=True)
+        if out is None:
+            out = self.scene.alloc_outputs(self.n_rays, label_image=True)
         org = (C.c_float * 3)(*[float(x) for x in origin])
         flags = _lib.LT_TRACE_WRITE_MISSES | _lib.LT_TRACE_LABEL_IMAGE
-        bnds = src["bnds"].cpu().numpy()      # (synchronises the stream)
-        if not (bnds[:, 0] <= bnds[:, 1]).all():
-            raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
-        vol = self._mergemesh_volume(bnds)
-        with torch.cuda.device(self.device):
+
+        def p(key):
+            a = out.get(key)
+            return a.data_ptr() if a is not None else None
+
+        def chain(vol):
             _lib.check(lib.lt_fusion_scan_dev(vol._h, self.mesh_obj._h, self.scene._h, self.rayset._h, 1, cp, dp, rp,
-                                              self.H, self.W, 1.0, vol._flags, org, out["endpoints"].data_ptr(),
-                                              out["endcolors"].data_ptr(), out["range"].data_ptr(),
-                                              out["endrem"].data_ptr(), out["tri"].data_ptr(), flags, vp(st.cuda_stream), 0),
-                       "lt_fusion_scan_dev")
+                                              self.H, self.W, 1.0, vol._flags, org, p("endpoints"), p("endcolors"), p("range"),
+                                              p("endrem"), p("tri"), flags, vp(st.cuda_stream), 0), "lt_fusion_scan_dev")
+
+        def verdict(geo):
+            mm.settle(ticket, geo)
+            if geo.status == 1:
+                raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
+            if geo.status == 2:
+                raise RuntimeError(f"DeviceDeform.mergemesh: the clipped volume is empty (bounds {list(geo.bnds_given)})")
+
+        with torch.cuda.device(self.device):
+            pred = mm.pred
+            mm.stats["scans"] += 1
+            if pred is None:          # the first scan of a sequence: nothing to assume
+                mm.stats["waited"] += 1
+                geo = mm.get(ticket)
+                verdict(geo)
+                vol = self._mergemesh_volume(geo.bnds_given, geo.dim)
+                chain(vol)
+            else:
+                vol = self._mm_vols.get(pred)
+                if vol is None:       # (another chain of the sequence verified this geometry)
+                    import numpy as np
+                    b = np.array(pred).reshape(3, 2)
+                    vol = self._mergemesh_volume(pred, np.ceil((b[:, 1] - b[:, 0]) / self._voxel_size).astype(int))
+                chain(vol)            # (waits for the stream once, inside marching cubes: the record has arrived with it)
+                geo = mm.get(ticket)
+                verdict(geo)
+                if tuple(geo.bnds_given) != pred:   # the bounds moved: this scan once more, on its own geometry
+                    mm.stats["rerun"] += 1
+                    vol = self._mergemesh_volume(geo.bnds_given, geo.dim)
+                    chain(vol)
             res = dict(range=out["range"].view(self.t_H, self.t_W), rem=out["endrem"].view(self.t_H, self.t_W),
                        label=out["endcolors"].view(self.t_H, self.t_W), endpoints=out["endpoints"], tri=out["tri"],
                        source=src, n_verts=self.mesh_obj.n_verts, n_faces=self.mesh_obj.n_faces,
-                       vol_dim=tuple(int(x) for x in vol._vol_dim), vol_origin=vol._vol_origin.copy(), volume=vol)
+                       vol_dim=tuple(int(x) for x in geo.dim), vol_origin=vol._vol_origin.copy(),
+                       vol_bnds_after=[float(x) for x in geo.bnds_after], volume=vol)
+            if pack:
+                res["bin"], res["label_file"] = self._pack(out["endpoints"], False, out["endrem"], out["endcolors"], None,
+                                                           self.n_rays, st)
+        return res
+
+    def _mergemesh_native(self, mm, clouds, origin, pack, out, seq):
+        """:meth:`mergemesh` as one native call per scan (+ one more when the bounds moved)"""
+        torch, lib = self._torch, self._lib
+        vp = C.c_void_p
+        try:
+            st = self._stream()
+            pts = torch.cat([c[0] for c in clouds]) if len(clouds) != 1 else clouds[0][0]
+            rem = torch.cat([c[1] for c in clouds]) if len(clouds) != 1 else clouds[0][1]
+            lab = torch.cat([c[2] for c in clouds]) if len(clouds) != 1 else clouds[0][2]
+            if pts.dtype not in (torch.float32, torch.float64):
+                raise TypeError("clouds: float32 or float64 points")
+            pts = pts.contiguous()
+            rem = rem.contiguous() if rem.dtype == torch.float32 else rem.to(torch.float32).contiguous()
+            lab = lab.contiguous() if lab.dtype == torch.int32 else lab.to(torch.int32).contiguous()
+            cl = (_lib.Cloud * 1)()
+            cl[0].points, cl[0].rem, cl[0].label, cl[0].n = pts.data_ptr(), rem.data_ptr(), lab.data_ptr(), int(pts.shape[0])
+            beams = None
+            if self.beam_angles:
+                import numpy as np
+                beams = np.ascontiguousarray(self.beam_angles, dtype=np.float64)
+            if out is None:
+                out = self.scene.alloc_outputs(self.n_rays, label_image=True)
+        except BaseException:
+            if seq is not None:
+                mm.skip(seq)
+            raise
+        org = (C.c_float * 3)(*[float(x) for x in origin])
+        flags = _lib.LT_TRACE_WRITE_MISSES | _lib.LT_TRACE_LABEL_IMAGE
+
+        def p(key):
+            a = out.get(key)
+            return a.data_ptr() if a is not None else None
+        pred = mm.pred
+        vol = None
+        if pred is not None:
+            vol = self._mm_vols.get(pred)
+            if vol is None:       # (another chain of the sequence verified this geometry)
+                import numpy as np
+                b = np.array(pred).reshape(3, 2)
+                vol = self._mergemesh_volume(pred, np.ceil((b[:, 1] - b[:, 0]) / self._voxel_size).astype(int))
+        tflags = vol._flags if vol is not None else (_lib.LT_TSDF_HOST_MODE if self._fusion == "numpy" else self._merge)
+        geo, done = _lib.MMGeometry(), C.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.lt_mergemesh_scan_dev(self.projector._h, mm._h, -1 if seq is None else int(seq),
+                                                 vol._h if vol is not None else None, self.mesh_obj._h, self.scene._h, self.rayset._h,
+                                                 cl, int(pts.dtype == torch.float64), self.t_fov_up, self.t_fov_down, self.H, self.W,
+                                                 beams.ctypes.data_as(vp) if beams is not None else None,
+                                                 0 if beams is None else len(beams), 1.0, tflags, org, p("endpoints"),
+                                                 p("endcolors"), p("range"), p("endrem"), p("tri"), flags, vp(st.cuda_stream),
+                                                 C.byref(geo), C.byref(done)), "lt_mergemesh_scan_dev")
+            mm.stats["scans"] += 1
+            mm.settle(geo.ticket, geo)
+            if geo.status == 1:
+                raise ValueError("DeviceDeform.mergemesh: no point survives the projection (numpy: zero-size array to amin)")
+            if geo.status == 2:
+                raise RuntimeError(f"DeviceDeform.mergemesh: the clipped volume is empty (bounds {list(geo.bnds_given)})")
+            if not done.value:
+                mm.stats["waited" if vol is None else "rerun"] += 1
+                vol = self._mergemesh_volume(geo.bnds_given, geo.dim)
+                _lib.check(lib.lt_mergemesh_rerun_dev(self.projector._h, vol._h, self.mesh_obj._h, self.scene._h, self.rayset._h,
+                                                      self.H, self.W, 1.0, vol._flags, org, p("endpoints"), p("endcolors"),
+                                                      p("range"), p("endrem"), p("tri"), flags, vp(st.cuda_stream)),
+                           "lt_mergemesh_rerun_dev")
+            res = dict(range=out["range"].view(self.t_H, self.t_W), rem=out["endrem"].view(self.t_H, self.t_W),
+                       label=out["endcolors"].view(self.t_H, self.t_W), endpoints=out["endpoints"], tri=out["tri"],
+                       n_verts=self.mesh_obj.n_verts, n_faces=self.mesh_obj.n_faces,
+                       vol_dim=tuple(int(x) for x in geo.dim), vol_origin=vol._vol_origin.copy(),
+                       vol_bnds_after=[float(x) for x in geo.bnds_after], volume=vol, _keep=(pts, rem, lab))
             if pack:
                 res["bin"], res["label_file"] = self._pack(out["endpoints"], False, out["endrem"], out["endcolors"], None,
                                                            self.n_rays, st)
@@ -279,10 +517,14 @@ class DeviceDeform:
         for v in getattr(self, "_mm_vols", {}).values():
             v.close()
         self._mm_vols = {}
+        if getattr(self, "_mm_state", None) is not None and getattr(self, "_mm_own", False):
+            self._mm_state.close()
+        self._mm_state = None
         for name in ("rayset", "scene", "mesh_obj", "vol", "projector"):
             obj = getattr(self, name, None)
             if obj is not None:
-                obj.close()
+                if name != "rayset" or getattr(self, "_rayset_own", True):
+                    obj.close()
                 setattr(self, name, None)
 
     def __enter__(self):

@@ -1,9 +1,16 @@
 """Scan-parallel multi-GPU driver: one process per GPU, no data-path collective, one gather.
 
-Every output scan of the reference has its own mesh, BVH and image -- the loop body of
-``lidar_deform.py:393-462`` carries no state from one iteration to the next -- so the scan index list
-is block-partitioned over the ranks of a ``torch.distributed`` job (backend ``nccl`` = RCCL over xGMI
-on the GPU box, ``gloo`` in CPU tests) and the rendered images are gathered ONCE at the end.
+Every output scan of the reference has its own mesh, BVH and image, and for the adaptions ``cp`` and ``mesh`` the loop
+body of ``lidar_deform.py:393-462`` carries no state from one iteration to the next -- so the scan index list is
+block-partitioned over the ranks of a ``torch.distributed`` job (backend ``nccl`` = RCCL over xGMI on the GPU box,
+``gloo`` in CPU tests) and the rendered images are gathered ONCE at the end.
+
+``mergemesh`` -- the adaption the reference's shipped config selects -- is the exception: it clips ONE ``voxel_bounds``
+array scan after scan (laserscan.py:957-962, fusion_lidar.py:33-37), so a scan's volume lattice depends on every EARLIER
+scan of its sequence, and the reference starts every sequence with the configured bounds (one process per sequence,
+experiments/run_lidar_deform.sh).  A rank whose block starts in the middle of a sequence must therefore first REPLAY the
+bounds of the scans before it (projection + bounds statements only: ``DeviceDeform.mergemesh_bounds``), and every rank
+resets the bounds where its block crosses into a new sequence: :func:`mergemesh_plan`.
 """
 from __future__ import annotations
 
@@ -112,6 +119,30 @@ def job_scan_list(sequences, nscans: int = 1, offset: int = 0, batch_interval: i
     for name, n_files in sequences:
         out += [(name, i) for i in scan_indices(int(n_files), nscans, offset, batch_interval)]
     return out
+
+
+def mergemesh_plan(job: Sequence, world_size: int, rank: int) -> Dict[str, List]:
+    """This rank's share of a ``mergemesh`` job (``job``: the list of :func:`job_scan_list`), with what its ORDER-DEPENDENT
+    bounds need: ``block`` -- the rank's contiguous block of output scans (:func:`partition`); ``replay`` -- the scans of
+    the block's first sequence that come BEFORE the block: their clouds go through ``DeviceDeform.mergemesh_bounds``
+    (projection + the bounds statements, no fusion) so that the block's first scan finds the bounds the single-process run
+    would have left; ``resets`` -- the positions in ``block`` at which a new sequence starts: ``reset_bounds(configured
+    bounds)`` before that scan.  Position 0 is in ``resets`` exactly when nothing is to be replayed."""
+    job = list(job)
+    block = partition(job, world_size, rank)
+    if not block:
+        return {"block": [], "replay": [], "resets": []}
+    first_seq = block[0][0]
+    base, extra = divmod(len(job), world_size)
+    start = rank * base + min(rank, extra)   # (where partition() starts this rank's block)
+    replay = []
+    i = start - 1
+    while i >= 0 and job[i][0] == first_seq:
+        replay.append(job[i])
+        i -= 1
+    replay.reverse()
+    resets = [k for k in range(len(block)) if (k == 0 and not replay) or (k > 0 and block[k][0] != block[k - 1][0])]
+    return {"block": block, "replay": replay, "resets": resets}
 
 
 def partition(items: Sequence, world_size: int, rank: int) -> List:

@@ -308,7 +308,7 @@ class FusionScanPipeline:
     (``lt_fusion_scan_dev``) on its chain's thread, so the interpreter lock is free while the GPU works."""
 
     def __init__(self, vol_bnds, voxel_size, fov_up, fov_down, rays, H, chains=3, device=None, merge=True,
-                 label_image=False, source_hw=None, beam_angles=None):
+                 label_image=False, source_hw=None, beam_angles=None, fixed_volume=True):
         import queue
         import threading
         import weakref
@@ -333,9 +333,15 @@ class FusionScanPipeline:
         self._src_hw = tuple(int(x) for x in source_hw) if source_hw is not None else None
         self._src_fov = (float(fov_up), float(fov_down))
         self._beam_angles = sorted(beam_angles) if beam_angles else None
+        # submit_mergemesh(): `vol_bnds` is the sequence's STATE (kept by reference: a numpy array passed in is kept current,
+        # laserscan.py:960-962), every chain gets a DeviceDeform of its own, all share one MergeMeshState and this ray set.
+        # fixed_volume=False: no volume of the unclipped bounds per chain (a pipeline that only runs submit_mergemesh)
+        self._mm_args = dict(vol_bnds=vol_bnds, voxel_size=voxel_size, merge=merge, H=int(H))
+        self._mm_state = None
+        self._mm_seq = 0
         self._chains = []
         for _ in range(int(chains)):
-            ch = dict(vol=TSDFVolume(vol_bnds, voxel_size, fov_up, fov_down, device=idx, merge=merge),
+            ch = dict(vol=TSDFVolume(vol_bnds, voxel_size, fov_up, fov_down, device=idx, merge=merge) if fixed_volume else None,
                       mesh=DeviceMesh(idx), scene=Scene(idx), stream=torch.cuda.Stream(self.device), q=queue.Queue())
             if self._src_hw is not None:
                 from .laserscan import Projector
@@ -364,6 +370,14 @@ class FusionScanPipeline:
             if out is None:
                 out = ch["scene"].alloc_outputs(self.n_rays, label_image=self.label_image)
             h = w = 0
+            if obs and len(obs[0]) == 5:  # ("mergemesh", points, rem, label, seq) items
+                try:
+                    return self._scan_mergemesh(ch, obs, origin, out)
+                except BaseException:
+                    self._mm_state.skip(obs[0][4])  # (a failed scan must not hold up the sequence's later scans)
+                    raise
+            if ch["vol"] is None:
+                raise RuntimeError("FusionScanPipeline: constructed with fixed_volume=False (submit_mergemesh only)")
             if obs and len(obs[0]) == 4:  # ("clouds", points, rem, label) items: ONE native call (lt_deform_scan_dev)
                 return self._scan_clouds(ch, obs, origin, out)
             for k, (color_im, depth_im, rem_im) in enumerate(obs):
@@ -437,6 +451,31 @@ class FusionScanPipeline:
         res["_done"] = (done, keep, items)
         return res
 
+    def _scan_mergemesh(self, ch, items, origin, out):
+        """deform('mergemesh') of one output scan on this chain (DeviceDeform.mergemesh on the chain's stream): projection
+        with the target field of view -> the bounds statements on the shared device state, in sequence order -> fusion
+        chain on the predicted geometry -> verified against the record"""
+        torch = self._torch
+        dd = ch.get("deform")
+        if dd is None:
+            from .deform import DeviceDeform
+            a = self._mm_args
+            sensor_s = (self._src_hw[0], self._src_hw[1], self._src_fov[0], self._src_fov[1])
+            sensor_t = (a["H"], self.n_rays // a["H"], self._src_fov[0], self._src_fov[1])
+            dd = DeviceDeform(sensor_s, sensor_t, None, a["voxel_size"], beam_angles=self._beam_angles, device=self.device.index,
+                              merge=a["merge"], mesh_volume=False, rayset=self.rayset, mm_state=self._mm_state)
+            ch["deform"] = dd
+        clouds = [(pts, rem, lab) for _, pts, rem, lab, _ in items]
+        with torch.cuda.stream(ch["stream"]):
+            got = dd.mergemesh(clouds, origin, pack=False, out=out, seq=items[0][4])
+            done = torch.cuda.Event()
+            done.record(ch["stream"])
+        res = dict(out)
+        for k in ("n_verts", "n_faces", "vol_dim", "vol_origin", "vol_bnds_after"):
+            res[k] = got[k]
+        res["_done"] = (done, [got.get("source"), got.get("_keep")], items)
+        return res
+
     def _run_job(self, ch, job):
         ticket, obs, origin, out = job
         try:
@@ -490,6 +529,38 @@ class FusionScanPipeline:
             items.append(("clouds", c[0], c[1], c[2]))
         return self._submit(items, origin, out, inputs_ready)
 
+    def submit_mergemesh(self, clouds, origin=(0.0, 0.0, 0.0), out=None, inputs_ready=False):
+        """Queue one output scan of the reference's DEFAULT adaption (config/lidar_transfer.yaml:3; laserscan.py:921-1012): the
+        source scans' clouds merged, projected with the TARGET field of view (this pipeline's ``fov_up`` / ``fov_down``) onto the
+        SOURCE image (``source_hw``), ``vol_bnds`` clipped by the kept points' rounded bounds -- the statements run on the
+        device in SUBMISSION order, whichever chain a scan lands on --, a volume of that geometry, one integrate, marching
+        cubes, ray cast.  ``out`` must hold ``range`` / ``endrem`` / ``endcolors`` (label image) / ``endpoints`` / ``tri`` as
+        ``Scene.alloc_outputs(n, label_image=True)`` returns.  The scans of ONE sequence, in order; :meth:`reset_bounds`
+        between sequences.  Results additionally carry ``vol_dim`` / ``vol_origin`` / ``vol_bnds_after``."""
+        torch = self._torch
+        if self._src_hw is None:
+            raise RuntimeError("FusionScanPipeline.submit_mergemesh: construct with source_hw=(H, W)")
+        if not self.label_image:
+            raise RuntimeError("FusionScanPipeline.submit_mergemesh: construct with label_image=True")
+        if self._mm_state is None:
+            from .deform import MergeMeshState
+            self._mm_state = MergeMeshState(self._mm_args["vol_bnds"], self._mm_args["voxel_size"], self.device.index)
+        items = []
+        for c in clouds:
+            if len(c) != 3 or not isinstance(c[0], torch.Tensor) or not c[0].is_cuda:
+                raise ValueError("clouds: (points, remissions, label) CUDA tensors")
+            items.append(("mergemesh", c[0], c[1], c[2], self._mm_seq))
+        self._mm_seq += 1
+        return self._submit(items, origin, out, inputs_ready)
+
+    def reset_bounds(self, vol_bnds):
+        """A new sequence for :meth:`submit_mergemesh`: every submitted scan is completed, then the bounds state goes back to
+        ``vol_bnds`` (the configured bounds; the reference starts a new process per sequence)."""
+        self.flush()
+        self._mm_seq = 0   # (the new sequence's scans are numbered from 0 again)
+        if self._mm_state is not None:
+            self._mm_state.reset(vol_bnds)
+
     def wait(self, ticket):
         """Images of the scan with this ticket (complete when the call returns).  A ticket is handed out once."""
         ticket = int(ticket)
@@ -529,11 +600,17 @@ class FusionScanPipeline:
         for ch in chains:
             if ch["thread"] is not threading.current_thread():  # (__del__ may run on a worker that dropped the last reference)
                 ch["thread"].join()
+            if ch.get("deform") is not None:
+                ch["deform"].close()
             ch["mesh"].close()
             ch["scene"].close()
-            ch["vol"].close()
+            if ch["vol"] is not None:
+                ch["vol"].close()
             if ch.get("projector") is not None:
                 ch["projector"].close()
+        if getattr(self, "_mm_state", None) is not None and chains:
+            self._mm_state.close()
+            self._mm_state = None
         if getattr(self, "rayset", None) is not None and chains:
             self.rayset.close()
 

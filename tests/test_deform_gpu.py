@@ -481,3 +481,160 @@ def test_mergemesh_error_paths_and_geometry_cache():
         assert (got["range"] > 0).sum().item() > 50
     assert bnds[0, 1] <= 3 and len(dd._mm_vols) == 3
     dd.close()
+
+
+def _mm_sequence(n=9):
+    """a mergemesh sequence whose bounds MOVE (the cloud is cut back scan by scan, then stays): (points, rem, label) per scan"""
+    g = _gold("f14_deform_mergemesh.npz")
+    pts, rem, lab = _gold_clouds(g, "a0", 1)[0]
+    seq = []
+    for lim in (6.4, 6.4, 5.4, 5.4, 5.4, 4.4, 4.4, 4.4, 4.4, 4.4)[:n]:
+        keep = (pts[:, 0] < lim) & (pts.norm(dim=1) > 0)
+        seq.append([(pts[keep].contiguous(), rem[keep].contiguous(), lab[keep].contiguous())])
+    return seq
+
+
+def _mm_serial(seq, bnds, src=(32, 512, 3.0, -25.0), voxel=0.1):
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    dd = DeviceDeform(src, src, bnds, voxel, mesh_volume=False)
+    outs = []
+    for clouds in seq:
+        got = dd.mergemesh(clouds)
+        torch.cuda.synchronize()
+        outs.append(dict(range=got["range"].clone(), label=got["label"].clone(), rem=got["rem"].clone(), bin=got["bin"].clone(),
+                         vol_dim=got["vol_dim"], after=got["vol_bnds_after"], bnds=bnds.copy()))
+    stats = dict(dd._mm_state.stats)
+    dd.close()
+    return outs, stats
+
+
+def test_mergemesh_geometry_is_decided_on_the_device_and_only_the_first_scan_waits():
+    """no read-back of the kept points' bounds between projection and fusion.  The chain of a scan is
+    launched on the geometry of the previous scan and verified against the device's record afterwards: over a sequence
+    whose bounds move twice, the first scan waits for its record (nothing to assume), the two scans at which the bounds
+    move are run again, every other scan runs once -- and every scan equals a fresh DeviceDeform that is fed the same
+    prefix of the sequence (whose LAST scan is then always a waited-for one)."""
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    seq = _mm_sequence()
+    bnds = np.array([[-7, 7], [-7, 7], [-2, 3]])
+    outs, stats = _mm_serial(seq, bnds)
+    assert stats == {"scans": len(seq), "waited": 1, "rerun": 2}, stats
+    dims = [o["vol_dim"] for o in outs]
+    assert dims[0] == dims[1] and dims[2] == dims[3] == dims[4] and dims[5] == dims[8] and len(set(dims)) == 3
+    for k in (0, 2, 4, 5, 8):   # the same prefix on a new object: scan k is then the object's ... (every path: waited / rerun / assumed)
+        b2 = np.array([[-7, 7], [-7, 7], [-2, 3]])
+        dd = DeviceDeform((32, 512, 3.0, -25.0), (32, 512, 3.0, -25.0), b2, 0.1, mesh_volume=False)
+        for clouds in seq[:k]:
+            dd.mergemesh_bounds(clouds)          # bounds only: no fusion, nothing read back
+        got = dd.mergemesh(seq[k])               # (waits for its record: the replayed scans were not verified)
+        torch.cuda.synchronize()
+        assert dd._mm_state.stats == {"scans": 1, "waited": 1, "rerun": 0}
+        o = outs[k]
+        assert got["vol_dim"] == o["vol_dim"] and np.array_equal(b2, o["bnds"]) and got["vol_bnds_after"] == o["after"]
+        assert torch.equal(got["range"].view(torch.int32), o["range"].view(torch.int32)) and torch.equal(got["label"], o["label"])
+        assert torch.equal(got["bin"], o["bin"])
+        dd.close()
+    # int bounds stay ints (fusion_lidar.py:36 truncates into the caller's integer array)
+    assert bnds.dtype.kind == "i" and bnds[0, 1] <= 5
+
+
+def test_pipelined_mergemesh_equals_the_serial_sequence():
+    """FusionScanPipeline.submit_mergemesh: three chains (streams, host threads, volumes) share ONE bounds state; the bounds
+    statements run in submission order whichever chain a scan lands on, so every scan's images, volume geometry and the bounds
+    left in the caller's array equal the one-scan-at-a-time DeviceDeform.mergemesh run."""
+    import torch
+    from lidar_transfer_amd.laserscan import create_rays_device
+    from lidar_transfer_amd.pipeline import FusionScanPipeline
+    seq = _mm_sequence()
+    want, _ = _mm_serial(seq, np.array([[-7, 7], [-7, 7], [-2, 3]]))
+    H, W, fu, fd = 32, 512, 3.0, -25.0
+    bnds = np.array([[-7, 7], [-7, 7], [-2, 3]])
+    rays = create_rays_device(fu, fd, H, W, device=0)
+    with FusionScanPipeline(bnds, 0.1, fu, fd, rays, H, chains=3, device=0, label_image=True, source_hw=(H, W),
+                            fixed_volume=False) as pipe:
+        for rep in range(2):   # a second sequence after reset_bounds: the same again
+            tickets = [pipe.submit_mergemesh(clouds, inputs_ready=True) for clouds in seq]
+            for k, t in enumerate(tickets):
+                got = pipe.wait(t)
+                w = want[k]
+                assert got["vol_dim"] == w["vol_dim"] and got["vol_bnds_after"] == w["after"], (rep, k)
+                assert torch.equal(got["range"].view(-1).view(torch.int32), w["range"].view(-1).view(torch.int32)), (rep, k)
+                assert torch.equal(got["endcolors"].view(-1), w["label"].view(-1)) and \
+                    torch.equal(got["endrem"].view(-1), w["rem"].view(-1)), (rep, k)
+            assert np.array_equal(bnds, want[-1]["bnds"])
+            st = pipe._mm_state.stats
+            assert st["scans"] == (rep + 1) * len(seq) and st["waited"] >= rep + 1
+            pipe.reset_bounds(np.array([[-7, 7], [-7, 7], [-2, 3]]))
+            assert np.array_equal(bnds, [[-7, 7], [-7, 7], [-2, 3]])
+        with pytest.raises(RuntimeError):
+            pipe.submit_clouds(seq[0])       # no fixed volume in this pipeline
+            pipe.wait(pipe._next - 1)
+
+
+def test_mergemesh_blocks_of_a_multi_rank_job_equal_the_single_process_run():
+    """mergemesh carries STATE from scan to scan, so a block partition of a job needs
+    lidar_transfer_amd.dist.mergemesh_plan -- replay the bounds of the scans before a block that starts inside a sequence,
+    reset the bounds where a block crosses into the next sequence.  Two sequences over three 'ranks' (run one after the other
+    here): every scan's bytes and geometry equal the single-process run with a reset between the sequences."""
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    from lidar_transfer_amd.dist import job_scan_list, mergemesh_plan
+    cfg = [[-7, 7], [-7, 7], [-2, 3]]
+    seqs = {"00": _mm_sequence(7), "01": list(reversed(_mm_sequence(5)))}
+    job = job_scan_list([("00", 7), ("01", 5)])
+    src = (32, 512, 3.0, -25.0)
+
+    def run(dd, item):
+        got = dd.mergemesh(seqs[item[0]][item[1]])
+        torch.cuda.synchronize()
+        return (got["range"].clone(), got["label"].clone(), got["bin"].clone(), got["vol_dim"], got["vol_bnds_after"])
+
+    single = {}
+    dd = DeviceDeform(src, src, np.array(cfg), 0.1, mesh_volume=False)
+    for k, item in enumerate(job):
+        if k > 0 and item[0] != job[k - 1][0]:
+            dd.reset_bounds(np.array(cfg))
+        single[item] = run(dd, item)
+    dd.close()
+    seen = []
+    for rank in range(3):
+        plan = mergemesh_plan(job, 3, rank)
+        dd = DeviceDeform(src, src, np.array(cfg), 0.1, mesh_volume=False)
+        for item in plan["replay"]:
+            dd.mergemesh_bounds(seqs[item[0]][item[1]])
+        for k, item in enumerate(plan["block"]):
+            if k in plan["resets"] and (k > 0 or plan["replay"]):
+                dd.reset_bounds(np.array(cfg))
+            got = run(dd, item)
+            w = single[item]
+            assert got[3] == w[3] and got[4] == w[4], (rank, item)
+            assert torch.equal(got[0].view(torch.int32), w[0].view(torch.int32)) and torch.equal(got[1], w[1]) and \
+                torch.equal(got[2], w[2]), (rank, item)
+            seen.append(item)
+        dd.close()
+    assert seen == job
+    assert mergemesh_plan(job, 3, 1)["replay"] == job[:4] and mergemesh_plan(job, 3, 2)["replay"] == [("01", 0)]
+
+
+def test_mergemesh_composed_from_the_public_steps_equals_the_one_call_scan():
+    """DeviceDeform.mergemesh(source_images=True) -- projection, lt_mm_geometry_dev, lt_fusion_scan_dev as separate calls, the
+    merged cloud's images returned -- against the default (lt_mergemesh_scan_dev: one native call per scan): same scans, same
+    bounds, same statistics."""
+    import torch
+    from lidar_transfer_amd.deform import DeviceDeform
+    seq = _mm_sequence(6)
+    want, stats = _mm_serial(seq, np.array([[-7.0, 7.0], [-7.0, 7.0], [-2.0, 3.0]]))   # float bounds this time
+    b2 = np.array([[-7.0, 7.0], [-7.0, 7.0], [-2.0, 3.0]])
+    dd = DeviceDeform((32, 512, 3.0, -25.0), (32, 512, 3.0, -25.0), b2, 0.1, mesh_volume=False)
+    for k, clouds in enumerate(seq):
+        got = dd.mergemesh(clouds, source_images=True)
+        torch.cuda.synchronize()
+        w = want[k]
+        assert got["vol_dim"] == w["vol_dim"] and got["vol_bnds_after"] == w["after"] and np.array_equal(b2, w["bnds"]), k
+        assert torch.equal(got["range"].view(torch.int32), w["range"].view(torch.int32)) and torch.equal(got["label"], w["label"])
+        assert torch.equal(got["bin"], w["bin"])
+        assert got["source"]["range"].shape == (32, 512) and tuple(got["source"]["bnds"].shape) == (3, 2)
+    assert dd._mm_state.stats == stats and b2.dtype == np.float64
+    dd.close()

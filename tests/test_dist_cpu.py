@@ -232,3 +232,25 @@ def test_bench_cli_parses_without_a_gpu():
     assert res.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in res.stdout
+
+
+def test_mergemesh_plan_replays_the_sequence_prefix_and_resets_at_sequence_boundaries():
+    """mergemesh clips ONE bounds array scan after scan (laserscan.py:957-962): a block that starts inside a sequence replays
+    the scans before it, a block that crosses into a new sequence resets there; the blocks still tile the job."""
+    from lidar_transfer_amd.dist import C5_SEQUENCES, job_scan_list, mergemesh_plan, partition
+    job = job_scan_list([("00", 10), ("01", 3), ("02", 7)])
+    cover = []
+    for r in range(4):
+        p = mergemesh_plan(job, 4, r)
+        assert p["block"] == partition(job, 4, r)
+        cover += p["block"]
+        first = p["block"][0]
+        assert p["replay"] == [it for it in job if it[0] == first[0] and it[1] < first[1]]
+        for k in p["resets"]:
+            assert p["block"][k][1] == 0 or (k == 0 and not p["replay"])
+        assert (0 in p["resets"]) == (not p["replay"])
+    assert cover == job
+    assert mergemesh_plan(job, 4, 2) == {"block": job[10:15], "replay": [], "resets": [0, 3]}
+    assert mergemesh_plan([], 4, 0) == {"block": [], "replay": [], "resets": []}
+    big = job_scan_list(C5_SEQUENCES)
+    assert sum(len(mergemesh_plan(big, 8, r)["block"]) for r in range(8)) == len(big) == 16338

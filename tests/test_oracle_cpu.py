@@ -233,14 +233,18 @@ def test_header_compiles_as_plain_c_and_its_structs_match_the_ctypes_mirrors(tmp
     from lidar_transfer_amd import _lib
     src = tmp_path / "abi.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lidarhip.h"\nint main(void) {\n'
-                   '  printf("%zu %zu %zu %zu %u %u\\n", sizeof(lt_stats), sizeof(lt_cloud), sizeof(lt_proj_images),\n'
-                   '         offsetof(lt_proj_images, bnds), (unsigned)LT_TSDF_MERGE, (unsigned)LT_TSDF_HOST_MODE);\n  return 0;\n}\n')
+                   '  printf("%zu %zu %zu %zu %u %u %zu %zu %d\\n", sizeof(lt_stats), sizeof(lt_cloud), sizeof(lt_proj_images),\n'
+                   '         offsetof(lt_proj_images, bnds), (unsigned)LT_TSDF_MERGE, (unsigned)LT_TSDF_HOST_MODE,\n'
+                   '         sizeof(lt_mm_geometry), offsetof(lt_mm_geometry, status), LT_ABI_VERSION);\n  return 0;\n}\n')
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got[0] == ctypes.sizeof(_lib.Stats) and got[1] == ctypes.sizeof(_lib.Cloud)
     assert got[2] == ctypes.sizeof(_lib.ProjImages) and got[3] == _lib.ProjImages.bnds.offset
     assert got[4] == _lib.LT_TSDF_MERGE and got[5] == _lib.LT_TSDF_HOST_MODE
+    assert got[6] == ctypes.sizeof(_lib.MMGeometry) and got[7] == _lib.MMGeometry.status.offset
+    # the layout version a caller compiled against THIS header carries is the one the library reports and the binding checks
+    assert got[8] == _lib.LT_ABI_VERSION == _lib.load().lt_abi_version()
 
 
 def test_c_trace_argument_checks_raise_before_any_device_work():

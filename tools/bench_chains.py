@@ -648,15 +648,47 @@ def main():
                 ts.append(time.perf_counter() - t0)
             res.append((float(np.median(ts)), got["bin"].clone(), got["label_file"].clone(), got["range"].clone(), got["vol_dim"],
                         bnds.tolist(), got["n_faces"]))
+            mm_stats = dict(dd._mm_state.stats)
             dd.close()
         same = bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and
                     torch.equal(res[0][3].view(torch.int32), res[1][3].view(torch.int32)))
-        return {"what": "DeviceDeform.mergemesh: one 120 k-point cloud -> projection (target FOV) -> bounds read-back -> volume of the "
-                        "clipped geometry -> integrate -> marching cubes -> ray cast -> packed .bin / .label bytes",
+        # ... and with three output scans in flight (FusionScanPipeline.submit_mergemesh: the bounds statements run on the device in
+        # submission order, every chain is launched on the previous scan's geometry and verified afterwards)
+        pipelined = None
+        try:
+            import gc
+            from lidar_transfer_amd.pipeline import FusionScanPipeline
+            bnds_p = np.array([-50, 50, -50, 50, -5, 5]).reshape(3, 2)
+            with FusionScanPipeline(bnds_p, 0.05, wl["fov_up"], wl["fov_down"], rays, H, chains=3, device=local_rank,
+                                    label_image=True, source_hw=(H, W), fixed_volume=False) as pipe:
+                for tk_ in [pipe.submit_mergemesh(cloud, inputs_ready=True) for _ in range(12)]:
+                    pipe.wait(tk_)
+                bufs = [pipe._chains[0]["scene"].alloc_outputs(R, label_image=True) for _ in range(144)]
+                torch.cuda.synchronize()
+                gc.collect()
+                gc.disable()
+                try:
+                    tp0 = time.perf_counter()
+                    tks = [pipe.submit_mergemesh(cloud, out=b_, inputs_ready=True) for b_ in bufs]
+                    outs_p = [pipe.wait(tk_) for tk_ in tks]
+                    dtp = time.perf_counter() - tp0
+                finally:
+                    gc.enable()
+                okp = all(bool(torch.equal(o_["range"].view(-1).view(torch.int32), res[0][3].view(-1).view(torch.int32))) for o_ in outs_p)
+                pipelined = {"chains_in_flight": 3, "output_scans": len(bufs), "ms_per_output_scan": round(dtp / len(bufs) * 1e3, 4),
+                             "output_scans_per_s": round(len(bufs) / dtp, 1), "verified": bool(okp),
+                             "geometry_stats": dict(pipe._mm_state.stats),
+                             "api": "lidar_transfer_amd.pipeline.FusionScanPipeline.submit_mergemesh (no write())"}
+        except Exception as e:  # noqa: BLE001
+            pipelined = {"error": repr(e)[:300]}
+        return {"what": "DeviceDeform.mergemesh: one 120 k-point cloud -> projection (target FOV) -> bounds statements on the device "
+                        "(no read-back before the fusion) -> volume of the clipped geometry -> integrate -> marching cubes -> ray "
+                        "cast -> packed .bin / .label bytes",
                 "ms_per_output_scan": round(min(r_[0] for r_ in res) * 1e3, 4), "points_in": int(cloud[0][0].shape[0]),
                 "vol_dim": list(res[0][4]), "vol_bnds_after": res[0][5], "mesh_faces": int(res[0][6]),
                 "points_written": int(res[0][1].shape[0]), "hit_fraction": round(float((res[0][3] > 0).float().mean().item()), 4),
-                "verified": same, "parity": "goldens F14 / F14b (tests/test_deform_gpu.py): the reference's own deform('mergemesh') + write()"}
+                "verified": same, "pipelined": pipelined, "geometry_stats": mm_stats,
+                "parity": "goldens F14 / F14b (tests/test_deform_gpu.py): the reference's own deform('mergemesh') + write()"}
 
     def e2e_pipelined(n_scans=200, depth=4):
         """The same host-buffer work for a SEQUENCE of scans (the reference's loop over output scans): lt_hostpipe keeps
