@@ -607,6 +607,7 @@ struct lt_projector {
   float* img = nullptr;                     // lt_deform_scan_dev: [n][3][H * W] source images (range, remission, folded label)
   size_t img_cap = 0;                       // floats
   double* mm_bnds = nullptr;                // lt_mergemesh_scan_dev: [6] the kept points' bounds of the scan
+  bool bacc_armed = true;                   // false while a call that accumulates bounds has not queued its prefix pass
   std::mutex mu;
 };
 
@@ -709,7 +710,13 @@ extern "C" int lt_projector_create(lt_projector** pj, int device) {
   }
   unsigned long long arm[LT_PB_MAX * 6];
   for (int k = 0; k < LT_PB_MAX * 6; ++k) arm[k] = (k & 1) ? 0ull : ~0ull;
-  LT_HIP(hipMemcpy(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice));
+  if (hipMemcpy(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p->meta); (void)hipFree(p->beams); (void)hipFree(p->bacc);
+    delete p;
+    lt_set_error("lt_projector_create: arming the bounds accumulators failed");
+    return LT_ERR_HIP;
+  }
   *pj = p;
   return LT_OK;
 }
@@ -751,6 +758,16 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
   hipStream_t st = (hipStream_t)stream;
   const bool old_f64 = is_f64 && !(flags & LT_PROJ_NEW);
   LT_CHECK(pj_reserve(p, n_max, (size_t)H * W, old_f64, st));
+  if (!p->bacc_armed) {  // a call that asked for bounds did not get to its prefix pass (which re-arms them): arm them here
+    bool want = false;
+    for (int k = 0; k < n_clouds; ++k) want = want || out[k].bnds;
+    if (want) {
+      unsigned long long arm[LT_PB_MAX * 6];
+      for (int k = 0; k < LT_PB_MAX * 6; ++k) arm[k] = (k & 1) ? 0ull : ~0ull;
+      LT_HIP(hipMemcpyAsync(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice, st));  // (pageable source: staged before return)
+      p->bacc_armed = true;
+    }
+  }
   p->armed = false;  // (until the resolve pass of this call has been queued)
   if (old_f64) p->dmin_armed = false;
   if (n_beams > 0 && (n_beams != p->n_beams_cached || memcmp(p->beams_host, beam_angles, n_beams * sizeof(double)) != 0)) {
@@ -779,11 +796,15 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
       need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept || o.bnds;
     }
     for (int k = A.n_clouds; k < LT_PB_MAX; ++k) { A.c[k] = A.c[0]; A.c[k].n = 0; A.c[k].block0 = 0x7fffffff; }
+    bool wants_bnds = false;
+    for (int k = 0; k < A.n_clouds; ++k) wants_bnds = wants_bnds || A.c[k].bacc;
+    if (wants_bnds) p->bacc_armed = false;  // (k_pb_prefix of this group re-arms the accumulators)
     const int rc = is_f64 ? pj_run<double>(p, A, blocks, old_f64, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
                                            color_lut, lut_len, range_init, rem_init, xyz_init, st)
                           : pj_run<float>(p, A, blocks, false, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
                                           color_lut, lut_len, range_init, rem_init, xyz_init, st);
     if (rc != LT_OK) return rc;
+    if (wants_bnds) p->bacc_armed = true;
   }
   p->armed = true;  // k_pb_resolve re-armed every cell it looked at
   if (old_f64) p->dmin_armed = true;

@@ -1981,6 +1981,10 @@ extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const fl
     lt_set_error("lt_tsdf_integrate_dev: invalid argument");
     return LT_ERR_INVALID_ARG;
   }
+  if ((flags & LT_TSDF_HOST_MODE) && (flags & LT_TSDF_MERGE)) {  // (the numpy branch has no class-aware update: lidarhip.h)
+    lt_set_error("lt_tsdf_integrate_dev: LT_TSDF_HOST_MODE excludes LT_TSDF_MERGE");
+    return LT_ERR_INVALID_ARG;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   LT_HIP(hipSetDevice(t->device));
   // other_params[6] * PI / 180.0 in double, stored to float (fusion_lidar.py:124-125); the launch passes the

@@ -345,3 +345,22 @@ def test_fused_observations_equal_one_integrate_per_observation(fu, fd, voxel, h
             assert int((a[0] < 0).sum()) > 1000 and int((a[1] > 1.5).sum()) > 1000, "the observations did not overlap"
             seq.reset(); fused.reset()
     seq.close(); fused.close()
+
+
+def test_host_mode_and_merge_flags_exclude_each_other():
+    """include/lidarhip.h: LT_TSDF_HOST_MODE (the reference's numpy branch) has no class-aware update -- both flags at once
+    are an argument error, not a silent choice."""
+    import ctypes as C
+    import torch
+    from lidar_transfer_amd import _lib
+    from lidar_transfer_amd.fusion import TSDFVolume
+    vol = TSDFVolume(np.array([[-2.0, 2.0], [-2.0, 2.0], [-1.0, 1.0]]), 0.1, 3.0, -25.0)
+    im = torch.zeros((16, 64), device="cuda")
+    lib = _lib.load()
+    rc = lib.lt_tsdf_integrate_dev(vol._h, im.data_ptr(), im.data_ptr(), im.data_ptr(), 16, 64, 1.0,
+                                   _lib.LT_TSDF_HOST_MODE | _lib.LT_TSDF_MERGE, None)
+    assert rc == -1 and b"excludes" in lib.lt_last_error()
+    cp = (C.c_void_p * 1)(im.data_ptr())
+    rc = lib.lt_tsdf_integrate_multi_dev(vol._h, 1, cp, cp, cp, 16, 64, 1.0, _lib.LT_TSDF_HOST_MODE | _lib.LT_TSDF_MERGE, None)
+    assert rc == -1
+    vol.close()

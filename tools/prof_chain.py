@@ -30,8 +30,11 @@ for k in range(1, n_obs):
     flip = torch.rand((H, W), device=dev, generator=gen) < 0.02
     obs.append((torch.where(flip, torch.full_like(folded, 50.0 * 65536.0), folded).contiguous(),
                 torch.where(hole | (depth == 0), torch.zeros_like(depth), depth + noise).contiguous()))
+evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]   # phase marks (--phases prints their medians)
 for i in range(n):
+    evs[i][0].record()
     assert lib.lt_tsdf_reset(vol._h, sp) == 0
+    evs[i][1].record()
     if os.environ.get("LT_CHAIN_SEQUENTIAL") == "1":   # one lt_tsdf_integrate_dev per observation (rounds 1-3)
         for f_k, d_k in obs:
             assert lib.lt_tsdf_integrate_dev(vol._h, f_k.data_ptr(), d_k.data_ptr(), remi.data_ptr(), H, W, 1.0, 1, sp) == 0
@@ -40,13 +43,24 @@ for i in range(n):
         assert lib.lt_tsdf_integrate_multi_dev(vol._h, len(obs), vpn(*[f_k.data_ptr() for f_k, _ in obs]),
                                                vpn(*[d_k.data_ptr() for _, d_k in obs]), vpn(*[remi.data_ptr()] * len(obs)),
                                                H, W, 1.0, 1, sp) == 0
+    evs[i][2].record()
     assert lib.lt_tsdf_extract_mesh_dev(vol._h, mesh._h, sp, None) == 0
+    evs[i][3].record()
     assert lib.lt_scene_set_mesh(sc._h, mesh._h) == 0
     assert lib.lt_scene_render_dev(sc._h, rs._h, org, o["endpoints"].data_ptr(), o["endcolors"].data_ptr(), o["range"].data_ptr(),
                                    o["endrem"].data_ptr(), o["tri"].data_ptr(), 1, sp, None) == 0
+    evs[i][4].record()
 torch.cuda.synchronize()
 dirty = None
 print("verts", mesh.n_verts, "faces", mesh.n_faces)
+if "--phases" in sys.argv:
+    import hashlib, json
+    ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(4)] for e in evs[2:]])
+    v, f, c, r = mesh.tensors()
+    sha = hashlib.sha256(v.cpu().numpy().tobytes() + f.cpu().numpy().tobytes() + c.cpu().numpy().tobytes() + r.cpu().numpy().tobytes()).hexdigest()[:16]
+    print(json.dumps({"phase_ms_median": dict(zip(("reset", "integrate", "marching_cubes", "render"), [round(float(x), 4) for x in np.median(ms, axis=0)])),
+                      "mc_min": round(float(ms[:, 2].min()), 4), "mesh_sha": sha, "range_sha": hashlib.sha256(o["range"].cpu().numpy().tobytes()).hexdigest()[:16],
+                      "env": {k: v_ for k, v_ in os.environ.items() if k.startswith("LIDARHIP_MC")}}))
 if os.environ.get("LIDARHIP_DEBUG_TSDF"):
     c3 = (C.c_ulonglong * 8)()
     if lib.lt_debug_tsdf_pix_counts(c3) == 0:
