@@ -415,26 +415,28 @@ def main():
     if rank == 0:
         bl.count_work(hz, (args.strategy,))
         n_scans = len(hz.job) if hz.job else world * hz.K
+        xport = "RCCL" if (hz.dist.is_initialized() and hz.dist.get_backend() == "nccl") else "gloo (host transport)"
         value = n_scans * R / dt / 1e6
-        step_s = dt / args.steps
+        steps = 1 if hz.job else args.steps   # (a --job is one pass over its scan list)
+        step_s = dt / steps
         out = {
             "metric": "Mrays/sec, one new ~1M-triangle mesh per scan -> 64x2048 range/label image",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "strong" if hz.job else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {hz.H}x{hz.W} rays vs {hz.n_faces}-triangle synthetic scene (fov "
                                    f"{hz.wl['fov_up']}/{hz.wl['fov_down']}); 1 step = {hz.SPS} scans, each a new mesh; "
                                    f"{len(hz.scenes)} scenes cycled",
-                       "scans_per_step": hz.SPS, "ms_per_scan": round(dt / hz.K * 1e3, 5), "strategy": args.strategy,
+                       "scans_per_step": n_scans if hz.job else hz.SPS, "ms_per_scan": round(dt / max(n_scans, 1) * world * 1e3, 5), "strategy": args.strategy,
                        "parallelism": f"scan-parallel x{world}" + ("" if not hz.dist.is_initialized() else (
-                           ", images stay sharded on the ranks that rendered them, per-scan metadata gathered to rank 0 over RCCL"
+                           f", images stay sharded on the ranks that rendered them, per-scan metadata gathered to rank 0 over {xport}"
                            if hz.gather_info.get("mode") == "sharded" else
-                           ", range f32 + label images gathered to rank 0 over RCCL inside the timed region")),
+                           f", range f32 + label images gathered to rank 0 over {xport} inside the timed region")),
                        "gather": hz.gather_info or None,
                        "job": args.job or None, "scans_in_flight": hz.S, "scans_per_call": args.batch if args.strategy == "scatter" else 1},
             "scans_per_s": round(n_scans / dt, 2), "hit_fraction": round(hits / R, 4),
             "verified": bool(verify and verify["ok"]), "verification": verify,
-            "roofline": bl.roofline_compact(hz, args.strategy, ser_ms, kern_ms, step_s),
+            "roofline": bl.roofline_compact(hz, args.strategy, ser_ms, kern_ms, None if hz.job else step_s),
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             try:

@@ -220,3 +220,35 @@ def deform_mesh_clouds(seed, n_scans, src, render):
         rm = np.concatenate([rem0[keep], [0.5]]).astype(np.float32)
         scans.append((np.ascontiguousarray(p), rm, lb))
     return scans
+
+
+# ---- golden F14c (tests/golden/make_golden_mergemesh_seq.py): SEQUENCES of mergemesh output scans on one bounds array ----------
+N_MERGEMESH_SEQ_CASES = 4
+MERGEMESH_SEQ_LEN = 6
+
+
+def mergemesh_seq_case(k):
+    """(source, target, vol_bnds [3,2] ints or floats, voxel, scene seed, crop limits per scan): six output scans in a row on ONE
+    bounds array (laserscan.py:957-962 clips it scan after scan; fusion_lidar.py:36 rewrites its upper bounds); the clouds are
+    cropped by limits that move in and out again, so the bounds shrink at several scans and then stay (they never grow)."""
+    rng = np.random.default_rng(9100 + k)
+    src = (int(rng.choice([16, 24, 32])), int(rng.choice([256, 360, 512])), float(rng.choice([3.0, 10.0])),
+           -float(rng.choice([20.0, 25.0])))
+    tgt = src if k % 2 == 0 else (int(rng.choice([16, 32])), int(rng.choice([256, 500])), float(rng.choice([2.0, 10.0])),
+                                  -float(rng.choice([25.0, 30.0])))
+    voxel = float([0.1, 0.2, 0.25, 0.1][k])
+    ext = 10 if voxel < 0.2 else 12
+    bnds = np.array([[-ext, ext], [-ext + 1, ext], [-3, 3]])
+    if k >= 2:
+        bnds = bnds.astype(np.float64) + (0.0 if k == 2 else 0.13)   # (floats; k == 3: not on the voxel lattice)
+    seed = int(rng.integers(100, 10000))
+    # per scan: (x_max, y_min) the cloud is cropped to -- moving in, out again (the bounds must NOT follow), further in
+    limits = [(9.4, -9.6), (7.4, -9.6), (8.6, -6.6), (7.4, -6.6), (5.6, -7.4), (5.6, -4.4)]
+    return src, tgt, bnds, voxel, seed, limits
+
+
+def mergemesh_seq_clouds(seed, src, render, limit):
+    """the one source scan of a sequence's output scan: deform_mesh_clouds' first scan, cropped to x < limit[0], y > limit[1]"""
+    p, rm, lb = deform_mesh_clouds(seed, 1, src, render)[0]
+    keep = (p[:, 0] < limit[0]) & (p[:, 1] > limit[1])
+    return [(np.ascontiguousarray(p[keep]), np.ascontiguousarray(rm[keep]), np.ascontiguousarray(lb[keep]))]

@@ -638,3 +638,94 @@ def test_mergemesh_composed_from_the_public_steps_equals_the_one_call_scan():
         assert got["source"]["range"].shape == (32, 512) and tuple(got["source"]["bnds"].shape) == (3, 2)
     assert dd._mm_state.stats == stats and b2.dtype == np.float64
     dd.close()
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_mergemesh_sequences_equal_the_references_own_runs(pipelined):
+    """Golden F14c (tests/golden/make_golden_mergemesh_seq.py): the reference's `deform('mergemesh')` + `write()` for SIX output
+    scans in a row on ONE bounds array, four configurations (integer / float bounds, on and off the voxel lattice -- incl. the
+    case in which fusion_lidar.py:36 GROWS an upper bound by an ulp), clouds cropped by limits that move in and out again.  The
+    bounds statements now run on the device (lt_mergemesh.hip) and the chain is launched on the previous scan's geometry: every
+    scan's volume dimensions and the bounds array afterwards must equal the reference's exactly, its bytes as F13b / F14b
+    (SHA-256, or -- a voxel on a pixel boundary -- within 1e-4 m / no label); one scan at a time (with the packed files) and
+    with three scans in flight (FusionScanPipeline.submit_mergemesh: images only)."""
+    import torch
+    import pin_cases
+    from lidar_transfer_amd.deform import DeviceDeform
+    from lidar_transfer_amd.laserscan import create_rays, create_rays_device
+    from lidar_transfer_amd.pipeline import FusionScanPipeline
+    from lidar_transfer_amd.raytracer import RaySet, Scene
+    g = _gold("f14c_mergemesh_seq.npz")
+
+    def render(v, f, c, r, H, W, fu, fd):
+        sc = Scene(0)
+        sc.set_mesh(*[torch.from_numpy(x).cuda() for x in (v, f, c, r)])
+        rs = RaySet(torch.from_numpy(create_rays(fu, fd, H, W)).cuda(), H)
+        o = sc.render(rs, (0.0, 0.0, 0.0))
+        torch.cuda.synchronize()
+        res = (o["endpoints"].cpu().numpy(), o["endcolors"].cpu().numpy().reshape(-1, 3)[:, 2], o["endrem"].cpu().numpy(),
+               o["range"].cpu().numpy())
+        rs.close(); sc.close()
+        return res
+
+    exact, inexact, reruns = 0, [], 0
+    for k in range(int(g["n_cases"])):
+        src, tgt, bnds, voxel, seed, limits = pin_cases.mergemesh_seq_case(k)
+        bnds = bnds.copy()
+        dev = []
+        for step, lim in enumerate(limits):
+            clouds = pin_cases.mergemesh_seq_clouds(seed, src, render, lim)
+            assert _sha(np.concatenate([c[0].reshape(-1) for c in clouds])) == str(g[f"q{k}s{step}_cloud_sha"])
+            dev.append([(torch.from_numpy(p).cuda(), torch.from_numpy(r).cuda(), torch.from_numpy(l.astype(np.int32)).cuda())
+                        for p, r, l in clouds])
+        results = []
+        if pipelined:
+            rays = create_rays_device(tgt[2], tgt[3], tgt[0], tgt[1], device=0)
+            with FusionScanPipeline(bnds, voxel, tgt[2], tgt[3], rays, tgt[0], chains=3, device=0, label_image=True,
+                                    source_hw=(src[0], src[1]), fixed_volume=False) as pipe:
+                # (numpy fusion mode is DeviceDeform's `fusion`: the pipeline's chains run the reference's CUDA-kernel arithmetic,
+                # whose image differs from the numpy-mode golden by design -- geometry and bounds do not depend on the mode)
+                for t in [pipe.submit_mergemesh(c, inputs_ready=True) for c in dev]:
+                    got = pipe.wait(t)
+                    results.append(dict(vol_dim=got["vol_dim"], after=got["vol_bnds_after"], range=None))
+                reruns += pipe._mm_state.stats["rerun"]
+                final = bnds.copy()
+        else:
+            dd = DeviceDeform(src, tgt, bnds, voxel, fusion="numpy", mesh_volume=False)
+            for c in dev:
+                got = dd.mergemesh(c)
+                torch.cuda.synchronize()
+                results.append(dict(vol_dim=got["vol_dim"], after=got["vol_bnds_after"], range=got["range"].cpu().numpy(),
+                                    label=got["label"].cpu().numpy(), bin=got["bin"].cpu().numpy(),
+                                    label_file=got["label_file"].cpu().numpy(), n_faces=got["n_faces"], bnds=bnds.copy()))
+            reruns += dd._mm_state.stats["rerun"]
+            assert dd._mm_state.stats["waited"] == 1
+            dd.close()
+            final = bnds.copy()
+        for step, res in enumerate(results):
+            tag = f"q{k}s{step}"
+            assert tuple(res["vol_dim"]) == tuple(int(x) for x in g[f"{tag}_vol_dim"]), tag
+            assert np.array_equal(np.array(res["after"]).reshape(3, 2), g[f"{tag}_bnds_after"].astype(np.float64)), tag
+            if res["range"] is None:
+                continue
+            assert np.array_equal(res["bnds"], g[f"{tag}_bnds_after"]) and res["bnds"].dtype == g[f"{tag}_bnds_after"].dtype, tag
+            have = [_sha(res["bin"]), _sha(res["label_file"]), _sha(res["range"]), _sha(res["label"])]
+            n_written, n_faces, n_points, n_hit = [int(x) for x in g[f"{tag}_counts"]]
+            dpix = int((res["range"].view(np.int32) != g[f"{tag}_range"].view(np.int32)).sum())
+            dlab = int((res["label"] != g[f"{tag}_limg"].astype(np.int32)).sum())
+            dmax = float(np.abs(res["range"] - g[f"{tag}_range"]).max())
+            if have == [str(x) for x in g[f"{tag}_sha"]] and res["n_faces"] == n_faces:
+                exact += 1
+                assert dpix == 0 and dlab == 0
+            else:
+                inexact.append((tag, res["n_faces"] - n_faces, dpix, dlab, dmax))
+        last = f"q{k}s{len(limits) - 1}"
+        assert np.array_equal(final, g[f"{last}_bnds_after"]) and final.dtype == g[f"{last}_bnds_after"].dtype
+    # the bounds move at 2-4 scans of every sequence: those scans were launched on the old geometry and run again (with scans in
+    # flight the first three of a sequence have nothing to assume and wait instead)
+    assert reruns >= (4 if pipelined else 8)
+    if not pipelined:
+        print(f"\nF14c: {exact} of 24 output scans reproduced to the byte; others: {inexact}")
+        assert exact >= 22 and len(inexact) <= 2
+        for tag, dfaces, dpix, dlab, dmax in inexact:
+            assert dmax <= 1e-4 and dlab == 0 and dpix <= 16 and abs(dfaces) <= 64, (tag, dfaces, dpix, dlab, dmax)
