@@ -400,7 +400,8 @@ struct pb_cloud {
   int* meta;                     // [2] number of kept points, original index of the last kept point (-1: none)
   int* idx_img; float* range_img; float* xyz_img; float* rem_img; int* label_img; float* color_img; float* mask_img;
   float* fold_img; int* px_img; int* py_img; void* xf_img; void* yf_img; int* n_kept;
-  unsigned long long* bacc;      // [6] order-preserving keys of the kept points' bounds (min x, max x, min y, ...); NULL: not wanted
+  unsigned long long* bacc;      // [blocks of the cloud][6] per-WORKGROUP order-preserving keys of the kept points' bounds (min x,
+                                 // max x, min y, ...), written by k_pb_project, folded by k_pb_prefix / k_pb_bnds; NULL: not wanted
   double* bnds_out;              // [6] get_bnds() of the kept points (laserscan.py:678-681), written by k_pb_prefix
 };
 struct pb_args { pb_cloud c[LT_PB_MAX]; int n_clouds; };
@@ -455,7 +456,10 @@ __global__ __launch_bounds__(256) void k_pb_project(pb_args A, T pi_t, T abs_fov
   }
   const unsigned long long m = __ballot(keep);
   if ((threadIdx.x & 63) == 0 && i < c.n) c.keep[i >> 6] = m;
-  if (c.bacc && m) {  // (wave-uniform) bounds of the kept points: SemLaserScan.get_bnds after remove_points (laserscan.py:678-681)
+  if (c.bacc) {  // bounds of the kept points: SemLaserScan.get_bnds after remove_points (laserscan.py:678-681)
+    // Per WORKGROUP, no atomics: six shared words for the whole cloud were 2 000 memory-side atomics in a row per word (150 us
+    // for a 130 k-point cloud), and even LOOKING at them first (a load per wave on six hot addresses) cost 25 us.
+    __shared__ unsigned long long s_b[4][6];
     const T* pts = (const T*)c.pts;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -467,13 +471,43 @@ __global__ __launch_bounds__(256) void k_pb_project(pb_args A, T pi_t, T abs_fov
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
       }
-      if ((threadIdx.x & 63) == 0) {
-        // Six words for the whole cloud: an atomic per wave on them is 2 000 memory-side atomics in a row per word (150 us for
-        // a 130 k-point cloud, measured).  The bounds only move outwards, so a wave first LOOKS: a value it cannot improve
-        // needs no atomic -- a stale look shows an older, i.e. less extreme, bound and costs one atomic too many at worst.
-        if (lo < __hip_atomic_load(&c.bacc[2 * a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&c.bacc[2 * a], lo);
-        if (hi > __hip_atomic_load(&c.bacc[2 * a + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&c.bacc[2 * a + 1], hi);
+      if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6][2 * a] = lo; s_b[threadIdx.x >> 6][2 * a + 1] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      unsigned long long v = s_b[0][threadIdx.x];
+      for (int w = 1; w < 4; ++w) {
+        const unsigned long long o = s_b[w][threadIdx.x];
+        v = (threadIdx.x & 1) ? (o > v ? o : v) : (o < v ? o : v);
       }
+      c.bacc[6 * (size_t)(blockIdx.x - c.block0) + threadIdx.x] = v;
+    }
+  }
+}
+
+// fold the workgroups' partial bounds of a cloud (all 64 lanes of one wave help); lane k < 6 writes word k
+__device__ __forceinline__ void pb_fold_bounds(const pb_cloud& c, int lane) {
+  const int nb = (c.n + 255) >> 8;
+  unsigned long long v[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = (k & 1) ? 0ull : ~0ull;
+  for (int b = lane; b < nb; b += 64)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned long long o = c.bacc[6 * (size_t)b + k];
+      v[k] = (k & 1) ? (o > v[k] ? o : v[k]) : (o < v[k] ? o : v[k]);
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long x = __shfl_xor(v[k], o);
+      v[k] = (k & 1) ? (x > v[k] ? x : v[k]) : (x < v[k] ? x : v[k]);
+    }
+    if (lane == k) {  // no kept point: (+inf, -inf) -- numpy's amin of an empty array raises
+      const bool is_min = (k & 1) == 0;
+      const bool none = is_min ? v[k] == ~0ull : v[k] == 0ull;
+      c.bnds_out[k] = none ? (is_min ? (double)INFINITY : -(double)INFINITY) : pb_unord(v[k]);
     }
   }
 }
@@ -529,13 +563,13 @@ __global__ __launch_bounds__(256) void k_pb_prefix(pb_args A) {
     c.meta[1] = last_s;
     if (c.n_kept) *c.n_kept = part[255];
   }
-  if (c.bacc && threadIdx.x < 6) {  // no kept point: (+inf, -inf) -- numpy's amin of an empty array raises
-    const unsigned long long k = c.bacc[threadIdx.x];
-    const bool is_min = (threadIdx.x & 1) == 0;
-    const bool none = is_min ? k == ~0ull : k == 0ull;
-    c.bnds_out[threadIdx.x] = none ? (is_min ? (double)INFINITY : -(double)INFINITY) : pb_unord(k);
-    c.bacc[threadIdx.x] = is_min ? ~0ull : 0ull;
-  }
+  if (c.bacc && threadIdx.x < 64) pb_fold_bounds(c, threadIdx.x);
+}
+
+// the bounds alone (no image wants the kept points' prefix): one thread per word, one workgroup per cloud
+__global__ __launch_bounds__(64) void k_pb_bnds(pb_args A) {
+  const pb_cloud& c = A.c[blockIdx.x];
+  if (c.bacc) pb_fold_bounds(c, threadIdx.x);
 }
 
 template <typename T, int MODE>
@@ -603,11 +637,11 @@ struct lt_projector {
   double* beams = nullptr;                  // [1024]
   double beams_host[1024];
   int n_beams_cached = -1;
-  unsigned long long* bacc = nullptr;       // [LT_PB_MAX][6] bounds accumulators, armed (min: ~0, max: 0); re-armed by k_pb_prefix
+  unsigned long long* bacc = nullptr;       // [LT_PB_MAX][bacc_blocks][6] per-workgroup partial bounds of the clouds (no arming: every
+  size_t bacc_blocks = 0;                   // workgroup of k_pb_project writes its six words)
   float* img = nullptr;                     // lt_deform_scan_dev: [n][3][H * W] source images (range, remission, folded label)
   size_t img_cap = 0;                       // floats
   double* mm_bnds = nullptr;                // lt_mergemesh_scan_dev: [6] the kept points' bounds of the scan
-  bool bacc_armed = true;                   // false while a call that accumulates bounds has not queued its prefix pass
   std::mutex mu;
 };
 
@@ -651,7 +685,7 @@ int pj_reserve(lt_projector* p, size_t n_max, size_t cells, bool need_dmin, hipS
 }
 
 template <typename T>
-int pj_run(lt_projector* p, pb_args& A, int total_blocks, bool old_f64, bool need_prefix, double fov_up_deg,
+int pj_run(lt_projector* p, pb_args& A, int total_blocks, bool old_f64, bool need_prefix, bool bnds_only, double fov_up_deg,
            double fov_down_deg, int H, int W, int n_beams, unsigned flags, const float* lut, int lut_len, float range_init,
            float rem_init, float xyz_init, hipStream_t st) {
   const double fu = fov_up_deg / 180.0 * M_PI, fd = fov_down_deg / 180.0 * M_PI;
@@ -670,6 +704,7 @@ int pj_run(lt_projector* p, pb_args& A, int total_blocks, bool old_f64, bool nee
     }
   }
   if (need_prefix) hipLaunchKernelGGL(k_pb_prefix, dim3(A.n_clouds), dim3(256), 0, st, A);
+  else if (bnds_only) hipLaunchKernelGGL(k_pb_bnds, dim3(A.n_clouds), dim3(64), 0, st, A);
   if (old_f64)
     hipLaunchKernelGGL((k_pb_resolve<T, 1>), dim3(bpc * A.n_clouds), dim3(256), 0, st, A, bpc, (T)M_PI, (T)fabs(fd), (T)fov,
                        H, W, (const double*)p->beams, n_beams, drop_zero, drop_outside, lut, lut_len, range_init, rem_init,
@@ -699,23 +734,13 @@ extern "C" int lt_projector_create(lt_projector** pj, int device) {
   }
   p->device = dev;
   if (hipMalloc((void**)&p->meta, LT_PB_MAX * 2 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&p->beams, 1024 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&p->bacc, LT_PB_MAX * 6 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void**)&p->beams, 1024 * sizeof(double)) != hipSuccess) {
     if (p->meta) (void)hipFree(p->meta);
     if (p->beams) (void)hipFree(p->beams);
     delete p;
     (void)hipGetLastError();
     lt_set_error("lt_projector_create: out of device memory");
     return LT_ERR_NO_MEMORY;
-  }
-  unsigned long long arm[LT_PB_MAX * 6];
-  for (int k = 0; k < LT_PB_MAX * 6; ++k) arm[k] = (k & 1) ? 0ull : ~0ull;
-  if (hipMemcpy(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(p->meta); (void)hipFree(p->beams); (void)hipFree(p->bacc);
-    delete p;
-    lt_set_error("lt_projector_create: arming the bounds accumulators failed");
-    return LT_ERR_HIP;
   }
   *pj = p;
   return LT_OK;
@@ -758,14 +783,15 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
   hipStream_t st = (hipStream_t)stream;
   const bool old_f64 = is_f64 && !(flags & LT_PROJ_NEW);
   LT_CHECK(pj_reserve(p, n_max, (size_t)H * W, old_f64, st));
-  if (!p->bacc_armed) {  // a call that asked for bounds did not get to its prefix pass (which re-arms them): arm them here
+  {  // the per-workgroup partial bounds of the clouds that want get_bnds()
     bool want = false;
     for (int k = 0; k < n_clouds; ++k) want = want || out[k].bnds;
-    if (want) {
-      unsigned long long arm[LT_PB_MAX * 6];
-      for (int k = 0; k < LT_PB_MAX * 6; ++k) arm[k] = (k & 1) ? 0ull : ~0ull;
-      LT_HIP(hipMemcpyAsync(p->bacc, arm, sizeof(arm), hipMemcpyHostToDevice, st));  // (pageable source: staged before return)
-      p->bacc_armed = true;
+    const size_t nb = n_max / 256 + 2;
+    if (want && nb > p->bacc_blocks) {
+      if (p->bacc) { LT_HIP(hipStreamSynchronize(st)); (void)hipFree(p->bacc); p->bacc = nullptr; p->bacc_blocks = 0; }
+      const size_t cap = nb + nb / 4 + 64;
+      LT_HIP(hipMalloc((void**)&p->bacc, LT_PB_MAX * cap * 6 * sizeof(unsigned long long)));
+      p->bacc_blocks = cap;
     }
   }
   p->armed = false;  // (until the resolve pass of this call has been queued)
@@ -792,19 +818,17 @@ extern "C" int lt_range_projection_batch_dev(lt_projector* p, int n_clouds, cons
       c.idx_img = o.idx; c.range_img = o.range; c.xyz_img = o.xyz; c.rem_img = o.rem; c.label_img = o.label;
       c.color_img = o.color; c.mask_img = o.mask; c.fold_img = o.label_folded; c.px_img = o.proj_x; c.py_img = o.proj_y;
       c.xf_img = o.proj_xf; c.yf_img = o.proj_yf; c.n_kept = o.n_kept;
-      c.bacc = o.bnds ? p->bacc + 6 * k : nullptr; c.bnds_out = o.bnds;
-      need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept || o.bnds;
+      c.bacc = o.bnds ? p->bacc + 6 * p->bacc_blocks * k : nullptr; c.bnds_out = o.bnds;
+      need_prefix = need_prefix || o.idx || o.mask || o.proj_x || o.proj_y || o.proj_xf || o.proj_yf || o.n_kept;
     }
     for (int k = A.n_clouds; k < LT_PB_MAX; ++k) { A.c[k] = A.c[0]; A.c[k].n = 0; A.c[k].block0 = 0x7fffffff; }
     bool wants_bnds = false;
     for (int k = 0; k < A.n_clouds; ++k) wants_bnds = wants_bnds || A.c[k].bacc;
-    if (wants_bnds) p->bacc_armed = false;  // (k_pb_prefix of this group re-arms the accumulators)
-    const int rc = is_f64 ? pj_run<double>(p, A, blocks, old_f64, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
+    const int rc = is_f64 ? pj_run<double>(p, A, blocks, old_f64, need_prefix, wants_bnds, fov_up, fov_down, H, W, n_beams, flags,
                                            color_lut, lut_len, range_init, rem_init, xyz_init, st)
-                          : pj_run<float>(p, A, blocks, false, need_prefix, fov_up, fov_down, H, W, n_beams, flags,
+                          : pj_run<float>(p, A, blocks, false, need_prefix, wants_bnds, fov_up, fov_down, H, W, n_beams, flags,
                                           color_lut, lut_len, range_init, rem_init, xyz_init, st);
     if (rc != LT_OK) return rc;
-    if (wants_bnds) p->bacc_armed = true;
   }
   p->armed = true;  // k_pb_resolve re-armed every cell it looked at
   if (old_f64) p->dmin_armed = true;
