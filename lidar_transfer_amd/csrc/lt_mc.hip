@@ -173,10 +173,16 @@ __device__ __forceinline__ unsigned lw_cell_eval(const float* __restrict__ c, si
 // triangles; k_mc_amb evaluates the queue -- one lane per cell --, adds the cell's triangles / centre vertex to the counts
 // of its word and of its block (atomics: the one place of the extraction that has them; the RESULT does not depend on their
 // order), and files the tiling under the voxel index in an open-addressing table that k_mc_emit_batch reads.
+// The queue is SHARDED: 64 segments of `cap` entries, a counter each in a 128-byte line of its own; a block of k_mc_words
+// appends to segment (block & 63).  One counter for all took ~5 000 returning atomics in a row on one address -- 10 of
+// k_mc_words' 43 us (measured by taking the atomic out); the order of the queue does not reach the output.
+#define LT_MC_SHARDS 64
+#define LT_MC_CTR_STRIDE 32  // ints between two shards' counters
 struct mc_amb {
-  uint2* queue;      // [cap]: (voxel index, case | block << 8)
-  int* counter;      // [0]: cells queued (may exceed cap: the host then grows the buffers and starts over)
-  uint2* table;      // [tcap], tcap a power of two >= 4 cap: (voxel index + 1, tiling); 0 = empty
+  uint2* queue;      // [LT_MC_SHARDS][cap]: (voxel index, case | block << 8)
+  int* counter;      // [LT_MC_SHARDS * LT_MC_CTR_STRIDE]: cells queued per shard (may exceed cap: the host then grows the
+                     // buffers and starts over), then [LT_MC_SHARDS] the counts of the LAST extraction (k_mc_clear)
+  uint2* table;      // [tcap], tcap a power of two >= 4 x LT_MC_SHARDS x cap: (voxel index + 1, tiling); 0 = empty
   unsigned cap, tmask;
 };
 __device__ __forceinline__ unsigned amb_slot(unsigned i, unsigned tmask) { return (i * 2654435761u) & tmask; }
@@ -467,8 +473,9 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
       const int slot = atomicAdd(&s_qn[wv], 1);  // (LDS)
       if (slot < LT_MC_QW) s_q[wv][slot] = e;
       else {  // (more than the buffer holds in one block of rows: straight to the queue)
-        const unsigned pos = (unsigned)atomicAdd(A.counter, 1);
-        if (pos < A.cap) A.queue[pos] = e;
+        const unsigned sh = (unsigned)blkid & (LT_MC_SHARDS - 1);
+        const unsigned pos = (unsigned)atomicAdd(A.counter + sh * LT_MC_CTR_STRIDE, 1);
+        if (pos < A.cap) A.queue[(size_t)sh * A.cap + pos] = e;
       }
       return 0u;
     };
@@ -555,10 +562,11 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
     const int nq = min(s_qn[wv], LT_MC_QW);  // (wave-uniform)
     if (nq > 0) {
       unsigned base = 0;
-      if (lane == 0) base = (unsigned)atomicAdd(A.counter, nq);
+      const unsigned sh = (unsigned)blkid & (LT_MC_SHARDS - 1);
+      if (lane == 0) base = (unsigned)atomicAdd(A.counter + sh * LT_MC_CTR_STRIDE, nq);
       base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
       for (int j = lane; j < nq; j += 64)
-        if (base + (unsigned)j < A.cap) A.queue[base + j] = s_q[wv][j];
+        if (base + (unsigned)j < A.cap) A.queue[(size_t)sh * A.cap + base + j] = s_q[wv][j];
     }
   }
   u64 p = pack3(na, nv, nt);  // (20 bits each: 64 rows x wz words x <= 768 triangles -- the host checks wz)
@@ -577,21 +585,24 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
 // ---- k_mc_amb: the queued ambiguous cells, one lane each ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, mc_dims D, mc_amb A, unsigned* __restrict__ cnt,
                                                 int* __restrict__ blk, int* __restrict__ wave_na) {
-  const unsigned n = min((unsigned)A.counter[0], A.cap);
+  // workgroup g: shard g % 64, its chunks of 256 cells g / 64, g / 64 + gridDim / 64, ...
+  const unsigned sh = blockIdx.x & (LT_MC_SHARDS - 1), per = max(gridDim.x / LT_MC_SHARDS, 1u);
+  const unsigned n = min((unsigned)A.counter[sh * LT_MC_CTR_STRIDE], A.cap);
+  const uint2* __restrict__ queue = A.queue + (size_t)sh * A.cap;
   const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
   // a workgroup takes 256 queued cells and deals them to its lanes SORTED by Lewiner's case (counting sort in LDS): the seven
   // ambiguous cases run different tests, and a wave pays for every case its lanes hold
   __shared__ uint2 s_e[256];
   __shared__ int s_n[16], s_o[16];
   const int tid = threadIdx.x;
-  for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {  // (workgroup-uniform)
+  for (unsigned base = (blockIdx.x / LT_MC_SHARDS) * 256; base < n; base += per * 256) {  // (workgroup-uniform)
     if (tid < 16) s_n[tid] = 0;
     __syncthreads();
     const bool valid = base + tid < n;
     uint2 e0 = make_uint2(0u, 0u);
     int bucket = 0, rank = 0;
     if (valid) {
-      e0 = A.queue[base + tid];
+      e0 = queue[base + tid];
       bucket = LT_LWC_CASE[e0.y & 255u];  // 3, 4, 6, 7, 10, 12, 13
       rank = atomicAdd(&s_n[bucket], 1);
     }
@@ -626,8 +637,10 @@ __global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, 
 __global__ __launch_bounds__(256) void k_mc_clear(const mc_rec* __restrict__ rec, int n, unsigned* __restrict__ cnt,
                                                   int* __restrict__ cmap, mc_amb A, int n_amb) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_amb) {
-    const unsigned key = A.queue[i].x + 1u;
+  // n_amb: the largest shard's count of the last extraction; thread i < 64 n_amb looks at entry i % n_amb of shard i / n_amb
+  const int sh = n_amb > 0 ? i / n_amb : LT_MC_SHARDS, j = n_amb > 0 ? i - sh * n_amb : 0;
+  if (sh < LT_MC_SHARDS && j < A.counter[LT_MC_SHARDS * LT_MC_CTR_STRIDE + sh]) {
+    const unsigned key = A.queue[(size_t)sh * A.cap + j].x + 1u;
     unsigned h = amb_slot(key - 1u, A.tmask);
     for (unsigned tries = 0; tries <= A.tmask; ++tries, h = (h + 1) & A.tmask)  // (not stopped by slots others emptied)
       if (A.table[h].x == key) { A.table[h].x = 0u; break; }
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(256) void k_mc_scan1(int* __restrict__ blk, int n_b
 }
 
 __global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_seg, int* __restrict__ totals,
-                                                   int* __restrict__ amb_counter) {
+                                                   int* __restrict__ amb_counter, int amb_cap) {
   __shared__ long long part[3][1024];
   const int t = threadIdx.x;
   long long s[3] = {0, 0, 0};
@@ -684,11 +697,17 @@ __global__ __launch_bounds__(1024) void k_mc_scan2(int* __restrict__ seg, int n_
   }
   if (t < n_seg)
     for (int k = 0; k < 3; ++k) seg[3 * t + k] = (int)min(part[k][t] - s[k], 2147483647ll);
-  if (t == 1023) {
-    for (int k = 0; k < 3; ++k) totals[k] = (int)min(part[k][1023], 2147483647ll);
-    totals[3] = amb_counter[0];  // the ambiguous cells queued (k_mc_amb is done); re-armed for the next extraction
-    amb_counter[0] = 0;
+  if (t < 64) {  // the ambiguous cells queued per shard (k_mc_amb is done): kept for k_mc_clear, re-armed for the next extraction
+    const int c = amb_counter[t * LT_MC_CTR_STRIDE];
+    amb_counter[LT_MC_SHARDS * LT_MC_CTR_STRIDE + t] = min(c, amb_cap);
+    amb_counter[t * LT_MC_CTR_STRIDE] = 0;
+    int mx = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (t == 0) totals[3] = mx;  // the fullest shard (beyond the capacity: the host grows the buffers and starts over)
   }
+  if (t == 1023)
+    for (int k = 0; k < 3; ++k) totals[k] = (int)min(part[k][1023], 2147483647ll);
 }
 
 // ---- k_mc_compact ----------------------------------------------------------------------------------------------------
@@ -1216,11 +1235,12 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   }
   // the ambiguous cells' queue and tiling table: grown when an extraction queued more cells than fit (below)
   if (!m->amb.queue) {
-    const size_t cap = m->amb_cap ? m->amb_cap : (size_t)1 << 16;
+    const size_t cap = m->amb_cap ? m->amb_cap : (size_t)1 << 10;   // per shard
     size_t tcap = 1;
-    while (tcap < 4 * cap) tcap <<= 1;
-    if (hipMalloc((void**)&m->amb.queue, cap * sizeof(uint2)) != hipSuccess || hipMalloc((void**)&m->amb.table, tcap * sizeof(uint2)) != hipSuccess ||
-        (!m->amb.counter && hipMalloc((void**)&m->amb.counter, 4 * sizeof(int)) != hipSuccess)) {
+    while (tcap < 4 * LT_MC_SHARDS * cap) tcap <<= 1;
+    const size_t n_ctr = LT_MC_SHARDS * LT_MC_CTR_STRIDE + LT_MC_SHARDS;
+    if (hipMalloc((void**)&m->amb.queue, LT_MC_SHARDS * cap * sizeof(uint2)) != hipSuccess || hipMalloc((void**)&m->amb.table, tcap * sizeof(uint2)) != hipSuccess ||
+        (!m->amb.counter && hipMalloc((void**)&m->amb.counter, n_ctr * sizeof(int)) != hipSuccess)) {
       (void)hipGetLastError();
       (void)hipFree(m->amb.queue); (void)hipFree(m->amb.table);
       m->amb.queue = nullptr; m->amb.table = nullptr;
@@ -1230,20 +1250,20 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     m->amb_cap = cap;
     m->amb.cap = (unsigned)cap;
     m->amb.tmask = (unsigned)(tcap - 1);
-    LT_HIP(hipMemsetAsync(m->amb.counter, 0, 4 * sizeof(int), stream));
+    LT_HIP(hipMemsetAsync(m->amb.counter, 0, n_ctr * sizeof(int), stream));
     LT_HIP(hipMemsetAsync(m->amb.table, 0, tcap * sizeof(uint2), stream));
     m->n_amb_prev = 0;
   }
   if (m->state_dirty) {  // new buffers, or an extraction that did not finish: cnt = 0, cmap = -1 everywhere, once
     LT_HIP(hipMemsetAsync(m->cnt, 0, m->cap_words * sizeof(unsigned), stream));
     LT_HIP(hipMemsetAsync(m->cmap, 0xFF, m->cap_words * sizeof(int), stream));
-    LT_HIP(hipMemsetAsync(m->amb.counter, 0, 4 * sizeof(int), stream));
+    LT_HIP(hipMemsetAsync(m->amb.counter, 0, (LT_MC_SHARDS * LT_MC_CTR_STRIDE + LT_MC_SHARDS) * sizeof(int), stream));
     LT_HIP(hipMemsetAsync(m->amb.table, 0, ((size_t)m->amb.tmask + 1) * sizeof(uint2), stream));
     m->n_prev = 0;
     m->n_amb_prev = 0;
   } else if (m->n_prev > 0) {
-    hipLaunchKernelGGL(k_mc_clear, dim3((max(m->n_prev, m->n_amb_prev) + 255) / 256), dim3(256), 0, stream, m->rec, m->n_prev,
-                       m->cnt, m->cmap, m->amb, m->n_amb_prev);
+    hipLaunchKernelGGL(k_mc_clear, dim3((max(m->n_prev, LT_MC_SHARDS * m->n_amb_prev) + 255) / 256), dim3(256), 0, stream, m->rec,
+                       m->n_prev, m->cnt, m->cmap, m->amb, m->n_amb_prev);
   }
   m->state_dirty = 1;  // until this extraction has finished
   m->n_prev = 0;
@@ -1269,13 +1289,13 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   hipLaunchKernelGGL(k_mc_words, dim3(sweep_wgs), dim3(256), 0, stream, m->amb, bits, D, m->cnt, m->blk, ext_bits ? col_epoch : nullptr,
                      epoch, ext_bits ? chunk_epoch : nullptr, m->wave_na, n_blocks);
   // Lewiner's ambiguous cells (1-2 % of a street scene's): tests on their eight values, counts added, tilings filed
-  hipLaunchKernelGGL(k_mc_amb, dim3(128), dim3(256), 0, stream, tsdf, D, m->amb, m->cnt, m->blk, m->wave_na);
+  hipLaunchKernelGGL(k_mc_amb, dim3(2 * LT_MC_SHARDS), dim3(256), 0, stream, tsdf, D, m->amb, m->cnt, m->blk, m->wave_na);
   hipLaunchKernelGGL(k_mc_scan1, dim3(n_seg), dim3(256), 0, stream, m->blk, n_blocks, seg_dev);
-  hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev, m->amb.counter);
+  hipLaunchKernelGGL(k_mc_scan2, dim3(1), dim3(1024), 0, stream, seg_dev, n_seg, totals_dev, m->amb.counter, (int)m->amb.cap);
   LT_HIP(hipMemcpyAsync(m->totals_host, totals_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
   LT_HIP(hipStreamSynchronize(stream));  // the one synchronisation: the sizes of the mesh
   if ((size_t)(unsigned)m->totals_host[3] > m->amb_cap) {
-    // more ambiguous cells than the queue holds (white noise: a third of all cells): the counts above are incomplete --
+    // more ambiguous cells in a shard than its segment holds (white noise: a third of all cells): the counts above are incomplete --
     // larger buffers, and the extraction once more from the start (cnt / cmap are swept: state_dirty is still set)
     const size_t need = (size_t)(unsigned)m->totals_host[3];
     (void)hipFree(m->amb.queue); (void)hipFree(m->amb.table);
@@ -1354,7 +1374,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   m->n_verts = nv;
   m->n_faces = nf;
   m->n_prev = n_active;  // (the records k_mc_clear will undo before the next extraction)
-  m->n_amb_prev = m->totals_host[3];
+  m->n_amb_prev = m->totals_host[3];  // (the fullest shard's count: k_mc_clear's extent per shard)
   m->state_dirty = 0;
   if (ms) {
     LT_HIP(hipEventRecord(m->ev[2], stream));
