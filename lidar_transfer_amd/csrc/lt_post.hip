@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void k_compare(const int* __restrict__ src_lab
   __shared__ double red[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
   double sq = 0.0;
+  bool counted = false;
+  unsigned pair = 0u;
   if (i < n) {
     const float csum = (src_color[3 * (size_t)i] + src_color[3 * (size_t)i + 1]) + src_color[3 * (size_t)i + 2];
     int sl = src_label[i], tl = tgt_label[i];
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void k_compare(const int* __restrict__ src_lab
     if (bg) tl = 0;
     if (src_masked) src_masked[i] = sl;
     if (tgt_masked) tgt_masked[i] = tl;
-    if ((unsigned)sl < (unsigned)n_labels && (unsigned)tl < (unsigned)n_labels)
-      atomicAdd(&conf[(size_t)tl * n_labels + sl], 1ull);
+    counted = (unsigned)sl < (unsigned)n_labels && (unsigned)tl < (unsigned)n_labels;
+    pair = counted ? (unsigned)tl * (unsigned)n_labels + (unsigned)sl : 0u;
     const float sr = bg ? 0.f : src_range[i], tr = bg ? 0.f : tgt_range[i];
     const float d = sr - tr;
     const float d2 = d * d;
@@ -202,6 +204,16 @@ __global__ __launch_bounds__(256) void k_compare(const int* __restrict__ src_lab
       const float a = bg ? 0.f : src_rem[i], b = bg ? 0.f : tgt_rem[i];
       rem_diff[i] = (a - b) * (a - b);
     }
+  }
+  // the confusion matrix: an image holds a handful of label pairs, so an atomic per cell is tens of thousands of memory-side
+  // atomics in a row on the same few words (~12 ns each).  The lanes of a wave that hold the same pair count themselves with
+  // ballots; one atomic per distinct pair and wave.
+  for (unsigned long long rest = __ballot(counted); rest;) {
+    const int leader = __ffsll((long long)rest) - 1;
+    const unsigned k = (unsigned)__shfl((int)pair, leader, 64);
+    const unsigned long long same = __ballot(counted && pair == k);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&conf[k], (unsigned long long)__popcll(same));
+    rest &= ~same;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
