@@ -927,12 +927,21 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
           for (int q = 0; q < 8; ++q) m8[q] = (unsigned)(s_cm[k][q] >> (8 * seg)) & 255u;
           int c = c0, sh = 0;
           unsigned cm8 = 0;
-          for (unsigned a8 = ac8; a8; a8 &= a8 - 1u, ++c, sh += 4) {
-            const int bb = __ffs((int)a8) - 1;
+          // the tilings of the segment's (up to eight) cells: ALL table look-ups first, independent of one another -- a loop
+          // over the set bits with the look-up inside was a chain of dependent global loads, one per cell of the fullest lane
+          // (the section's 3.0 of a batch's 9.4 us, tools/mc_wave_times.py)
+          unsigned selv[8];
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) {
             unsigned cs = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
-            unsigned sel = LT_LWC_FIXED[cs];
+            selv[bb] = ((ac8 >> bb) & 1u) ? LT_LWC_FIXED[cs] : 0u;
+          }
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) {
+            if (!((ac8 >> bb) & 1u)) continue;
+            unsigned sel = selv[bb];
             if (sel == 0xFFFFFFFFu)  // an ambiguous case: the tiling k_mc_amb filed under the cell's voxel index
               sel = amb_lookup(A, (unsigned)((s_xyz[k][0] * D.ny + s_xyz[k][1]) * D.nz + s_xyz[k][2] * 64 + 8 * seg + bb));
             const unsigned nt = LW_NT(sel);
@@ -940,6 +949,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
             cm8 |= LW_C(sel) << bb;
             ntp |= nt << sh;
             tsum += (int)nt;
+            ++c; sh += 4;
           }
           if (cm8) atomicOr((unsigned long long*)&s_ccm[k], (unsigned long long)cm8 << (8 * seg));
         }
