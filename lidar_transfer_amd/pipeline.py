@@ -538,6 +538,8 @@ class FusionScanPipeline:
         ``Scene.alloc_outputs(n, label_image=True)`` returns.  The scans of ONE sequence, in order; :meth:`reset_bounds`
         between sequences.  Results additionally carry ``vol_dim`` / ``vol_origin`` / ``vol_bnds_after``."""
         torch = self._torch
+        if not self._chains:
+            raise RuntimeError("FusionScanPipeline.submit_mergemesh: the pipeline is closed")
         if self._src_hw is None:
             raise RuntimeError("FusionScanPipeline.submit_mergemesh: construct with source_hw=(H, W)")
         if not self.label_image:
