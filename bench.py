@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 PROBE_EVERY = int(os.environ.get("LT_BENCH_PROBE_EVERY", "8"))  # HIP-event pair around every n-th dominant launch
+RAMP_MS = float(os.environ.get("LT_BENCH_RAMP_MS", "80"))  # least GPU work before the clock (the chip's ramp to its sustained rate)
 MAX_LINE_BYTES = 8000   # the driver parses ONE stdout line; round 5's 21.6 KB line was not parsed
 
 
@@ -154,7 +155,7 @@ class Harness:
         torch.cuda.synchronize()
         self.raysets = [self.shared_rays] * S
         self.scratch = [self.workers[0].alloc_outputs(R) for _ in range(S)]
-        self.gather_info = {}
+        self.gather_info, self.ramp_info = {}, None
         self.cnt = None
 
     def close(self):
@@ -282,11 +283,21 @@ class Harness:
                 works.extend(gather_to_root(src, recv[c][k] if rank == 0 else None, dst=0, copy_self=False))
 
         torch.cuda.synchronize()
-        t_w = time.perf_counter()
+        t0w = t_w = time.perf_counter()
         for i in range(0, Wm, BATCH):
             step_batch(i, min(BATCH, Wm - i)) if BATCH > 1 else step(i)
         torch.cuda.synchronize()
         t_w = time.perf_counter() - t_w
+        # the chip needs ~30 ms under load before it runs at its sustained rate (profiles/r06/steps_sweep2.txt: the same
+        # 20 timed steps read 10.3 Grays/s behind 4 ms of warm-up, 11.5 behind 30 ms): the W warm-up steps asked for are
+        # extended to RAMP_MS of GPU work -- untimed like them, counted in config.warmup_ramp
+        n_ramp = 0
+        if Wm > 0 and RAMP_MS > 0 and t_w * 1e3 < RAMP_MS:
+            n_ramp = int(np.ceil((RAMP_MS * 1e-3 - t_w) * Wm / max(t_w, 1e-6) / BATCH)) * BATCH
+            for i in range(Wm, Wm + n_ramp, BATCH):
+                step_batch(i, BATCH) if BATCH > 1 else step(i)
+            torch.cuda.synchronize()
+        self.ramp_info = {"min_ms": RAMP_MS, "scans": n_ramp, "ms": round((time.perf_counter() - t0w) * 1e3, 1)}
         if do_gather:
             # what the links sustain (MEASURED with all peers sending at once, before the clock) against what the ranks produce
             # (the slowest rank's warm-up rate): LT_BENCH_GATHER=auto (default) keeps the images on the ranks that rendered
@@ -432,7 +443,7 @@ def main():
                            f", images stay sharded on the ranks that rendered them, per-scan metadata gathered to rank 0 over {xport}"
                            if hz.gather_info.get("mode") == "sharded" else
                            f", range f32 + label images gathered to rank 0 over {xport} inside the timed region")),
-                       "gather": hz.gather_info or None,
+                       "gather": hz.gather_info or None, "warmup_ramp": hz.ramp_info,
                        "job": args.job or None, "scans_in_flight": hz.S, "scans_per_call": args.batch if args.strategy == "scatter" else 1},
             "scans_per_s": round(n_scans / dt, 2), "hit_fraction": round(hits / R, 4),
             "verified": bool(verify and verify["ok"]), "verification": verify,
