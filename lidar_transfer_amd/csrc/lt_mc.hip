@@ -930,12 +930,22 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
           // the tilings of the segment's (up to eight) cells: ALL table look-ups first, independent of one another -- a loop
           // over the set bits with the look-up inside was a chain of dependent global loads, one per cell of the fullest lane
           // (the section's 3.0 of a batch's 9.4 us, tools/mc_wave_times.py)
+          // case index of voxel bb: bit q = bit bb of corner mask q (mc_case: corner q = dx | dy << 1 | dz << 2) -- the
+          // transpose of an 8 x 8 bit matrix (rows = the masks' bytes), three swap steps on a 64-bit word instead of 64
+          // single-bit moves
+          u64 tm = 0ull;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tm |= (u64)m8[q] << (8 * q);
+          u64 tt = (tm ^ (tm >> 7)) & 0x00AA00AA00AA00AAull;
+          tm ^= tt ^ (tt << 7);
+          tt = (tm ^ (tm >> 14)) & 0x0000CCCC0000CCCCull;
+          tm ^= tt ^ (tt << 14);
+          tt = (tm ^ (tm >> 28)) & 0x00000000F0F0F0F0ull;
+          tm ^= tt ^ (tt << 28);
           unsigned selv[8];
 #pragma unroll
           for (int bb = 0; bb < 8; ++bb) {
-            unsigned cs = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cs |= ((m8[q] >> bb) & 1u) << q;  // (mc_case: corner q = dx | dy << 1 | dz << 2)
+            const unsigned cs = (unsigned)(tm >> (8 * bb)) & 255u;
             selv[bb] = ((ac8 >> bb) & 1u) ? LT_LWC_FIXED[cs] : 0u;
           }
 #pragma unroll
@@ -1089,12 +1099,14 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       const unsigned tl = s_tl[j];
       const unsigned e = s_cl[tl & 1023u];
       const int k = e & 15, b = (e >> 4) & 63, t = (int)(tl >> 10);
-      const unsigned char* codes = LT_LWF + (e >> 15) + 3 * t;  // (already in the reference's order: np.fliplr(faces))
+      // the triangle's three codes in one 16-bit word (already in the reference's order: np.fliplr(faces)); three byte loads
+      // with a branch on each were three dependent round trips per triangle window
+      const unsigned codes = LT_LWF3[(e >> 15) / 3u + (unsigned)t];
       const int tid = tbase0 + tb + j;
       int id[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const int code = codes[q];
+        const int code = (int)((codes >> (5 * q)) & 31u);
         if (code == 31) {  // the cell's centre vertex: behind the word's edge vertices, ranked among the word's centre cells
           const mc_rec& Rk = s_rec[k];
           id[q] = Rk.vbase + __popcll(Rk.ex) + __popcll(Rk.ey) + __popcll(Rk.ez) + __popcll(s_ccm[k] & ((1ull << b) - 1ull));
