@@ -207,7 +207,7 @@ extern "C" int lt_debug_mc_stamps(unsigned long long* out, int n_waves) {
 #define LT_MC_STAMP_AT(which, w, i, v) do { if (LT_MC_STAMP == (which) && (threadIdx.x & 63) == 0 && (w) < (1 << 16)) g_mc_stamp[(w) * 4 + (i)] = (v); } while (0)
 // =3: k_mc_emit_batch by section -- g_mc_stamp[8 b + i]: the wall clock between marks i - 1 and i of batch b (plain stores:
 // atomics on eight shared words serialise the waves behind them and measure themselves)
-#define LT_MC_SECTION(i) do { if (LT_MC_STAMP == 3) { const unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0 && bi < (1 << 15)) g_mc_stamp[bi * 8 + (i)] = t_ - st_last; st_last = t_; } } while (0)
+#define LT_MC_SECTION(i) do { if (LT_MC_STAMP == 3) { const unsigned long long t_ = wall_clock64(); if ((threadIdx.x & 63) == 0 && bi < (1 << 15)) g_mc_stamp[bi * 8 + (i)] = t_ - st_last; st_last = t_; } } while (0)
 #else
 #define LT_MC_STAMP_AT(which, w, i, v) do { } while (0)
 #define LT_MC_SECTION(i) do { } while (0)
@@ -793,8 +793,11 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 // are consecutive), and then lane j computes vertex j / triangle j: every lane live, every store coalesced.
 #define LT_MC_VCAP 256   // list windows; a batch with more vertices / triangles is emitted in several passes
 #define LT_MC_TCAP 256   // (LDS per wave decides how many batches a CU holds: 10.8 KB -> 8.2 KB = 14 -> 19 waves per CU)
+#define LT_MC_EW 4  // waves per workgroup of the emission
+#define LT_MC_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <int K>
-__global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
+__global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
                                                       const float* __restrict__ rem_vol, const u64* __restrict__ bits,
                                                       mc_dims D, const int* __restrict__ cmap,
                                                       const mc_rec* __restrict__ rec, int n_active, float voxel_size,
@@ -802,18 +805,32 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
                                                       int* __restrict__ faces, int* __restrict__ colors,
                                                       float* __restrict__ rem, int cap_v, int cap_f, mc_amb A, int xcd_map) {
   static_assert(K <= 16, "list entries hold the word in 4 bits");
-  __shared__ mc_rec s_rec[K];
-  __shared__ int s_xyz[K][3];       // x, y, wz of the words
-  __shared__ u64 s_sg[K][8];        // sign words of the cell corners, [dx | dy << 1 | dw << 2]
-  __shared__ mc_nb s_nb[K][8];      // records of the 8 words a cell's triangles can reference
-  __shared__ u64 s_cm[K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
-  __shared__ unsigned short s_vl[LT_MC_VCAP];  // vertex j of the window:   k | b << 4 | axis << 10 (12 bits; axis 3 = the cell's centre vertex)
-  __shared__ unsigned short s_tl[LT_MC_TCAP];  // triangle j of the window: index into s_cl | t << 10
-  __shared__ unsigned s_cl[K * 64];      // active cells of the batch in order: k | b << 4 | triangles << 10 | centre << 14 | tiling offset << 15
-  __shared__ unsigned short s_ct[K * 64];  // ... and the (batch-relative) index of their first triangle (< 16 x 64 x 12)
-  __shared__ u64 s_ccm[K];               // the words' cells that own a centre vertex
-  __shared__ int s_cpre[K + 1];          // active cells before word k
-  const int lane = threadIdx.x;
+  static_assert(64 * LT_MC_EW == 256, "the tiling table is staged by 256 threads");
+  // LT_MC_EW waves per workgroup, each with arrays of its own and no business with the others: what would be a workgroup
+  // barrier orders ONE wave's LDS accesses, which the hardware executes in order anyway -- LT_MC_WSYNC only keeps the
+  // compiler from moving them.  (Four waves instead of one per workgroup change nothing by themselves -- 82.7 us both;
+  // they share the tiling table below, 256 B of LDS per wave instead of 1 KB: 80 us.)
+  __shared__ mc_rec S_rec[LT_MC_EW][K];
+  __shared__ int S_xyz[LT_MC_EW][K][3];       // x, y, wz of the words
+  __shared__ mc_nb S_nb[LT_MC_EW][K][8];      // records of the 8 words a cell's triangles can reference
+  __shared__ u64 S_cm[LT_MC_EW][K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
+  // sg: sign words of the cell corners, [dx | dy << 1 | dw << 2] -- dead once the corner masks are built, where
+  // vl: vertex j of the window: k | b << 4 | axis << 10 (12 bits; axis 3 = the cell's centre vertex) begins its life
+  union sg_vl { u64 sg[K][8]; unsigned short vl[LT_MC_VCAP]; };
+  __shared__ sg_vl S_sv[LT_MC_EW];
+  __shared__ unsigned short S_tl[LT_MC_EW][LT_MC_TCAP];  // triangle j of the window: index into s_cl | t << 10
+  __shared__ unsigned S_cl[LT_MC_EW][K * 64];      // active cells of the batch in order: k | b << 4 | triangles << 10 | centre << 14 | tiling offset << 15
+  __shared__ unsigned short S_ct[LT_MC_EW][K * 64];  // ... and the (batch-relative) index of their first triangle (< 16 x 64 x 12)
+  __shared__ u64 S_ccm[LT_MC_EW][K];               // the words' cells that own a centre vertex
+  __shared__ int S_cpre[LT_MC_EW][K + 1];          // active cells before word k
+  __shared__ unsigned s_lwc[256];  // LT_LWC_FIXED, once per workgroup: a cell's tiling without a global round trip
+  s_lwc[threadIdx.x & 255u] = LT_LWC_FIXED[threadIdx.x & 255u];
+  __syncthreads();  // (the only workgroup barrier: before any wave's first batch)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  auto& s_rec = S_rec[wv]; auto& s_xyz = S_xyz[wv]; auto& s_sg = S_sv[wv].sg; auto& s_nb = S_nb[wv]; auto& s_cm = S_cm[wv];
+  auto& s_vl = S_sv[wv].vl; auto& s_tl = S_tl[wv]; auto& s_cl = S_cl[wv]; auto& s_ct = S_ct[wv]; auto& s_ccm = S_ccm[wv];
+  auto& s_cpre = S_cpre[wv];
+  const int lane = (int)(threadIdx.x & 63u);
   // (a wave takes batches until none is left; by default the grid has a wave per batch -- see the launch)
   const int n_batches = (n_active + K - 1) / K;
   // Batch order: active words are numbered x-major, so the batch list walks the volume plane by plane.  Workgroups are dealt
@@ -823,9 +840,9 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
   // xcd_map = C > 0: the list is cut into CHUNKS of C batches (a few planes), chunk c belongs to XCD c % 8, and the waves of
   // an XCD take the batches of its chunks in turn -- eight contiguous eighths (one per XCD) moved the fewest bytes but the
   // XCDs finished at different times (a batch costs 1.5 - 42 us depending on where in the scene it lies).
-  const int per_xcd = gridDim.x >> 3, xq = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  const int per_xcd = (int)(gridDim.x >> 3) * LT_MC_EW, xq = blockIdx.x & 7, xslot = (int)(blockIdx.x >> 3) * LT_MC_EW + wv;
   if (xcd_map && xslot >= per_xcd) return;  // (a grid that is not a multiple of eight: the tail waves have no share)
-  for (int it = xcd_map ? xslot : (int)blockIdx.x;; it += xcd_map ? per_xcd : (int)gridDim.x) {
+  for (int it = xcd_map ? xslot : (int)blockIdx.x * LT_MC_EW + wv;; it += xcd_map ? per_xcd : (int)gridDim.x * LT_MC_EW) {
     int bi = it;
     if (xcd_map) bi = ((it / xcd_map) * 8 + xq) * xcd_map + it % xcd_map;
     if (xcd_map ? (it / xcd_map) * 8 * xcd_map >= n_batches : bi >= n_batches) break;
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     s_xyz[lane][0] = row / D.ny;
     s_xyz[lane][1] = row - (row / D.ny) * D.ny;
   }
-  __syncthreads();
+  LT_MC_WSYNC();
   LT_MC_SECTION(0);  // records
   for (int p = lane; p < 8 * nw; p += 64) {  // (k, slot): sign word and record of the word (x + dx, y + dy, wz + dw)
     const int k = p >> 3, slot = p & 7;
@@ -867,7 +884,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     s_sg[k][slot] = sg;
     s_nb[k][slot] = e;
   }
-  __syncthreads();
+  LT_MC_WSYNC();
   LT_MC_SECTION(1);  // sign words, compact indices, neighbour records
   if (lane < nw) {  // the cell masks of word `lane`, once
     u64 w8[8];
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
     if (lane < K) s_ccm[lane] = 0ull;
     (void)mine;
   }
-  __syncthreads();
+  LT_MC_WSYNC();
   const mc_rec first = s_rec[0], last = s_rec[nw - 1];
   const int vbase0 = first.vbase, tbase0 = first.tbase;
   const int nvt = last.vbase + __popcll(last.ex) + __popcll(last.ey) + __popcll(last.ez) + (last.pad >> 16) - vbase0;
@@ -946,7 +963,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
 #pragma unroll
           for (int bb = 0; bb < 8; ++bb) {
             const unsigned cs = (unsigned)(tm >> (8 * bb)) & 255u;
-            selv[bb] = ((ac8 >> bb) & 1u) ? LT_LWC_FIXED[cs] : 0u;
+            selv[bb] = ((ac8 >> bb) & 1u) ? s_lwc[cs] : 0u;
           }
 #pragma unroll
           for (int bb = 0; bb < 8; ++bb) {
@@ -979,7 +996,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       run += __shfl(inc, 63, 64);
     }
   }
-  __syncthreads();
+  LT_MC_WSYNC();
   LT_MC_SECTION(5);  // cell masks, cell list, triangle offsets
 #if defined(LT_MC_STOP) && LT_MC_STOP == 4  // ... + cell list and scan
   continue;
@@ -1024,7 +1041,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
         }
       }
     }
-    __syncthreads();
+    LT_MC_WSYNC();
     LT_MC_SECTION(3);  // vertex list
 #if defined(LT_MC_STOP) && LT_MC_STOP == 2  // ... + vertex list
     continue;
@@ -1079,7 +1096,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
         rem[vid] = rm;
       }
     }
-    __syncthreads();
+    LT_MC_WSYNC();
   }
   LT_MC_SECTION(4);  // vertex pass (field samples, attributes, stores drained)
 #if defined(LT_MC_STOP) && LT_MC_STOP == 3  // ... + vertex pass
@@ -1093,7 +1110,7 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
       for (int t = 0; t < nt; ++t)
         if ((unsigned)(j0 + t) < LT_MC_TCAP) s_tl[j0 + t] = (unsigned short)((unsigned)c | ((unsigned)t << 10));
     }
-    __syncthreads();
+    LT_MC_WSYNC();
     const int nwin = min(LT_MC_TCAP, ntt - tb);
     for (int j = lane; j < nwin; j += 64) {
       const unsigned tl = s_tl[j];
@@ -1128,10 +1145,10 @@ __global__ __launch_bounds__(64) void k_mc_emit_batch(const float* __restrict__ 
         faces[3 * (size_t)tid + 2] = id[2];
       }
     }
-    __syncthreads();
+    LT_MC_WSYNC();
   }
     LT_MC_SECTION(6);  // triangle list + pass (stores drained)
-    __syncthreads();  // the batch's arrays are reused
+    LT_MC_WSYNC();  // the batch's arrays are reused
   }
 }
 
@@ -1384,12 +1401,12 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     const int max_waves = env_waves > 0 ? env_waves : (env_waves == 0 ? (1 << 24) : dflt_waves);
     // LIDARHIP_MC_EMIT_XCD=0: batches dealt to the waves round-robin over the whole list (rounds 3-4)
     static const int env_xcd = []() { const char* e = getenv("LIDARHIP_MC_EMIT_XCD"); return e ? atoi(e) : 64; }();
-    auto grid = [&](int k) { return dim3((unsigned)min((n_active + k - 1) / k, max_waves)); };
-    const int xcd_map = (env_xcd > 0 && (int)grid(kk >= 16 ? 16 : kk >= 8 ? 8 : kk >= 4 ? 4 : 2).x >= 64) ? env_xcd : 0;
-    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, grid(4), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
-    else hipLaunchKernelGGL(k_mc_emit_batch<2>, grid(2), dim3(64), 0, stream, LT_MC_EMIT_ARGS);
+    auto grid = [&](int k) { return dim3((unsigned)((min((n_active + k - 1) / k, max_waves) + LT_MC_EW - 1) / LT_MC_EW)); };
+    const int xcd_map = (env_xcd > 0 && (int)grid(kk >= 16 ? 16 : kk >= 8 ? 8 : kk >= 4 ? 4 : 2).x * LT_MC_EW >= 64) ? env_xcd : 0;
+    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, grid(4), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else hipLaunchKernelGGL(k_mc_emit_batch<2>, grid(2), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
   }
 #undef LT_MC_EMIT_ARGS
   LT_HIP(hipGetLastError());
