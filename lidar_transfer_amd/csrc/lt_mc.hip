@@ -462,6 +462,9 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
   // counted by the WAVE, a lane per cell: the owner's eight corner masks are broadcast (v_readlane), every lane looks up
   // its cell, three ballots add the counts up (42 -> 32 us on the default volume, with the threshold swept and the lanes'
   // own loops on 32-bit half words).
+#ifndef LT_MC_HEAVY_LANES
+#define LT_MC_HEAVY_LANES 8   // (swept: 4 .. 12: 31.5 us, 20 .. 32: 32.4, 64 = never walked: 37.5)
+#endif
 #ifndef LT_MC_HEAVY
 #define LT_MC_HEAVY 16  // (swept on the default volume: 2: 50 us, 4: 39, 6: 38, 10 .. 24: 32-33, 40: 35, never: 39)
 #endif
@@ -479,7 +482,10 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
       }
       return 0u;
     };
-    const bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
+    // ... unless MANY lanes hold such a word (a wall across the block's rows): the wave's turn costs ~90 instructions
+    // per heavy word, the lanes' own loops ~25 per cell of the fullest lane -- 64 heavy words at once are cheaper walked
+    bool heavy = __popcll(M.ac) > LT_MC_HEAVY;
+    if (__popcll(__ballot(heavy)) > LT_MC_HEAVY_LANES) heavy = false;
     if (!heavy) {
       // the word's halves one after the other: with 32-bit masks a cell is 8 x (v_bfe_u32, v_lshl_or_b32) + a 32-bit
       // find-first / clear-lowest, a third of the instructions of the 64-bit shifts of mc_case

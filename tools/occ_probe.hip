@@ -30,13 +30,18 @@ static int max_alive(const std::vector<uint64_t>& h, size_t n) {
   return best;
 }
 
-int main() {
+int main(int argc, char**) {
   const int n_wg = 16384;
   uint64_t* d;
   CK(hipMalloc(&d, (size_t)n_wg * 4 * 2 * sizeof(uint64_t)));
   printf("%10s %8s %16s %14s %12s\n", "threads/WG", "LDS B", "waves alive max", "per CU (/256)", "ms");
+  // (argv: "fine" = the sizes around the emission's workgroups, to find the allocation granule)
+  const bool fine = argc > 1;
+  const std::vector<int> coarse = {512, 2048, 4096, 6144, 8200, 12288, 16384, 32768, 40000};
+  const std::vector<int> fine64 = {6400, 6656, 6724, 6912, 7168, 7424, 7492, 7680, 7752, 8192};
+  const std::vector<int> fine256 = {25600, 26112, 26624, 26880, 26896, 27136, 27306, 27648, 28160, 29968, 30720, 31744, 32016, 32768};
   for (int threads : {64, 256}) {
-    for (int lds : {512, 2048, 4096, 6144, 8200, 12288, 16384, 32768, 40000}) {
+    for (int lds : (fine ? (threads == 64 ? fine64 : fine256) : coarse)) {
       CK(hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
       const size_t nw = (size_t)n_wg * (threads / 64);
       hipEvent_t e0, e1;
