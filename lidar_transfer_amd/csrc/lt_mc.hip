@@ -797,8 +797,13 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 // kernel's 265 us (more words per wave or a lane per word change nothing: 272 / 332 us measured).  Here a wave takes K
 // words, lists their vertices and triangles in LDS (in output order: the lists ARE the output ranges, a batch's words
 // are consecutive), and then lane j computes vertex j / triangle j: every lane live, every store coalesced.
+// LDS decides how many batches a CU holds, in granules of 1 280 B per WORKGROUP (tools/occ_probe.hip fine): the 29 968 B of
+// four waves are 24 granules = 5 workgroups = 20 waves per CU (one-wave workgroups of 7 752 B held 18).  Six workgroups
+// (<= 26 880 B and <= 80 registers: lists of 128, the tiling table back in global memory) were built and measured: 90 us
+// against 80 -- the kernel issues vector instructions 0.6 of the time (924 per batch: staging 155, cells 222, vertices 283,
+// triangles 263; tools/mc_sections.sh), more waves do not hide what is not latency.
 #define LT_MC_VCAP 256   // list windows; a batch with more vertices / triangles is emitted in several passes
-#define LT_MC_TCAP 256   // (LDS per wave decides how many batches a CU holds: 10.8 KB -> 8.2 KB = 14 -> 19 waves per CU)
+#define LT_MC_TCAP 256
 #define LT_MC_EW 4  // waves per workgroup of the emission
 #define LT_MC_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -1395,8 +1400,9 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
                         m->verts, m->faces, m->colors, m->rem, m->cap_v, m->cap_f, m->amb, xcd_map
   if (n_active > 0) {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
-    // The grid: persistent waves taking batches in turn (bi += gridDim), twice the resident capacity (18 waves of 8.2 KB
-    // LDS per CU, tools/occ_probe.hip).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on
+    // The grid: persistent waves taking batches in turn (bi += gridDim), 36 per CU -- 1.8 x the resident capacity (20 waves
+    // per CU, see LT_MC_VCAP; swept again with four-wave workgroups: 24 / 36 / 48 / 72 / 96 per CU = 118 / 90 / 100 / 92 / 102 us
+    // on the six-workgroup variant, the same order on this one).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on
     // average and up to 42, tools/mc_wave_times.py): a wave per batch 96 us -- a wave's start and drain 31 500 times --,
     // 4 608 / 9 216 / 18 432 persistent waves 107 / 87 / 86 us (static dealing is at the mercy of the heavy batches: with
     // one round of waves the slowest wave is the kernel), and persistent waves DRAWING their batches from eight counters
