@@ -219,15 +219,24 @@ struct mc_dims {
   int nx, ny, nz;
   int wz;        // 64-bit words per (x, y) row
   int n_words;   // nx * ny * wz
+  unsigned ny_m; int ny_s;  // row / ny likewise (mc_x_of)
   unsigned wz_m; int wz_s;  // w / wz by multiplication (mc_row_of): an integer division is ~40 vector instructions, and
                             // k_mc_words runs one per word of the volume (16 M on the default one)
 };
 
 // row = w / D.wz for 0 <= w < 2^31 (round-up method: m = floor(2^32 (2^s - d) / d) + 1, s = ceil(log2 d))
-__device__ __forceinline__ int mc_row_of(const mc_dims& D, int w) {
-  if (D.wz_s == 0) return w;  // wz == 1
-  const unsigned n = (unsigned)w, t = __umulhi(n, D.wz_m);
-  return (int)((t + ((n - t) >> 1)) >> (D.wz_s - 1));
+__device__ __forceinline__ int mc_udiv(int n_, unsigned m, int s) {
+  if (s == 0) return n_;  // d == 1
+  const unsigned n = (unsigned)n_, t = __umulhi(n, m);
+  return (int)((t + ((n - t) >> 1)) >> (s - 1));
+}
+__device__ __forceinline__ int mc_row_of(const mc_dims& D, int w) { return mc_udiv(w, D.wz_m, D.wz_s); }
+__device__ __forceinline__ int mc_x_of(const mc_dims& D, int row) { return mc_udiv(row, D.ny_m, D.ny_s); }  // x = row / ny
+static void mc_magic(unsigned d, unsigned* m, int* s) {  // (host)
+  int sh = 0;
+  while ((1u << sh) < d) ++sh;
+  *s = sh;
+  *m = sh == 0 ? 0u : (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << sh) - d)) / d + 1ull);
 }
 
 struct mc_rec {  // one per active word
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(256) void k_mc_words(mc_amb A, const u64* __restric
   // (a clean row writes nothing: its words hold 0 -- no active word of the last extraction is left, k_mc_clear)
   const bool rowlive = row < n_rows && mc_rows_dirty(col_epoch, epoch, D, row);
   const int rowc = min(row, n_rows - 1);
-  const int x = rowc / D.ny, y = rowc - x * D.ny;
+  const int x = mc_x_of(D, rowc), y = rowc - x * D.ny;
   // Triangles of a word = sum over its active cells of the case's count.  A lane walking its own cells is a chain of
   // ~60 instructions and an LDS look-up per cell, and a row through a wall along z has 60 active cells a word: its wave
   // waits for that one lane, and the launch for its slowest waves.  Words with more than LT_MC_HEAVY cells are therefore
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
   int ci = sg[0] + blk[3 * blkid] + (int)(ex & 0xFFFFF);
   int vb = sg[1] + blk[3 * blkid + 1] + (int)((ex >> 20) & 0xFFFFF);
   int tb = sg[2] + blk[3 * blkid + 2] + (int)((ex >> 40) & 0xFFFFF);
-  const int x = row / D.ny, y = row - x * D.ny;
+  const int x = mc_x_of(D, row), y = row - x * D.ny;
   for (int k = 0; k < D.wz; ++k) {
     const int w = row * D.wz + k;
     const unsigned c = cnt[w];
@@ -823,6 +832,7 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
   // they share the tiling table below, 256 B of LDS per wave instead of 1 KB: 80 us.)
   __shared__ mc_rec S_rec[LT_MC_EW][K];
   __shared__ int S_xyz[LT_MC_EW][K][3];       // x, y, wz of the words
+  __shared__ size_t S_base[LT_MC_EW][K];      // ... and the voxel index of their first voxel
   __shared__ mc_nb S_nb[LT_MC_EW][K][8];      // records of the 8 words a cell's triangles can reference
   __shared__ u64 S_cm[LT_MC_EW][K][9];        // corner masks m[dx][dy], s[dx][dy] (mc_masks) and the active-cell mask of the words
   // sg: sign words of the cell corners, [dx | dy << 1 | dw << 2] -- dead once the corner masks are built, where
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
   s_lwc[threadIdx.x & 255u] = LT_LWC_FIXED[threadIdx.x & 255u];
   __syncthreads();  // (the only workgroup barrier: before any wave's first batch)
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  auto& s_rec = S_rec[wv]; auto& s_xyz = S_xyz[wv]; auto& s_sg = S_sv[wv].sg; auto& s_nb = S_nb[wv]; auto& s_cm = S_cm[wv];
+  auto& s_rec = S_rec[wv]; auto& s_xyz = S_xyz[wv]; auto& s_base = S_base[wv]; auto& s_sg = S_sv[wv].sg; auto& s_nb = S_nb[wv]; auto& s_cm = S_cm[wv];
   auto& s_vl = S_sv[wv].vl; auto& s_tl = S_tl[wv]; auto& s_cl = S_cl[wv]; auto& s_ct = S_ct[wv]; auto& s_ccm = S_ccm[wv];
   auto& s_cpre = S_cpre[wv];
   const int lane = (int)(threadIdx.x & 63u);
@@ -867,10 +877,11 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
   if (lane < nw) {
     const mc_rec r = rec[ci0 + lane];
     s_rec[lane] = r;
-    const int row = r.w / D.wz;
+    const int row = mc_row_of(D, r.w), x = mc_x_of(D, row);
     s_xyz[lane][2] = r.w - row * D.wz;
-    s_xyz[lane][0] = row / D.ny;
-    s_xyz[lane][1] = row - (row / D.ny) * D.ny;
+    s_xyz[lane][0] = x;
+    s_xyz[lane][1] = row - x * D.ny;
+    s_base[lane] = (size_t)x * sx + (size_t)(row - x * D.ny) * sy + (size_t)(r.w - row * D.wz) * 64;
   }
   LT_MC_WSYNC();
   LT_MC_SECTION(0);  // records
@@ -1062,7 +1073,7 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
       const unsigned e = s_vl[j];
       const int k = e & 15, b = (e >> 4) & 63, a = (e >> 10) & 3;
       const int x = s_xyz[k][0], y = s_xyz[k][1], z = s_xyz[k][2] * 64 + b;
-      const size_t i = (size_t)x * sx + (size_t)y * sy + z;
+      const size_t i = s_base[k] + (size_t)b;  // (64-bit multiplications are quarter rate: once per word, not per vertex)
       float p0 = (float)x, p1 = (float)y, p2 = (float)z;
       if (a == 3) {
         // the cell's centre vertex (Cell.calculate_center_vertex): the centre of mass of the eight corners with weights
@@ -1087,9 +1098,11 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
       }
       // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
       // (clamped: a NaN field value must not become a wild address; numpy would raise there)
-      const int i0 = min(max((int)rintf(p0), 0), D.nx - 1), i1 = min(max((int)rintf(p1), 0), D.ny - 1),
-                i2 = min(max((int)rintf(p2), 0), D.nz - 1);
-      const size_t jj = (size_t)i0 * sx + (size_t)i1 * sy + (size_t)i2;
+      // The vertex lies on an edge (or inside a cell) that starts at voxel (x, y, z): every rounded coordinate is the
+      // voxel's or the next one's, and the next one exists where the edge / the cell does.  (Anything else -- a NaN field
+      // value, on which numpy would raise -- counts as "the next one": never a wild address.)
+      const size_t jj = i + ((int)rintf(p0) == x ? (size_t)0 : sx) + ((int)rintf(p1) == y ? (size_t)0 : sy) +
+                        ((int)rintf(p2) == z ? (size_t)0 : (size_t)1);
       const float rgb = color_vol[jj];
       const float rm = rem_vol[jj];
       const int vid = vbase0 + vb + j;
@@ -1252,12 +1265,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   mc_dims D;
   D.nx = nx; D.ny = ny; D.nz = nz;
   D.wz = (nz + 63) / 64;
-  {
-    int sh = 0;
-    while ((1u << sh) < (unsigned)D.wz) ++sh;
-    D.wz_s = sh;
-    D.wz_m = sh == 0 ? 0u : (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << sh) - (unsigned)D.wz)) / (unsigned)D.wz + 1ull);
-  }
+  mc_magic((unsigned)D.wz, &D.wz_m, &D.wz_s);
+  mc_magic((unsigned)D.ny, &D.ny_m, &D.ny_s);
   const size_t n_words = (size_t)nx * ny * D.wz;
   if (n_words >= 2147483647ull) {
     lt_set_error("lt_marching_cubes_dev: volume too large");
