@@ -809,8 +809,10 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 // LDS decides how many batches a CU holds, in granules of 1 280 B per WORKGROUP (tools/occ_probe.hip fine): the 29 968 B of
 // four waves are 24 granules = 5 workgroups = 20 waves per CU (one-wave workgroups of 7 752 B held 18).  Six workgroups
 // (<= 26 880 B and <= 80 registers: lists of 128, the tiling table back in global memory) were built and measured: 90 us
-// against 80 -- the kernel issues vector instructions 0.6 of the time (924 per batch: staging 155, cells 222, vertices 283,
-// triangles 263; tools/mc_sections.sh), more waves do not hide what is not latency.
+// against 80 -- a batch is ~1 400 instructions (924 vector: staging 155, cells 222, vertices 283, triangles 263,
+// tools/mc_sections.sh; 362 scalar, 102 LDS) and ONE wave issues an instruction every 5-7 cycles whatever runs beside it
+// (profiles/r03/valu_calib.txt: 4.7 cycles alone, 7.2 with eight waves per SIMD): 3-4 us of a batch's 8.4 are its own
+// instruction stream, which more waves do not shorten and fewer registers (= more instructions) lengthen.
 #define LT_MC_VCAP 256   // list windows; a batch with more vertices / triangles is emitted in several passes
 #define LT_MC_TCAP 256
 #define LT_MC_EW 4  // waves per workgroup of the emission
