@@ -774,10 +774,20 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
     }
     return a;
   };
+  // (An item's chunks dealt to several workgroups, each repeating phase A, were measured: 2 parts 88 us, 4 parts 129 against
+  // 65 -- an item is 6 us of phase A, 3 of its first chunk's pairs and 9 of voxel rounds: tools/tsdf_written_times.py --pix.)
   for (int p0 = blockIdx.x * 64; p0 < n_pix; p0 += gridDim.x * 64) {  // (workgroup-uniform)
     const unsigned long long tm0 = VCOUNT ? (unsigned long long)wall_clock64() : 0ull;  // (100 MHz; debug)
     LT_PIX_MARK(0);
     // ---- A: the pixels' runs of table entries ------------------------------------------------------------------------
+    // (wave 0's own loads -- its pixel, its row's table entry, its wedge's extent -- are issued BEFORE the staging and its
+    // barrier: one dependent round trip less per item)
+    const int pA = p0 + lane;
+    const bool inA = wave == 0 && pA < n_pix;
+    const int pxA = inA ? pA / im_h : 0, rA = inA ? pA - pxA * im_h : 0;
+    const float2 dcA = inA ? dct[pA] : make_float2(0.f, 1.f);
+    const float4 rowA = rowtab[rA];
+    const int s0A = wd_start[pxA], s1A = wd_start[pxA + 1];
     {  // stage the quanta of the wedges these 64 pixels search (one image column when im_h is a multiple of 64)
       const int px_a = p0 / im_h, px_b = min(p0 + 63, n_pix - 1) / im_h;
       stage0 = wd_start[px_a];
@@ -787,19 +797,27 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       staged = false;
 #endif
       if (staged)
-        for (int i = tid; i < n_stage; i += 256) c_buf[i] = (int)wd_key[stage0 + i];
+      {  // all loads first, then the LDS stores: the rolled loop waited for every load before it issued the next
+        // (up to 15 dependent round trips: 10 of an item's ~20 us)
+        constexpr int NS = (LT_PIX_STAGE + 255) / 256;
+        uint32_t sv[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sv[k] = tid + 256 * k < n_stage ? wd_key[stage0 + tid + 256 * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+          if (tid + 256 * k < n_stage) c_buf[tid + 256 * k] = (int)sv[k];
+      }
       __syncthreads();
     }
     if (wave != 0) {
       for (int i = tid - 64; i < LT_PIX_AGG; i += 192) { a_lo[i] = 0u; a_hi[i] = 0u; }
     }
     if (wave == 0) {
-      const int p = p0 + lane;  // pixel (row r, column px) at dct[px * im_h + r]
-      const bool in = p < n_pix;
-      const int px = in ? p / im_h : 0, r = in ? p - px * im_h : 0;
-      const float2 dc = in ? dct[p] : make_float2(0.f, 1.f);
+      const bool in = inA;  // pixel (row r, column px) at dct[px * im_h + r]
+      const int px = pxA, r = rA;
+      const float2 dc = dcA;
       const float D = dc.x;
-      const float4 row = rowtab[r];  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
+      const float4 row = rowA;  // (tan_lo, tan_hi, cos_min, cos_max); tan_lo > tan_hi: no voxel can take this row
       const bool row_ok = row.x <= row.y;
       const bool finite = D == D && fabsf(D) < 1e30f;
       // the reference leaves at depth_value == 0; with another colour than 0 only the band is written (and nothing at all
@@ -809,7 +827,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
       const float eps = __fmaf_rn(4e-6f, fabsf(D) + trunc_margin, 1e-6f);
       const float d_hi = finite ? D + trunc_margin + eps : 3e38f;
       const float d_lo = zero_class ? 0.f : D - eps;
-      const int s0 = wd_start[px], s1 = wd_start[px + 1];
+      const int s0 = s0A, s1 = s1A;
       int k = 0, kend = 0;
       if ((normal || zero_class) && d_hi > 0.f) {
         const float rho1 = fmaxf(d_lo, 0.f) * row.z * 0.999999f;
@@ -1199,7 +1217,16 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix_multi(
       staged = false;
 #endif
       if (staged)
-        for (int i = tid; i < n_stage; i += 256) c_buf[i] = (int)wd_key[stage0 + i];
+      {  // all loads first, then the LDS stores: the rolled loop waited for every load before it issued the next
+        // (up to 15 dependent round trips: 10 of an item's ~20 us)
+        constexpr int NS = (LT_PIX_STAGE + 255) / 256;
+        uint32_t sv[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sv[k] = tid + 256 * k < n_stage ? wd_key[stage0 + tid + 256 * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+          if (tid + 256 * k < n_stage) c_buf[tid + 256 * k] = (int)sv[k];
+      }
       __syncthreads();
     }
     if (wave != 0) {
