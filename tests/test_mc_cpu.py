@@ -31,6 +31,11 @@ def test_committed_tables_are_what_the_generator_emits():
             for n, dims in re.findall(r"LT_LW_(TILING\w+?)((?:\[\d+\])+) =", committed)}
     assert set(lens) == set(rows) and int(m.group(1)) == sum(rows[n] * lens[n] for n in rows)
     assert "LT_LW_CASES[256][2]" in committed
+    # the emission's one-word-per-triangle copy of the flat rows: code 0 | code 1 << 5 | code 2 << 10
+    flat = [int(v) for v in re.search(r"LT_LWF\[\d+\] = \{(.*?)\};", committed, re.S).group(1).replace("\n", "").split(",") if v.strip()]
+    packed = [int(v) for v in re.search(r"LT_LWF3\[\d+\] = \{(.*?)\};", committed, re.S).group(1).replace("\n", "").split(",") if v.strip()]
+    assert len(flat) == int(m.group(1)) and len(packed) * 3 == len(flat) and max(flat) <= 31
+    assert packed == [flat[i] | flat[i + 1] << 5 | flat[i + 2] << 10 for i in range(0, len(flat), 3)]
 
 
 def _random_field_mesh(oracle, seed, shape=(9, 8, 7), smooth=False):
