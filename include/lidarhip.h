@@ -350,9 +350,14 @@ int lt_tsdf_integrate_multi_dev(lt_tsdf* vol, int n_obs, const float* const* col
                                 const float* const* rem_ims, int im_h, int im_w, float obs_weight, unsigned flags,
                                 void* stream);
 
-/* Device pointers of the volumes (TSDFVolume.get_volume, fusion_lidar.py:395-400, without the copies). */
+/* Device pointers of the volumes (TSDFVolume.get_volume, fusion_lidar.py:395-400, without the copies): the four fields of
+ * voxel 0.  The volume is ONE array of (tsdf, weight, colour, remission) records, [x][y][z]: voxel v's field is
+ * lt_tsdf_volume_stride() (= 4) floats x v behind the pointer.  (Four separate arrays until ABI 6; one record per voxel
+ * makes an update one 16-byte access and hands marching cubes a vertex's samples and attributes in the lines it reads
+ * anyway.) */
 int lt_tsdf_volumes(lt_tsdf* vol, int* dims, float* origin, float** tsdf, float** weight, float** color,
                     float** rem);
+int lt_tsdf_volume_stride(void);
 /* Tell the volume that its fields were modified through the pointers above (the library tracks which (x, y) columns
  * its own integrate calls wrote, so that reset and marching cubes skip the untouched ones). */
 int lt_tsdf_touch(lt_tsdf* vol);
@@ -512,7 +517,7 @@ const char* lt_version(void);
 
 /* Layout version of the structs this header declares (lt_proj_images, lt_stats, lt_mm_geometry ...): a caller compiled
  * against another header must not pass them.  lt_abi_version() returns the library's; the Python binding compares at load. */
-#define LT_ABI_VERSION 6
+#define LT_ABI_VERSION 7
 int lt_abi_version(void);
 
 #ifdef __cplusplus

@@ -28,13 +28,13 @@ SYMBOLS = ["lt_ctrace", "lt_ctrace_ex", "lt_scene_create", "lt_scene_set_mesh_de
            "lt_version", "lt_create_rays_dev", "lt_range_projection_dev", "lt_range_projection", "lt_rayset_create_dev",
            "lt_rayset_destroy", "lt_scene_render_dev", "lt_scene_render_batch_dev", "lt_scene_set_probe", "lt_reverse_projection_dev",
            "lt_pack_scan_dev", "lt_compare_dev", "lt_tsdf_create", "lt_tsdf_reset", "lt_tsdf_integrate_dev",
-           "lt_tsdf_volumes", "lt_tsdf_touch", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
+           "lt_tsdf_volumes", "lt_tsdf_volume_stride", "lt_tsdf_touch", "lt_tsdf_destroy", "lt_mesh_create", "lt_mesh_destroy", "lt_tsdf_extract_mesh_dev",
            "lt_marching_cubes_dev", "lt_mesh_get", "lt_scene_set_mesh", "lt_fusion_scan_dev", "lt_hostpipe_create", "lt_hostpipe_submit", "lt_hostpipe_wait",
            "lt_hostpipe_flush", "lt_hostpipe_destroy", "lt_host_alloc", "lt_host_free", "lt_projector_create",
            "lt_projector_destroy", "lt_range_projection_batch_dev", "lt_mesh_renumber_dev",
            "lt_tsdf_integrate_multi_dev", "lt_deform_scan_dev", "lt_mm_state_create", "lt_mm_state_destroy", "lt_mm_state_reset",
            "lt_mm_geometry_dev", "lt_mm_geometry_get", "lt_mergemesh_scan_dev", "lt_mergemesh_rerun_dev", "lt_abi_version"]
-LT_ABI_VERSION = 6   # include/lidarhip.h: layout version of the structs mirrored below
+LT_ABI_VERSION = 7   # include/lidarhip.h: layout version of the structs mirrored below
 
 
 class Stats(C.Structure):
@@ -201,6 +201,7 @@ def load():
                  "lt_mergemesh_scan_dev", "lt_mergemesh_rerun_dev", "lt_abi_version"):
         getattr(lib, name).restype = C.c_int
     lib.lt_abi_version.argtypes = []
+    lib.lt_tsdf_volume_stride.argtypes = []
     if lib.lt_abi_version() != LT_ABI_VERSION:  # a stale prebuilt library: its structs are laid out differently
         raise RuntimeError(f"{path}: ABI version {lib.lt_abi_version()} != {LT_ABI_VERSION} of this binding (rebuild the library)")
     _lib = lib

@@ -162,10 +162,10 @@ __device__ __noinline__ unsigned lw_select(const double* v, int cs) {
 // corner p sits at (a0, a1, a2) = LW_CORNER[p] of the generator / the oracle: 0 (0,0,0)  1 (0,0,1)  2 (0,1,1)  3 (0,1,0)
 // 4 (1,0,0)  5 (1,0,1)  6 (1,1,1)  7 (1,1,0) -- scikit-image's x is the last axis).  Only k_mc_amb calls this: the double
 // precision tests cost 100 vector registers, which the sweep and the emission kernels must not pay for 1-2 % of the cells.
-__device__ __forceinline__ unsigned lw_cell_eval(const float* __restrict__ c, size_t sx, size_t sy, int cs) {
-  double v[8];
-  v[0] = (double)c[0];       v[1] = (double)c[1];           v[2] = (double)c[sy + 1];      v[3] = (double)c[sy];
-  v[4] = (double)c[sx];      v[5] = (double)c[sx + 1];      v[6] = (double)c[sx + sy + 1]; v[7] = (double)c[sx + sy];
+__device__ __forceinline__ unsigned lw_cell_eval(const float* __restrict__ c, size_t sx, size_t sy, size_t sz, int cs) {
+  double v[8];  // (sx, sy, sz: floats between neighbours along x, y, z)
+  v[0] = (double)c[0];       v[1] = (double)c[sz];          v[2] = (double)c[sy + sz];      v[3] = (double)c[sy];
+  v[4] = (double)c[sx];      v[5] = (double)c[sx + sz];     v[6] = (double)c[sx + sy + sz]; v[7] = (double)c[sx + sy];
   return lw_select(v, cs);
 }
 // ---- the ambiguous cells' side channel -------------------------------------------------------------------------------
@@ -220,6 +220,8 @@ struct mc_dims {
   int wz;        // 64-bit words per (x, y) row
   int n_words;   // nx * ny * wz
   unsigned ny_m; int ny_s;  // row / ny likewise (mc_x_of)
+  int vs;        // floats between two voxels of a field array: 1 (three separate arrays, lt_marching_cubes_dev) or 4 (a
+                 // TSDF volume's interleaved (tsdf, weight, colour, remission) records, lt_tsdf.hip LT_VOX)
   unsigned wz_m; int wz_s;  // w / wz by multiplication (mc_row_of): an integer division is ~40 vector instructions, and
                             // k_mc_words runs one per word of the volume (16 M on the default one)
 };
@@ -288,13 +290,13 @@ __global__ __launch_bounds__(256) void k_mc_signs(const float* __restrict__ tsdf
     while (m) {
       const int r = chunk * 64 + (__ffsll((long long)m) - 1);
       m &= m - 1;
-      const float* src = tsdf + (size_t)r * D.nz;
+      const float* src = tsdf + (size_t)r * D.nz * D.vs;
       for (int k0 = 0; k0 < D.wz; k0 += 4) {
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int z = (k0 + k) * 64 + lane;
-          v[k] = z < D.nz ? src[z] : 1.0f;
+          v[k] = z < D.nz ? src[(size_t)z * D.vs] : 1.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, 
   const unsigned sh = blockIdx.x & (LT_MC_SHARDS - 1), per = max(gridDim.x / LT_MC_SHARDS, 1u);
   const unsigned n = min((unsigned)A.counter[sh * LT_MC_CTR_STRIDE], A.cap);
   const uint2* __restrict__ queue = A.queue + (size_t)sh * A.cap;
-  const size_t sy = (size_t)D.nz, sx = (size_t)D.ny * D.nz;
+  const size_t sz = (size_t)D.vs, sy = (size_t)D.nz * sz, sx = (size_t)D.ny * sy;
   // a workgroup takes 256 queued cells and deals them to its lanes SORTED by Lewiner's case (counting sort in LDS): the seven
   // ambiguous cases run different tests, and a wave pays for every case its lanes hold
   __shared__ uint2 s_e[256];
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256) void k_mc_amb(const float* __restrict__ tsdf, 
     const uint2 e = s_e[tid];
     const unsigned i = e.x;
     const int cs = (int)(e.y & 255u), b = (int)(e.y >> 8);
-    const unsigned sel = lw_cell_eval(tsdf + i, sx, sy, cs);
+    const unsigned sel = lw_cell_eval(tsdf + (size_t)i * sz, sx, sy, sz, cs);
     for (unsigned h = amb_slot(i, A.tmask);; h = (h + 1) & A.tmask)  // (every cell is queued once: the slot is free or foreign)
       if (atomicCAS(&A.table[h].x, 0u, i + 1u) == 0u) { A.table[h].y = sel; break; }
     const unsigned nt = LW_NT(sel), c = LW_C(sel);
@@ -818,7 +820,10 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 #define LT_MC_EW 4  // waves per workgroup of the emission
 #define LT_MC_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-template <int K>
+// AOS: the three field pointers are one array of (tsdf, weight, colour, remission) records (a TSDF volume, D.vs == 4): an
+// edge vertex's two field samples and its attributes -- which are those of one of the edge's two ends -- come with TWO
+// 16-byte loads, nothing waits for the vertex rule (separate arrays: four loads, the last two behind the rule)
+template <int K, bool AOS>
 __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __restrict__ tsdf, const float* __restrict__ color_vol,
                                                       const float* __restrict__ rem_vol, const u64* __restrict__ bits,
                                                       mc_dims D, const int* __restrict__ cmap,
@@ -1077,36 +1082,49 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
       const int x = s_xyz[k][0], y = s_xyz[k][1], z = s_xyz[k][2] * 64 + b;
       const size_t i = s_base[k] + (size_t)b;  // (64-bit multiplications are quarter rate: once per word, not per vertex)
       float p0 = (float)x, p1 = (float)y, p2 = (float)z;
+      constexpr size_t VS = AOS ? 4 : 1;
+      float rgb, rm;
       if (a == 3) {
         // the cell's centre vertex (Cell.calculate_center_vertex): the centre of mass of the eight corners with weights
         // 1 / (eps + |v|), summed in Lewiner's corner order (0 .. 7) in double, stored as float32
-        const float* c = tsdf + i;
+        const float* c = tsdf + i * VS;
         double ff = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll 1  // (rare: a rolled loop keeps the kernel's registers where they were without the centre vertex)
         for (int q = 0; q < 8; ++q) {  // Lewiner's corner q sits at (a0, a1, a2) = (q >> 2, q >> 1 & 1, (q ^ q >> 1) & 1)
           const int a0 = q >> 2, a1 = (q >> 1) & 1, a2 = (q ^ (q >> 1)) & 1;
-          const double w = 1.0 / (LT_MC_EPS + fabs((double)c[(size_t)a0 * sx + (size_t)a1 * sy + (size_t)a2]));
+          const double w = 1.0 / (LT_MC_EPS + fabs((double)c[((size_t)a0 * sx + (size_t)a1 * sy + (size_t)a2) * VS]));
           ff += w;
           if (a2) f2 += w;
           if (a1) f1 += w;
           if (a0) f0 += w;
         }
         p0 = (float)((double)x + f0 / ff); p1 = (float)((double)y + f1 / ff); p2 = (float)((double)z + f2 / ff);
+        // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409).
+        // The vertex lies inside a cell (below: on an edge) that starts at voxel (x, y, z): every rounded coordinate is
+        // the voxel's or the next one's, and the next one exists where the cell / the edge does.  (Anything else -- a NaN
+        // field value, on which numpy would raise -- counts as "the next one": never a wild address.)
+        const size_t jj = i + ((int)rintf(p0) == x ? (size_t)0 : sx) + ((int)rintf(p1) == y ? (size_t)0 : sy) +
+                          ((int)rintf(p2) == z ? (size_t)0 : (size_t)1);
+        rgb = color_vol[jj * VS];
+        rm = rem_vol[jj * VS];
       } else {
-        const float v0 = tsdf[i];
-        const float v1 = tsdf[i + (a == 0 ? sx : (a == 1 ? sy : (size_t)1))];
-        const float pe = mc_edge_coord(a == 0 ? x : (a == 1 ? y : z), v0, v1);
-        if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+        const size_t i1 = i + (a == 0 ? sx : (a == 1 ? sy : (size_t)1));
+        const int ce = a == 0 ? x : (a == 1 ? y : z);
+        if (AOS) {
+          const float4 q0 = reinterpret_cast<const float4*>(tsdf)[i], q1 = reinterpret_cast<const float4*>(tsdf)[i1];
+          const float pe = mc_edge_coord(ce, q0.x, q1.x);
+          if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+          const bool far_end = (int)rintf(pe) != ce;
+          rgb = far_end ? q1.z : q0.z;
+          rm = far_end ? q1.w : q0.w;
+        } else {
+          const float pe = mc_edge_coord(ce, tsdf[i], tsdf[i1]);
+          if (a == 0) p0 = pe; else if (a == 1) p1 = pe; else p2 = pe;
+          const size_t jj = (int)rintf(pe) != ce ? i1 : i;
+          rgb = color_vol[jj];
+          rm = rem_vol[jj];
+        }
       }
-      // verts_ind = np.round(verts).astype(int) on the float32 coordinates (fusion_lidar.py:409)
-      // (clamped: a NaN field value must not become a wild address; numpy would raise there)
-      // The vertex lies on an edge (or inside a cell) that starts at voxel (x, y, z): every rounded coordinate is the
-      // voxel's or the next one's, and the next one exists where the edge / the cell does.  (Anything else -- a NaN field
-      // value, on which numpy would raise -- counts as "the next one": never a wild address.)
-      const size_t jj = i + ((int)rintf(p0) == x ? (size_t)0 : sx) + ((int)rintf(p1) == y ? (size_t)0 : sy) +
-                        ((int)rintf(p2) == z ? (size_t)0 : (size_t)1);
-      const float rgb = color_vol[jj];
-      const float rm = rem_vol[jj];
       const int vid = vbase0 + vb + j;
       if (vid < cap_v) {
         verts[3 * (size_t)vid] = p0 * voxel_size + ox;  // verts * voxel_size + vol_origin in float32 (:412)
@@ -1245,7 +1263,7 @@ static int mc_grow(T** p, size_t* cap, size_t need) {
   return LT_OK;
 }
 
-static int mc_extract(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny, int nz,
+static int mc_extract(const float* tsdf, const float* color_vol, const float* rem_vol, int vs, int nx, int ny, int nz,
                       float voxel_size, const float* origin, lt_mesh* m, void* stream_, float* ms,
                       const unsigned* col_epoch, unsigned epoch, const u64* ext_bits, const unsigned* chunk_epoch) {
   if (!tsdf || !color_vol || !rem_vol || !origin || !m || nx <= 0 || ny <= 0 || nz <= 0) {
@@ -1265,7 +1283,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     return LT_OK;
   }
   mc_dims D;
-  D.nx = nx; D.ny = ny; D.nz = nz;
+  D.nx = nx; D.ny = ny; D.nz = nz; D.vs = vs;
   D.wz = (nz + 63) / 64;
   mc_magic((unsigned)D.wz, &D.wz_m, &D.wz_s);
   mc_magic((unsigned)D.ny, &D.ny_m, &D.ny_s);
@@ -1362,7 +1380,7 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     (void)hipFree(m->amb.queue); (void)hipFree(m->amb.table);
     m->amb.queue = nullptr; m->amb.table = nullptr;
     m->amb_cap = need + need / 4 + 1024;
-    return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, col_epoch, epoch, ext_bits, chunk_epoch);
+    return mc_extract(tsdf, color_vol, rem_vol, vs, nx, ny, nz, voxel_size, origin, m, stream_, ms, col_epoch, epoch, ext_bits, chunk_epoch);
   }
   const int n_active = m->totals_host[0], nv = m->totals_host[1], nf = m->totals_host[2];
   static const bool dbg_mc = getenv("LIDARHIP_DEBUG_MC") != nullptr;
@@ -1425,11 +1443,12 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
     // LIDARHIP_MC_EMIT_XCD=0: batches dealt to the waves round-robin over the whole list (rounds 3-4)
     static const int env_xcd = []() { const char* e = getenv("LIDARHIP_MC_EMIT_XCD"); return e ? atoi(e) : 64; }();
     auto grid = [&](int k) { return dim3((unsigned)((min((n_active + k - 1) / k, max_waves) + LT_MC_EW - 1) / LT_MC_EW)); };
-    const int xcd_map = (env_xcd > 0 && (int)grid(kk >= 16 ? 16 : kk >= 8 ? 8 : kk >= 4 ? 4 : 2).x * LT_MC_EW >= 64) ? env_xcd : 0;
-    if (kk >= 16) hipLaunchKernelGGL(k_mc_emit_batch<16>, grid(16), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 8) hipLaunchKernelGGL(k_mc_emit_batch<8>, grid(8), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
-    else if (kk >= 4) hipLaunchKernelGGL(k_mc_emit_batch<4>, grid(4), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
-    else hipLaunchKernelGGL(k_mc_emit_batch<2>, grid(2), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    const int xcd_map = (env_xcd > 0 && (int)grid(vs == 4 ? 8 : kk >= 16 ? 16 : kk >= 8 ? 8 : kk >= 4 ? 4 : 2).x * LT_MC_EW >= 64) ? env_xcd : 0;
+    if (vs == 4) hipLaunchKernelGGL((k_mc_emit_batch<8, true>), grid(8), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 16) hipLaunchKernelGGL((k_mc_emit_batch<16, false>), grid(16), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 8) hipLaunchKernelGGL((k_mc_emit_batch<8, false>), grid(8), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else if (kk >= 4) hipLaunchKernelGGL((k_mc_emit_batch<4, false>), grid(4), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
+    else hipLaunchKernelGGL((k_mc_emit_batch<2, false>), grid(2), dim3(64 * LT_MC_EW), 0, stream, LT_MC_EMIT_ARGS);
   }
 #undef LT_MC_EMIT_ARGS
   LT_HIP(hipGetLastError());
@@ -1620,7 +1639,7 @@ extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, fl
     return LT_ERR_INVALID_ARG;
   }
   // the volume knows which columns were written since its last reset: the others are not read
-  return mc_extract(t->tsdf, t->color, t->rem, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m, stream, ms,
+  return mc_extract(t->tsdf, t->color, t->rem, 4 /* LT_VOX records */, t->dim[0], t->dim[1], t->dim[2], t->voxel_size, t->origin, m, stream, ms,
                     t->all_dirty ? nullptr : t->col_epoch, t->epoch, t->all_dirty ? nullptr : t->bits,
                     t->all_dirty ? nullptr : t->chunk_epoch);
 }
@@ -1628,7 +1647,7 @@ extern "C" int lt_tsdf_extract_mesh_dev(lt_tsdf* t, lt_mesh* m, void* stream, fl
 extern "C" int lt_marching_cubes_dev(const float* tsdf, const float* color_vol, const float* rem_vol, int nx, int ny,
                                      int nz, float voxel_size, const float* origin, lt_mesh* m, void* stream_,
                                      float* ms) {
-  return mc_extract(tsdf, color_vol, rem_vol, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u, nullptr, nullptr);
+  return mc_extract(tsdf, color_vol, rem_vol, 1, nx, ny, nz, voxel_size, origin, m, stream_, ms, nullptr, 0u, nullptr, nullptr);
 }
 
 extern "C" int lt_scene_set_mesh(lt_scene* s, lt_mesh* m) {

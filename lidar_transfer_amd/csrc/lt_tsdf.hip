@@ -48,14 +48,15 @@
 #define LT_ZW_LO(a) (0x7FFF - (int)(a))
 #define LT_ZW_HI(b) ((int)(b) - 1)
 
-__global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, float* __restrict__ weight,
-                                                   float* __restrict__ color, float* __restrict__ rem, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    tsdf[i] = 1.0f;  // np.ones (fusion_lidar.py:47)
-    weight[i] = 0.0f;
-    color[i] = 0.0f;
-    rem[i] = 0.0f;
-  }
+// The volume is ONE array of float4 per voxel -- (tsdf, weight, colour, remission), [x][y][z] -- not the reference's four
+// arrays: an update is one 16-byte read-modify-write instead of four 4-byte ones in four places (a z run of ~10 written
+// voxels was 2-3 32-byte sectors in each of four arrays: 3.3 x the bytes of the voxels), and marching cubes finds a
+// vertex's field samples and its attributes in the two lines it reads anyway.  The kernels keep their four pointer
+// arguments (base, base + 1, base + 2, base + 3: what lt_tsdf_volumes hands out, stride 4); only LT_VOX touches memory.
+#define LT_VOX(tsdf_base, idx) (reinterpret_cast<float4*>(tsdf_base) + (idx))
+__global__ __launch_bounds__(256) void k_tsdf_fill(float4* __restrict__ vol, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    vol[i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // np.ones / np.zeros (fusion_lidar.py:47-51)
 }
 
 // the update of one voxel (fusion_lidar.py:178-228); returns what
@@ -64,17 +65,17 @@ __global__ __launch_bounds__(256) void k_tsdf_fill(float* __restrict__ tsdf, flo
 // `fresh`: the voxel's column has not been written since the last reset, so the old values are the initial ones
 // (tsdf 1, weight 0, colour 0, remission 0) and need not be loaded
 template <bool MERGE>
-__device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ weight_vol,
-                                            float* __restrict__ color_vol, float* __restrict__ rem_vol, int voxel_idx,
+__device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* __restrict__ /*weight_vol*/,
+                                            float* __restrict__ /*color_vol*/, float* __restrict__ /*rem_vol*/, int voxel_idx,
                                             float dist, float obs_weight, float new_color, float new_rem,
                                             bool fresh = false) {
+  float4* const vox = LT_VOX(tsdf_vol, voxel_idx);
+  const float4 o = fresh ? make_float4(1.0f, 0.0f, 0.0f, 0.0f) : *vox;  // (tsdf, weight, colour, remission)
   if (!MERGE) {
-    const float w_old = fresh ? 0.0f : weight_vol[voxel_idx];
+    const float w_old = o.y;
     const float w_new = w_old + obs_weight;
-    weight_vol[voxel_idx] = w_new;
-    const float tv = __fmaf_rn(fresh ? 1.0f : tsdf_vol[voxel_idx], w_old, dist) / w_new;
-    tsdf_vol[voxel_idx] = tv;
-    const float old_color = fresh ? 0.0f : color_vol[voxel_idx];
+    const float tv = __fmaf_rn(o.x, w_old, dist) / w_new;
+    const float old_color = o.z;
     const float old_b = floorf(old_color / (256 * 256));
     const float old_g = floorf((old_color - old_b * 256 * 256) / 256);
     const float old_r = old_color - old_b * 256 * 256 - old_g * 256;
@@ -84,27 +85,22 @@ __device__ __forceinline__ int tsdf_update(float* __restrict__ tsdf_vol, float* 
     new_b = fminf(roundf(__fmaf_rn(old_b, w_old, new_b) / w_new), 255.0f);
     new_g = fminf(roundf(__fmaf_rn(old_g, w_old, new_g) / w_new), 255.0f);
     new_r = fminf(roundf(__fmaf_rn(old_r, w_old, new_r) / w_new), 255.0f);
-    color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
-    rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
+    *vox = make_float4(tv, w_new, new_b * 256 * 256 + new_g * 256 + new_r, __fmaf_rn(o.w, w_old, new_rem) / w_new);
     return !(tv > 0.0f) ? 2 : 1;
   } else {
-    const float dist_old = fresh ? 0.0f : weight_vol[voxel_idx];  // sic: the reference compares against the weight volume
-    const float old_color = fresh ? 0.0f : color_vol[voxel_idx];
-    if (old_color == new_color) {  // same class: integrate
-      const float w_old = fresh ? 0.0f : weight_vol[voxel_idx];
+    const float dist_old = o.y;  // sic: the reference compares against the weight volume
+    const float old_color = o.z;
+    if (old_color == new_color) {  // same class: integrate (the colour stays)
+      const float w_old = o.y;
       const float w_new = w_old + obs_weight;
-      weight_vol[voxel_idx] = w_new;
-      const float tv = __fmaf_rn(fresh ? 1.0f : tsdf_vol[voxel_idx], w_old, dist) / w_new;
-      tsdf_vol[voxel_idx] = tv;
-      rem_vol[voxel_idx] = __fmaf_rn(fresh ? 0.0f : rem_vol[voxel_idx], w_old, new_rem) / w_new;
+      const float tv = __fmaf_rn(o.x, w_old, dist) / w_new;
+      *vox = make_float4(tv, w_new, o.z, __fmaf_rn(o.w, w_old, new_rem) / w_new);
       return !(tv > 0.0f) ? 2 : 1;
-    } else if (dist < dist_old) {  // other class: the closer observation wins
-      tsdf_vol[voxel_idx] = dist;
+    } else if (dist < dist_old) {  // other class: the closer observation wins (the weight stays)
       const float new_b = floorf(new_color / (256 * 256));
       const float new_g = floorf((new_color - new_b * 256 * 256) / 256);
       const float new_r = new_color - new_b * 256 * 256 - new_g * 256;
-      color_vol[voxel_idx] = new_b * 256 * 256 + new_g * 256 + new_r;
-      rem_vol[voxel_idx] = new_rem;
+      *vox = make_float4(dist, o.y, new_b * 256 * 256 + new_g * 256 + new_r, new_rem);
       return !(dist > 0.0f) ? 2 : 1;
     }
     return 0;
@@ -598,10 +594,7 @@ __global__ __launch_bounds__(256) void k_tsdf_reset_cols(float* __restrict__ tsd
       const int z0 = (int)(r & 0xFFFFu), z1 = min((int)(r >> 16), dim_z - 1);
       const size_t base = (size_t)(chunk * 64 + bit) * dim_z;
       for (int z = z0 + gl; z <= z1; z += 16) {
-        tsdf[base + z] = 1.0f;
-        weight[base + z] = 0.0f;
-        color[base + z] = 0.0f;
-        rem[base + z] = 0.0f;
+        *LT_VOX(tsdf, base + z) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
       }
     }
   }
@@ -714,12 +707,18 @@ __device__ __forceinline__ void col_mark_written(unsigned* __restrict__ col_zw, 
 // 5 m four voxels altogether -- 368 us with two waves per SIMD, most lanes idle; colour-0 pixels, whose run is the wedge up
 // to the band, are simply long runs here)
 #define LT_PIX_CHUNK 512    // pairs per chunk (two per thread)
-#define LT_PIX_AGG 1024     // table entries whose written ranges a workgroup merges in LDS before it touches col_zw
+#ifndef LT_PIX_AGG
+#define LT_PIX_AGG 1024
+#endif
+// LT_PIX_AGG: table entries whose written ranges a workgroup merges in LDS before it touches col_zw
 #define LT_PIX_STAGE 3840   // rho quanta staged in LDS for the binary searches (a wedge of the default volume: 2000 - 3900);
                             // 15 KB: with the other arrays 19.5 KB per workgroup = EIGHT per CU -- the 2048 workgroups of a
                             // 64 x 2048 image are resident at once (at 4096 entries, seven per CU: a second round)
+#ifndef LT_PIX_WPE
+#define LT_PIX_WPE 5
+#endif
 template <bool MERGE, bool VCOUNT>
-__global__ __launch_bounds__(256) void k_tsdf_integrate_pix(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_PIX_WPE, 8))) void k_tsdf_integrate_pix(
     float* __restrict__ tsdf_vol, float* __restrict__ weight_vol, float* __restrict__ color_vol,
     float* __restrict__ rem_vol, int vol_dim_x, int vol_dim_y, int vol_dim_z, float ox, float oy, float oz,
     float voxel_size, float inv_vs, int im_h, int im_w, float trunc_margin, float obs_weight, float fov_up,
@@ -1089,10 +1088,7 @@ __device__ __forceinline__ int tsdf_updates_fresh(float* __restrict__ tsdf_vol, 
     }
   }
   if (!written) return 0;
-  tsdf_vol[voxel_idx] = tv;
-  weight_vol[voxel_idx] = wv;
-  color_vol[voxel_idx] = cv;
-  rem_vol[voxel_idx] = rv;
+  *LT_VOX(tsdf_vol, voxel_idx) = make_float4(tv, wv, cv, rv);
   return !(tv > 0.0f) ? 2 : 1;
 }
 
@@ -1633,7 +1629,7 @@ extern "C" int lt_tsdf_destroy(lt_tsdf* t) {
   if (!t) return LT_OK;
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {t->tsdf, t->weight, t->color, t->rem, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
+  void* ps[] = {t->tsdf, t->col_epoch, t->colinfo, t->colmax, t->bits, t->col_zw, t->dct,
                 t->wd_px, t->wd_start, t->wd_ent, t->wd_key, t->wd_qcols, t->rowtab, t->zw_snap, t->chunk_epoch, t->obs4};
   for (void* p : ps)
     if (p) (void)hipFree(p);
@@ -1660,7 +1656,7 @@ static col_geom tsdf_geom(const lt_tsdf* t) {
 }
 
 static int tsdf_full_reset(lt_tsdf* t, hipStream_t stream) {
-  hipLaunchKernelGGL(k_tsdf_fill, dim3(4096), dim3(256), 0, stream, t->tsdf, t->weight, t->color, t->rem, t->n);
+  hipLaunchKernelGGL(k_tsdf_fill, dim3(4096), dim3(256), 0, stream, reinterpret_cast<float4*>(t->tsdf), t->n);
   LT_HIP(hipMemsetAsync(t->col_epoch, 0, (size_t)t->dim[0] * t->dim[1] * sizeof(unsigned), stream));
   LT_HIP(hipMemsetAsync(t->bits, 0, (size_t)t->dim[0] * t->dim[1] * ((t->dim[2] + 63) / 64) * sizeof(unsigned long long),
                         stream));
@@ -1734,14 +1730,13 @@ extern "C" int lt_tsdf_create(lt_tsdf** out, const double* vol_bnds, double voxe
   t->trunc_margin = (float)(voxel_size * 5);  // fusion_lidar.py:31
   t->fov_up_deg = fov_up;
   t->fov_down_deg = fov_down;
-  float** ps[] = {&t->tsdf, &t->weight, &t->color, &t->rem};
-  for (float** p : ps) {
-    if (hipMalloc((void**)p, t->n * sizeof(float)) != hipSuccess) {
-      lt_set_error("lt_tsdf_create: hipMalloc of %zu bytes failed", t->n * sizeof(float));
-      lt_tsdf_destroy(t);
-      return LT_ERR_NO_MEMORY;
-    }
+  if (hipMalloc((void**)&t->tsdf, t->n * sizeof(float4)) != hipSuccess) {  // one float4 per voxel (LT_VOX)
+    lt_set_error("lt_tsdf_create: hipMalloc of %zu bytes failed", t->n * sizeof(float4));
+    t->tsdf = nullptr;
+    lt_tsdf_destroy(t);
+    return LT_ERR_NO_MEMORY;
   }
+  t->weight = t->tsdf + 1; t->color = t->tsdf + 2; t->rem = t->tsdf + 3;  // (the fields of voxel 0; stride 4)
   const size_t n_cols = (size_t)t->dim[0] * t->dim[1];
   if (hipMalloc((void**)&t->col_epoch, n_cols * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void**)&t->colinfo, (3 * n_cols + (n_cols + 63) / 64 + 64) * sizeof(int)) != hipSuccess ||  // + one flag per chunk, colz, colrho2
@@ -1906,7 +1901,7 @@ static int tsdf_integrate_pix(lt_tsdf* t, const float* color_im, const float* de
   // workgroups then walk the groups of 64 in turn, so that the launch is ONE round of resident workgroups
   // (LIDARHIP_PIX_WGS=n: n workgroups; =0: one per 64 pixels)
   static const int env_wgs = []() { const char* e = getenv("LIDARHIP_PIX_WGS"); return e ? atoi(e) : -1; }();
-  const int res_wgs = lt_cu_count(t->device) * 5;
+  const int res_wgs = lt_cu_count(t->device) * LT_PIX_WPE;
   const int groups = (n_pix + 63) / 64;
   const unsigned nb = (unsigned)min(groups, env_wgs > 0 ? env_wgs : (env_wgs == 0 ? (1 << 20) : res_wgs));
   const unsigned* zw_snap = nullptr;
@@ -1983,12 +1978,13 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_host_mode(
   const double depth_diff = depth_val - depth;
   if (!(depth_val > 0.0 && depth_diff >= -trunc_margin)) return;
   const double dist = fmin(1.0, depth_diff / trunc_margin);
-  const float w_old = weight_vol[v];
+  float4* const vox = LT_VOX(tsdf_vol, v);
+  const float4 o = *vox;  // (tsdf, weight, colour, remission -- which this branch of the reference never touches)
+  const float w_old = o.y;
   const float w_new = w_old + obs_weight;
-  weight_vol[v] = w_new;
-  const float tw = tsdf_vol[v] * w_old;
-  tsdf_vol[v] = (float)(((double)tw + dist) / (double)w_new);
-  const float old_color = color_vol[v];
+  const float tw = o.x * w_old;
+  const float tv_new = (float)(((double)tw + dist) / (double)w_new);
+  const float old_color = o.z;
   const float old_b = floorf(old_color / 65536.0f);
   const float old_g = floorf((old_color - old_b * 256.0f * 256.0f) / 256.0f);
   const float old_r = old_color - old_b * 256.0f * 256.0f - old_g * 256.0f;
@@ -1999,7 +1995,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_host_mode(
   new_b = fminf(rintf((old_b * w_old + new_b) / w_new), 255.0f);
   new_g = fminf(rintf((old_g * w_old + new_g) / w_new), 255.0f);
   new_r = fminf(rintf((old_r * w_old + new_r) / w_new), 255.0f);
-  color_vol[v] = new_b * 256.0f * 256.0f + new_g * 256.0f + new_r;
+  *vox = make_float4(tv_new, w_new, new_b * 256.0f * 256.0f + new_g * 256.0f + new_r, o.w);
 }
 
 extern "C" int lt_tsdf_integrate_dev(lt_tsdf* t, const float* color_im, const float* depth_im, const float* rem_im,
@@ -2198,12 +2194,14 @@ extern "C" int lt_tsdf_volumes(lt_tsdf* t, int* dims, float* origin, float** tsd
     if (dims) dims[k] = t->dim[k];
     if (origin) origin[k] = t->origin[k];
   }
-  if (tsdf) *tsdf = t->tsdf;
+  if (tsdf) *tsdf = t->tsdf;      // the fields of voxel 0: voxel v's are LT_VOLUME_STRIDE * v floats further (LT_VOX)
   if (weight) *weight = t->weight;
   if (color) *color = t->color;
   if (rem) *rem = t->rem;
   return LT_OK;
 }
+
+extern "C" int lt_tsdf_volume_stride(void) { return 4; }
 
 // debug helper (not part of the documented ABI): {pairs, candidate voxels, written voxels} of the last pixel-centric
 // integrate (LIDARHIP_DEBUG_TSDF=1)

@@ -266,7 +266,9 @@ class TSDFVolume:
                 o["range"].cpu().numpy().reshape(-1, W), o["endrem"].cpu().numpy().reshape(-1, W))
 
     def get_volume_tensors(self):
-        """Zero-copy ``torch`` views of the four device volumes (tsdf, weight, color, rem)."""
+        """Zero-copy ``torch`` views ``[dx, dy, dz]`` of the four device volumes (tsdf, weight, color, rem).  The library keeps
+        ONE record of the four fields per voxel (``lt_tsdf_volume_stride()`` floats apart): the views are strided, reads and
+        writes (``copy_``, indexing; then :meth:`touch`) go straight to the volume; ``.contiguous()`` for a packed copy."""
         torch, C = self._torch, self._C
         dims = (C.c_int * 3)()
         org = (C.c_float * 3)()
@@ -274,10 +276,11 @@ class TSDFVolume:
         self._libmod.check(self._lib.lt_tsdf_volumes(self._h, dims, org, *[C.byref(p) for p in ptrs]),
                            "lt_tsdf_volumes")
         n = int(dims[0]) * int(dims[1]) * int(dims[2])
-        out = []
-        for p in ptrs:
-            out.append(_wrap_device_pointer(torch, p.value, n, self.device).view(int(dims[0]), int(dims[1]), int(dims[2])))
-        return out
+        vs = int(self._lib.lt_tsdf_volume_stride())
+        if [p.value for p in ptrs] != [ptrs[0].value + 4 * k for k in range(4)] or vs != 4:
+            raise RuntimeError("lt_tsdf_volumes: not the interleaved layout this binding was written for")
+        rec = _wrap_device_pointer(torch, ptrs[0].value, n * vs, self.device).view(int(dims[0]), int(dims[1]), int(dims[2]), vs)
+        return [rec[..., k] for k in range(4)]
 
 
 class DeviceMesh:

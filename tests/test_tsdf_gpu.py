@@ -189,7 +189,8 @@ if os.environ.get("LT_TEST_TSDF") == "dense":
         c = dev(color_im)
         folded = torch.floor(c[:, :, 0] * 256 * 256 + c[:, :, 1] * 256 + c[:, :, 2]).contiguous()   # fusion_lidar.py:261-264
         d, r = dev(depth_im), dev(rem_im)
-        t, w, cv, rv = vol.get_volume_tensors()
+        views = vol.get_volume_tensors()          # strided views of the volume's (tsdf, weight, colour, remission) records
+        t, w, cv, rv = [x.contiguous() for x in views]   # the oracle kernel works on four packed arrays, as the reference does
         dims = (C.c_int * 3)(*[int(x) for x in t.shape])
         org = (C.c_float * 3)(*[float(x) for x in vol._vol_origin])
         vp = C.c_void_p
@@ -198,6 +199,8 @@ if os.environ.get("LT_TEST_TSDF") == "dense":
                                                 vp(folded.data_ptr()), vp(d.data_ptr()), vp(r.data_ptr()), H, W,
                                                 C.c_float(obs_weight), 1 if merge else 0, vp(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
+        for dst, src in zip(views, (t, w, cv, rv)):
+            dst.copy_(src)
         torch.cuda.synchronize()
         vol.touch()   # written without column stamps: reset / extraction must take every column for written
     vol.integrate = integrate_dense
