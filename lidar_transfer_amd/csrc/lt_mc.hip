@@ -750,11 +750,23 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
   live &= live - 1;
   const int row = blkid * 64 + lane;
   unsigned na = 0, nv = 0, nt = 0;
-  if (row < n_rows)
-    for (int k = 0; k < D.wz; ++k) {
-      const unsigned c = cnt[(size_t)row * D.wz + k];
-      na += c ? 1u : 0u; nv += c & 0xFFFFu; nt += c >> 16;
+  // the row's counts: up to four words ALL loaded before the first is used and kept for the loop below (a rolled loop
+  // waited for every load before it issued the next, twice: eight dependent round trips per block of rows)
+  const bool few = D.wz <= 4;  // (wave-uniform)
+  unsigned c4[4] = {0u, 0u, 0u, 0u};
+  if (row < n_rows) {
+    if (few) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c4[k] = k < D.wz ? cnt[(size_t)row * D.wz + k] : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { na += c4[k] ? 1u : 0u; nv += c4[k] & 0xFFFFu; nt += c4[k] >> 16; }
+    } else {
+      for (int k = 0; k < D.wz; ++k) {
+        const unsigned c = cnt[(size_t)row * D.wz + k];
+        na += c ? 1u : 0u; nv += c & 0xFFFFu; nt += c >> 16;
+      }
     }
+  }
   const u64 mine = pack3(na, nv, nt);
   const u64 ex = wave_incl_scan(mine) - mine;
   if (row >= n_rows) continue;
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(256) void k_mc_compact(const u64* __restrict__ bits
   const int x = mc_x_of(D, row), y = row - x * D.ny;
   for (int k = 0; k < D.wz; ++k) {
     const int w = row * D.wz + k;
-    const unsigned c = cnt[w];
+    const unsigned c = few ? (k == 0 ? c4[0] : k == 1 ? c4[1] : k == 2 ? c4[2] : c4[3]) : cnt[w];
     int mine_ci = -1;
     if (c) {
       if (ci < cap_rec) {
