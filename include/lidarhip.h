@@ -319,7 +319,7 @@ int lt_range_projection_batch_dev(lt_projector* projector, int n_clouds, const l
 
 /* ---- before the render: class-aware TSDF fusion of range images (device-resident volumes) -------- */
 
-typedef struct lt_tsdf lt_tsdf; /* opaque: four float32 volumes [dim_x][dim_y][dim_z] (tsdf, weight, colour, rem) */
+typedef struct lt_tsdf lt_tsdf; /* opaque: one (tsdf, weight, colour, rem) float32 record per voxel, [dim_x][dim_y][dim_z] */
 
 #define LT_TSDF_MERGE 1u /* class-aware update, the branch the reference runs (fusion_lidar.py:177, :191-228) */
 /* the reference's numpy branch of `integrate` (FUSION_GPU_MODE == 0: what it runs without pycuda, fusion_lidar.py:290-388):

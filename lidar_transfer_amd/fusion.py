@@ -77,7 +77,7 @@ class TSDFVolume:
     """Device-resident mirror of the reference's ``TSDFVolume`` fusion part
     (auxiliary/fusion_lidar.py:21-63 constructor, :252-287 ``integrate``, :395-400 ``get_volume``).
 
-    Same constructor and ``integrate`` signature; the four volumes live in HBM (``lt_tsdf``) and every
+    Same constructor and ``integrate`` signature; the four fields live in HBM, one record per voxel (``lt_tsdf``) and every
     ``integrate`` is one launch of the HIP kernel -- no per-launch image round trip, no grid loop.
     ``merge=True`` (default) is the class-aware branch the reference's CUDA kernel runs; ``mode="numpy"`` selects the
     arithmetic of the reference's OTHER fusion mode instead -- its numpy branch (``FUSION_GPU_MODE == 0``, what it runs where

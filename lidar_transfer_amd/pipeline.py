@@ -293,7 +293,7 @@ class FusionScanPipeline:
     (laserscan.py:874-903), ``get_mesh`` (fusion_lidar.py:403-424), ``throw_rays_at_mesh`` (:426-455) -- entirely in HBM
     and with ``chains`` output scans IN FLIGHT: output scans are independent (own volume, mesh and image,
     lidar_deform.py:393-462), the chain's kernels are mostly sparse sweeps that leave the chip half empty (DESIGN.md
-    section 7c), and 4 x 3.2 GB per default volume is nothing in 288 GB.  Every chain owns a :class:`TSDFVolume`, a
+    section 7c), and 12.8 GB per default volume is nothing in 288 GB.  Every chain owns a :class:`TSDFVolume`, a
     :class:`DeviceMesh`, a :class:`Scene`, a HIP stream and a host thread; scans are dealt to the chains in turn.
 
         pipe = FusionScanPipeline(vol_bnds, voxel_size, fov_up, fov_down, rays, H)   # source fov; target rays [H*W,3] CUDA
