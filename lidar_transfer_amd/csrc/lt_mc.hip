@@ -820,7 +820,7 @@ __device__ __forceinline__ float mc_edge_coord(int c, float v1, float v2) {
 // kernel's 265 us (more words per wave or a lane per word change nothing: 272 / 332 us measured).  Here a wave takes K
 // words, lists their vertices and triangles in LDS (in output order: the lists ARE the output ranges, a batch's words
 // are consecutive), and then lane j computes vertex j / triangle j: every lane live, every store coalesced.
-// LDS decides how many batches a CU holds, in granules of 1 280 B per WORKGROUP (tools/occ_probe.hip fine): the 29 968 B of
+// LDS decides how many batches a CU holds, in granules of 1 280 B per WORKGROUP (tools/occ_probe.hip fine): the 30 224 B of
 // four waves are 24 granules = 5 workgroups = 20 waves per CU (one-wave workgroups of 7 752 B held 18).  Six workgroups
 // (<= 26 880 B and <= 80 registers: lists of 128, the tiling table back in global memory) were built and measured: 90 us
 // against 80 -- a batch is ~1 400 instructions (924 vector: staging 155, cells 222, vertices 283, triangles 263,
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64 * LT_MC_EW) void k_mc_emit_batch(const float* __
   // LT_MC_EW waves per workgroup, each with arrays of its own and no business with the others: what would be a workgroup
   // barrier orders ONE wave's LDS accesses, which the hardware executes in order anyway -- LT_MC_WSYNC only keeps the
   // compiler from moving them.  (Four waves instead of one per workgroup change nothing by themselves -- 82.7 us both;
-  // they share the tiling table below, 256 B of LDS per wave instead of 1 KB: 80 us.)
+  // they share the tiling table below, 256 B of LDS per wave instead of 1 KB: 80 us; 75 on a volume of records, AOS.)
   __shared__ mc_rec S_rec[LT_MC_EW][K];
   __shared__ int S_xyz[LT_MC_EW][K][3];       // x, y, wz of the words
   __shared__ size_t S_base[LT_MC_EW][K];      // ... and the voxel index of their first voxel
@@ -1442,8 +1442,8 @@ static int mc_extract(const float* tsdf, const float* color_vol, const float* re
   if (n_active > 0) {
     static const int kk = []() { const char* e = getenv("LIDARHIP_MC_EMIT_K"); return e ? atoi(e) : 8; }();
     // The grid: persistent waves taking batches in turn (bi += gridDim), 36 per CU -- 1.8 x the resident capacity (20 waves
-    // per CU, see LT_MC_VCAP; swept again with four-wave workgroups: 24 / 36 / 48 / 72 / 96 per CU = 118 / 90 / 100 / 92 / 102 us
-    // on the six-workgroup variant, the same order on this one).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on
+    // per CU, see LT_MC_VCAP; swept again with four-wave workgroups on the six-workgroup variant: 24 / 36 / 48 / 72 / 96 per
+    // CU = 118 / 90 / 100 / 92 / 102 us).  On the default volume's street scene (31 500 batches; a batch lives 8.3 us on
     // average and up to 42, tools/mc_wave_times.py): a wave per batch 96 us -- a wave's start and drain 31 500 times --,
     // 4 608 / 9 216 / 18 432 persistent waves 107 / 87 / 86 us (static dealing is at the mercy of the heavy batches: with
     // one round of waves the slowest wave is the kernel), and persistent waves DRAWING their batches from eight counters

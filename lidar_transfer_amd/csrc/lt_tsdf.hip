@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_PIX_WPE,
 #endif
       if (staged)
       {  // all loads first, then the LDS stores: the rolled loop waited for every load before it issued the next
-        // (up to 15 dependent round trips: 10 of an item's ~20 us)
+        // (up to 15 dependent round trips; phase A 6.6 -> 5.8 us of an item's ~20 together with the hoisted loads above)
         constexpr int NS = (LT_PIX_STAGE + 255) / 256;
         uint32_t sv[NS];
 #pragma unroll
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_pix_multi(
 #endif
       if (staged)
       {  // all loads first, then the LDS stores: the rolled loop waited for every load before it issued the next
-        // (up to 15 dependent round trips: 10 of an item's ~20 us)
+        // (up to 15 dependent round trips, as in k_tsdf_integrate_pix)
         constexpr int NS = (LT_PIX_STAGE + 255) / 256;
         uint32_t sv[NS];
 #pragma unroll
