@@ -874,28 +874,40 @@ __global__ __launch_bounds__(256) void k_sc_resolve(const sc_batch B) {
   bool hit = false;
   if (ray < J.n_rays) {
     const unsigned long long key = cell[ray];
+    const float4 d = J.dirs[ray];  // (does not wait for the key: issued with it)
     cell[ray] = LT_EMPTY_KEY;
     hit = key != LT_EMPTY_KEY;
     if (hit) {
       const float t = __uint_as_float((unsigned)(key >> 32));
       const int face = (int)(unsigned)(key & 0xFFFFFFFFull);
-      const float4 d = J.dirs[ray];
       const int i0 = faces[3 * (size_t)face], i1 = faces[3 * (size_t)face + 1], i2 = faces[3 * (size_t)face + 2];
+      // everything the images need is loaded BEFORE the first store: with the stores in between the compiler waited for
+      // each attribute in turn -- key, face, colour, remission were four dependent round trips, three are needed
+      const int* __restrict__ colors = J.colors;
+      const float* __restrict__ rem = J.rem;
+      const bool label = (flags & LT_TRACE_LABEL_IMAGE) != 0;  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
+      int c0 = 0, c1 = 0, c2 = 0;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+      if (endcolors) {
+        c2 = colors[3 * (size_t)i0 + 2];
+        if (!label) { c0 = colors[3 * (size_t)i0]; c1 = colors[3 * (size_t)i0 + 1]; }
+      }
+      if (endrem) { r0 = rem[i0]; r1 = rem[i1]; r2 = rem[i2]; }
       if (endpoints) {
         endpoints[3 * (size_t)ray] = J.ox + d.x * t;
         endpoints[3 * (size_t)ray + 1] = J.oy + d.y * t;
         endpoints[3 * (size_t)ray + 2] = J.oz + d.z * t;
       }
       if (endcolors) {
-        if (flags & LT_TRACE_LABEL_IMAGE) {  // deform's unpack label_image = ray_colors[..., 2], laserscan.py:912
-          endcolors[ray] = (int)(float)J.colors[3 * (size_t)i0 + 2];
+        if (label) {
+          endcolors[ray] = (int)(float)c2;
         } else {
-          endcolors[3 * (size_t)ray] = (int)(float)J.colors[3 * (size_t)i0];
-          endcolors[3 * (size_t)ray + 1] = (int)(float)J.colors[3 * (size_t)i0 + 1];
-          endcolors[3 * (size_t)ray + 2] = (int)(float)J.colors[3 * (size_t)i0 + 2];
+          endcolors[3 * (size_t)ray] = (int)(float)c0;
+          endcolors[3 * (size_t)ray + 1] = (int)(float)c1;
+          endcolors[3 * (size_t)ray + 2] = (int)(float)c2;
         }
       }
-      if (endrem) endrem[ray] = ((J.rem[i0] + J.rem[i1]) + J.rem[i2]) / 3.0f;
+      if (endrem) endrem[ray] = ((r0 + r1) + r2) / 3.0f;
       if (range) range[ray] = t;
       if (tri_out) tri_out[ray] = face;
     } else if (flags & LT_TRACE_WRITE_MISSES) {
